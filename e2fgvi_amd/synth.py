@@ -1,0 +1,187 @@
+"""Checkpoint layout + deterministic synthetic weights / clips.
+
+``state_spec`` lists the reference checkpoint format (names, shapes, order) that the
+drop-in ``InpaintGenerator`` must keep (reference model/e2fgvi.py:134-208,
+model/modules/feat_prop.py:61-79, tfocal_transformer.py:19-72,150-208,402-464,
+flow_comp.py:49-82,172-215).  ``synth_state_dict`` fills that layout with values that depend
+only on (key, seed) -- not on module construction order or on the torch RNG stream -- so the
+very same weights can be rebuilt on the GPU box, loaded into the reference (in the build
+container, to make golden fixtures) and into this implementation.
+
+kind="default": the distribution of the reference's random init (e2fgvi.py:29-68,203-208):
+    Conv/Linear weights N(0, 0.02), biases 0, DCN weight U(+-1/sqrt(C*9)), conv_offset[-1]
+    zero, LayerNorm (1, 0), sc.bias 0, SPyNet kaiming(fan_out) (mmcv ConvModule default).
+kind="stress": O(1) activations, non-trivial DCN offsets / masks / biases, so that a 1e-3
+    absolute check actually bites.
+"""
+import math
+import zlib
+from collections import OrderedDict
+
+import torch
+
+MODELS = ("e2fgvi", "e2fgvi_hq")
+
+
+def rolled_valid_index():
+    """int64[120]: positions kept from the four rolled 5x9 windows (tl,tr,bl,br); reference
+    tfocal_transformer.py:169-180 registers it as buffer ``attn.valid_ind_rolled``."""
+    idx = []
+    for n, (top, left) in enumerate(((True, True), (True, False), (False, True), (False, False))):
+        for r in range(5):
+            for c in range(9):
+                # tl keeps rows >= 3 or cols >= 5 ... expressed per roll direction
+                in_r = (r >= 5 - 2) if top else (r < 2)
+                in_c = (c >= 9 - 4) if left else (c < 4)
+                if in_r or in_c:
+                    idx.append(n * 45 + r * 9 + c)
+    return torch.tensor(idx, dtype=torch.int64)
+
+
+def state_spec(model="e2fgvi"):
+    """OrderedDict name -> (shape, dtype) in the reference's state_dict order."""
+    assert model in MODELS
+    f32 = torch.float32
+    s = OrderedDict()
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"] = ((co, ci, k, k), f32)
+        s[name + ".bias"] = ((co,), f32)
+
+    def lin(name, co, ci):
+        s[name + ".weight"] = ((co, ci), f32)
+        s[name + ".bias"] = ((co,), f32)
+
+    for i, (co, ci) in zip(range(0, 18, 2), ((64, 3), (64, 64), (128, 64), (256, 128), (384, 256),
+                                             (512, 320), (384, 192), (256, 80), (128, 512))):
+        conv("encoder.layers.%d" % i, co, ci, 3)
+    conv("decoder.0.conv", 128, 128, 3)
+    conv("decoder.2", 64, 128, 3)
+    conv("decoder.4.conv", 64, 64, 3)
+    conv("decoder.6", 3, 64, 3)
+    for d in ("backward_", "forward_"):
+        p = "feat_prop_module.deform_align." + d
+        conv(p, 128, 256, 3)
+        conv(p + ".conv_offset.0", 128, 388, 3)
+        conv(p + ".conv_offset.2", 128, 128, 3)
+        conv(p + ".conv_offset.4", 128, 128, 3)
+        conv(p + ".conv_offset.6", 432, 128, 3)
+    for i, d in enumerate(("backward_", "forward_")):
+        p = "feat_prop_module.backbone." + d
+        conv(p + ".0", 128, (2 + i) * 128, 3)
+        conv(p + ".2", 128, 128, 3)
+    conv("feat_prop_module.fusion", 128, 256, 1)
+    lin("ss.embedding", 512, 6272)
+    if model == "e2fgvi":
+        s["sc.bias"] = ((128, 60, 108), f32)
+        lin("sc.embedding", 6272, 512)
+    else:
+        lin("sc.embedding", 6272, 512)
+        conv("sc.bias_conv", 128, 128, 3)
+    for i in range(8):
+        p = "transformer.%d." % i
+        lin(p + "pool_layers.0", 1, 45)
+        s[p + "norm1.weight"] = ((512,), f32)
+        s[p + "norm1.bias"] = ((512,), f32)
+        s[p + "attn.valid_ind_rolled"] = ((120,), torch.int64)
+        lin(p + "attn.qkv", 1536, 512)
+        lin(p + "attn.proj", 512, 512)
+        s[p + "norm2.weight"] = ((512,), f32)
+        s[p + "norm2.bias"] = ((512,), f32)
+        lin(p + "mlp.conv1.0", 1960, 512)
+        lin(p + "mlp.conv2.1", 512, 1960)
+    s["update_spynet.mean"] = ((1, 3, 1, 1), f32)
+    s["update_spynet.std"] = ((1, 3, 1, 1), f32)
+    for lv in range(6):
+        for j, (co, ci) in enumerate(((32, 8), (64, 32), (32, 64), (16, 32), (2, 16))):
+            conv("update_spynet.basic_module.%d.basic_module.%d.conv" % (lv, j), co, ci, 7)
+    return s
+
+
+def _gen(key, seed):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def synth_state_dict(model="e2fgvi", kind="default", seed=0):
+    assert kind in ("default", "stress")
+    sd = OrderedDict()
+    for key, (shape, dtype) in state_spec(model).items():
+        g = _gen(key, seed)
+        if key.endswith("valid_ind_rolled"):
+            sd[key] = rolled_valid_index()
+            continue
+        if key == "update_spynet.mean":
+            sd[key] = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+            continue
+        if key == "update_spynet.std":
+            sd[key] = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+            continue
+        is_w = key.endswith(".weight")
+        is_norm = ".norm1." in key or ".norm2." in key
+        is_dcn_main = key.startswith("feat_prop_module.deform_align.") and "conv_offset" not in key
+        is_last_off = ".conv_offset.6." in key
+        is_spy = key.startswith("update_spynet.")
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        r = torch.randn(shape, generator=g)
+        if kind == "default":
+            if is_norm:
+                v = torch.ones(shape) if is_w else torch.zeros(shape)
+            elif key == "sc.bias" or not is_w or is_last_off:
+                v = torch.zeros(shape)
+            elif is_dcn_main:
+                v = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            elif is_spy:
+                fan_out = shape[0] * shape[2] * shape[3]
+                v = r * math.sqrt(2.0 / fan_out)
+            else:
+                v = r * 0.02
+        else:
+            if is_norm:
+                v = 1 + 0.1 * r if is_w else 0.1 * r
+            elif key == "sc.bias":
+                v = 0.5 * r
+            elif "pool_layers" in key:
+                v = (1.0 / 45 + 0.02 * r) if is_w else 0.1 * r
+            elif is_last_off:
+                # raw outputs O(0.3): 10*tanh gives residual offsets of a few pixels, masks vary
+                v = r * (0.3 / math.sqrt(fan_in)) if is_w else 0.2 * r
+            elif is_spy:
+                # keep SPyNet flows at a few pixels: default kaiming gain gives ~30 px at random init
+                v = r * (0.7 / math.sqrt(fan_in)) if is_w else 0.05 * r
+            elif is_w:
+                gain = 1.0 if (key.startswith("ss.") or ".attn." in key
+                               or ".mlp." in key or "fusion" in key) else 1.3
+                if key.startswith("sc.embedding"):
+                    gain = 0.3          # the fold sums up to 9 overlapping patches
+                if key.startswith("decoder."):
+                    gain = 0.25 if key.startswith("decoder.6") else 0.9   # keep tanh unsaturated
+                v = r * (gain / math.sqrt(fan_in))
+            else:
+                v = 0.1 * r
+        sd[key] = v.to(dtype).contiguous()
+    return sd
+
+
+def synth_clip(b=1, t=10, h=240, w=432, seed=0, moving=False, smooth=True):
+    """Synthetic masked clip as in BASELINE.md section 3: frames in [-1,1], box mask
+    [H/4:H/2, W/4:W/2] = 1 (optionally moving 2 px / frame), masked = frames * (1 - mask)
+    (reference test.py:155).  ``smooth`` low-pass filters the noise so SPyNet sees structure."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    if smooth:
+        low = torch.rand(b, 3, h // 8 + 2, w // 8 + 2, generator=g)
+        base = torch.nn.functional.interpolate(low, size=(h + 32, w + 32), mode="bilinear", align_corners=True)
+        frames = torch.stack([base[:, :, 2 * i:2 * i + h, 3 * i % 32:3 * i % 32 + w] for i in range(t)], 1)
+        frames = frames + 0.1 * torch.rand(b, t, 3, h, w, generator=g)
+        frames = (frames / 1.1) * 2 - 1
+    else:
+        frames = torch.rand(b, t, 3, h, w, generator=g) * 2 - 1
+    mask = torch.zeros(b, t, 1, h, w)
+    for i in range(t):
+        s = 2 * i if moving else 0
+        mask[:, i, :, h // 4 + s:h // 2 + s, w // 4 + s:w // 2 + s] = 1
+    return (frames * (1 - mask)).contiguous(), mask
