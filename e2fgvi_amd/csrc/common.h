@@ -1,0 +1,85 @@
+// Shared device/host helpers for libe2fgvi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/e2fgvi_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void e2fgvi_set_error(const char* fmt, ...);
+
+#define E2_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            e2fgvi_set_error(__VA_ARGS__);     \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define E2_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            e2fgvi_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA tile product shared by the conv and the deformable-conv kernels.
+//
+// One wave owns a (TM*32) x (TN*32) block of the output tile.  v_mfma_f32_32x32x2_f32 operand
+// maps (cdna guide section 3): lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in register r.
+//
+// The K order inside a tile is free as long as A and B agree, so each half-wave (h = l>>5) takes
+// a run of 4 consecutive k (one ds_read_b128) and feeds 4 consecutive MFMAs from it:
+//   step (m8, e): lanes of half h use k = 8*m8 + 4*h + e.
+// LDS images:  A: [BM rows][LDA = BK+4 floats]  (row padding makes the b128 reads conflict-free)
+//              B: [BK/4][BN][4]                (k-quad interleaved, lane-linear b128 reads)
+// ---------------------------------------------------------------------------------------------
+template <int TM, int TN, int BK, int LDA, int BN>
+__device__ __forceinline__ void mma_ktile(const float* __restrict__ sA, const float* __restrict__ sB,
+                                          f32x16 (&acc)[TM][TN], int a_row0, int b_col0, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m8 = 0; m8 < BK / 8; ++m8) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            a[tm] = *reinterpret_cast<const f32x4*>(sA + (a_row0 + tm * 32 + i) * LDA + (2 * m8 + h) * 4);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            b[tn] = *reinterpret_cast<const f32x4*>(sB + ((2 * m8 + h) * BN + b_col0 + tn * 32 + i) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+    }
+}
+
+// XCD-aware bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): gives every XCD a
+// contiguous run of logical tiles so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == E2FGVI_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == E2FGVI_ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == E2FGVI_ACT_TANH) return tanhf(v);
+    return v;
+}

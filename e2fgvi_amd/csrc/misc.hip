@@ -1,0 +1,495 @@
+// HBM-bound helper kernels of the E2FGVI forward (gfx950): layout transforms, bilinear resizes,
+// flow warps, LayerNorm, window pooling and the fold/unfold gathers.  All are pure data movement
+// with a few flops per byte: the rules that matter are coalesced 16-byte accesses along the
+// channel axis (NHWC) and no intermediate copies.  Reference call sites: include/e2fgvi_hip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int NTH = 256;
+
+// ------------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int ld,
+                                    float scale, float shift) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int c = c0 + r, p = p0 + threadIdx.x;
+        tile[r][threadIdx.x] = (c < C && p < HW) ? src[((long long)n * C + c) * HW + p] * scale + shift : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int p = p0 + r, c = c0 + threadIdx.x;
+        if (p < HW && c < ld) dst[((long long)n * HW + p) * ld + c] = (c < C) ? tile[threadIdx.x][r] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int p = p0 + r, c = c0 + threadIdx.x;
+        tile[r][threadIdx.x] = (c < C && p < HW) ? src[((long long)n * HW + p) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int c = c0 + r, p = p0 + threadIdx.x;
+        if (c < C && p < HW) dst[((long long)n * C + c) * HW + p] = tile[threadIdx.x][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ resize
+// torch upsample_bilinear2d index rule
+__device__ __forceinline__ void src_index(int d, float scale, int align, int in, int& i0, int& i1, float& l1) {
+    float s = align ? scale * (float)d : fmaxf(scale * ((float)d + 0.5f) - 0.5f, 0.f);
+    i0 = min((int)s, in - 1);
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ src, int src_nchw, int src_ld, float* __restrict__ dst,
+                                       int dst_ld, int N, int C, int H, int W, int Ho, int Wo, int align, float sh,
+                                       float sw, const float* __restrict__ scale, const float* __restrict__ shift,
+                                       long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    long long r = idx / C;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(oy, sh, align, H, y0, y1, ly);
+    src_index(ox, sw, align, W, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v00, v01, v10, v11;
+    if (src_nchw) {
+        const float* b = src + ((long long)n * C + c) * H * W;
+        v00 = b[y0 * W + x0]; v01 = b[y0 * W + x1]; v10 = b[y1 * W + x0]; v11 = b[y1 * W + x1];
+    } else {
+        const float* b = src + (long long)n * H * W * src_ld + c;
+        v00 = b[((long long)y0 * W + x0) * src_ld]; v01 = b[((long long)y0 * W + x1) * src_ld];
+        v10 = b[((long long)y1 * W + x0) * src_ld]; v11 = b[((long long)y1 * W + x1) * src_ld];
+    }
+    float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    if (scale) v *= scale[c];
+    if (shift) v += shift[c];
+    dst[(((long long)n * Ho + oy) * Wo + ox) * dst_ld + c] = v;
+}
+
+__global__ void avgpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int Ho = H / 2, Wo = W / 2;
+    const int c = (int)(idx % C);
+    long long r = idx / C;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long long n = r / Ho;
+    const float* b = src + ((n * H + 2 * oy) * W + 2 * ox) * C + c;
+    dst[idx] = (b[0] + b[C] + b[(long long)W * C] + b[(long long)W * C + C]) * 0.25f;
+}
+
+// ------------------------------------------------------------------------------------------ SPyNet
+// one thread per (pair, y, x)
+__global__ void spynet_level_input_kernel(const float* __restrict__ pyr, const int* __restrict__ ref_idx,
+                                          const int* __restrict__ supp_idx, const float* __restrict__ flow_prev,
+                                          float* __restrict__ out, int Np, int h, int w) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Np * h * w) return;
+    const int x = (int)(idx % w);
+    const int y = (int)((idx / w) % h);
+    const int n = (int)(idx / ((long long)w * h));
+    float fu = 0.f, fv = 0.f;
+    if (flow_prev) {   // flow_up = 2 * bilinear x2 (align_corners=True) of the previous level
+        const int hp = h / 2, wp = w / 2;
+        const float sh = hp > 1 ? (float)(hp - 1) / (float)(h - 1) : 0.f;
+        const float sw = wp > 1 ? (float)(wp - 1) / (float)(w - 1) : 0.f;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_index(y, sh, 1, hp, y0, y1, ly);
+        src_index(x, sw, 1, wp, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* b = flow_prev + (long long)n * hp * wp * 2;
+        const float2 a00 = *reinterpret_cast<const float2*>(b + (y0 * wp + x0) * 2);
+        const float2 a01 = *reinterpret_cast<const float2*>(b + (y0 * wp + x1) * 2);
+        const float2 a10 = *reinterpret_cast<const float2*>(b + (y1 * wp + x0) * 2);
+        const float2 a11 = *reinterpret_cast<const float2*>(b + (y1 * wp + x1) * 2);
+        fu = 2.f * (hy * (hx * a00.x + lx * a01.x) + ly * (hx * a10.x + lx * a11.x));
+        fv = 2.f * (hy * (hx * a00.y + lx * a01.y) + ly * (hx * a10.y + lx * a11.y));
+    }
+    const float* rimg = pyr + (long long)ref_idx[n] * h * w * 4;
+    const float* simg = pyr + (long long)supp_idx[n] * h * w * 4;
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(rimg + ((long long)y * w + x) * 4);
+    // border-padded bilinear warp (grid_sample padding_mode='border', align_corners=True)
+    float px = fminf(fmaxf((float)x + fu, 0.f), (float)(w - 1));
+    float py = fminf(fmaxf((float)y + fv, 0.f), (float)(h - 1));
+    const float fx = floorf(px), fy = floorf(py);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    const float lx = px - fx, ly = py - fy, hx = 1.f - lx, hy = 1.f - ly;
+    const f32x4 s00 = *reinterpret_cast<const f32x4*>(simg + ((long long)y0 * w + x0) * 4);
+    const f32x4 s01 = *reinterpret_cast<const f32x4*>(simg + ((long long)y0 * w + x1) * 4);
+    const f32x4 s10 = *reinterpret_cast<const f32x4*>(simg + ((long long)y1 * w + x0) * 4);
+    const f32x4 s11 = *reinterpret_cast<const f32x4*>(simg + ((long long)y1 * w + x1) * 4);
+    const f32x4 sv = s00 * (hy * hx) + s01 * (hy * lx) + s10 * (ly * hx) + s11 * (ly * lx);
+    float* o = out + idx * 8;
+    f32x4 o0 = {rv[0], rv[1], rv[2], sv[0]};
+    f32x4 o1 = {sv[1], sv[2], fu, fv};
+    *reinterpret_cast<f32x4*>(o) = o0;
+    *reinterpret_cast<f32x4*>(o + 4) = o1;
+}
+
+// ------------------------------------------------------------------------------------------ propagation
+struct Bil {
+    long long o00, o01, o10, o11;   // pixel offsets (in pixels) of the 4 corners, clamped
+    float w00, w01, w10, w11;       // weights, zero for corners outside the image
+};
+__device__ __forceinline__ Bil bil_zeros(float px, float py, int H, int W) {
+    Bil b;
+    const float fx = floorf(px), fy = floorf(py);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float lx = px - fx, ly = py - fy, hx = 1.f - lx, hy = 1.f - ly;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    // positions far outside (or NaN) give no valid corner
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    b.o00 = (long long)cy0 * W + cx0; b.o01 = (long long)cy0 * W + cx1;
+    b.o10 = (long long)cy1 * W + cx0; b.o11 = (long long)cy1 * W + cx1;
+    b.w00 = (vy0 && vx0) ? hy * hx : 0.f;
+    b.w01 = (vy0 && vx1) ? hy * lx : 0.f;
+    b.w10 = (vy1 && vx0) ? ly * hx : 0.f;
+    b.w11 = (vy1 && vx1) ? ly * lx : 0.f;
+    return b;
+}
+
+// thread = (pixel, 4-channel chunk); C/4 threads per pixel
+__global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const float* __restrict__ f2, int f2_ld,
+                                 const float* __restrict__ flow_a, const float* __restrict__ flow_b,
+                                 long long flow_img_stride, float* __restrict__ cond, float* __restrict__ flows, int N,
+                                 int H, int W, int C) {
+    const int cq = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * H * W * cq) return;
+    const int c4 = (int)(idx % cq);
+    const long long pix = idx / cq;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long long)W * H));
+    const long long ip = (long long)y * W + x;
+    const float* fa = flow_a + n * flow_img_stride;
+    const float2 f1 = *reinterpret_cast<const float2*>(fa + ip * 2);
+    const Bil b1 = bil_zeros((float)x + f1.x, (float)y + f1.y, H, W);
+    float2 fl2 = make_float2(0.f, 0.f);
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c2 = z;
+    if (flow_b) {
+        const float* fb = flow_b + n * flow_img_stride;
+        const float2 a00 = *reinterpret_cast<const float2*>(fb + b1.o00 * 2);
+        const float2 a01 = *reinterpret_cast<const float2*>(fb + b1.o01 * 2);
+        const float2 a10 = *reinterpret_cast<const float2*>(fb + b1.o10 * 2);
+        const float2 a11 = *reinterpret_cast<const float2*>(fb + b1.o11 * 2);
+        fl2.x = f1.x + (a00.x * b1.w00 + a01.x * b1.w01 + a10.x * b1.w10 + a11.x * b1.w11);
+        fl2.y = f1.y + (a00.y * b1.w00 + a01.y * b1.w01 + a10.y * b1.w10 + a11.y * b1.w11);
+        const Bil b2 = bil_zeros((float)x + fl2.x, (float)y + fl2.y, H, W);
+        const float* s2 = f2 + (long long)n * H * W * f2_ld + c4 * 4;
+        c2 = *reinterpret_cast<const f32x4*>(s2 + b2.o00 * f2_ld) * b2.w00 +
+             *reinterpret_cast<const f32x4*>(s2 + b2.o01 * f2_ld) * b2.w01 +
+             *reinterpret_cast<const f32x4*>(s2 + b2.o10 * f2_ld) * b2.w10 +
+             *reinterpret_cast<const f32x4*>(s2 + b2.o11 * f2_ld) * b2.w11;
+    }
+    const float* s1 = fp + (long long)n * H * W * fp_ld + c4 * 4;
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(s1 + b1.o00 * fp_ld) * b1.w00 +
+                     *reinterpret_cast<const f32x4*>(s1 + b1.o01 * fp_ld) * b1.w01 +
+                     *reinterpret_cast<const f32x4*>(s1 + b1.o10 * fp_ld) * b1.w10 +
+                     *reinterpret_cast<const f32x4*>(s1 + b1.o11 * fp_ld) * b1.w11;
+    float* co = cond + pix * (2 * C);
+    *reinterpret_cast<f32x4*>(co + c4 * 4) = c1;
+    *reinterpret_cast<f32x4*>(co + C + c4 * 4) = c2;
+    if (c4 == 0) {
+        f32x4 fo = {f1.x, f1.y, fl2.x, fl2.y};
+        *reinterpret_cast<f32x4*>(flows + pix * 4) = fo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; C = 256 * VPL
+template <int VPL>
+__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ y, long long rows, int C) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * C;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = v[i] - mean;
+        q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / (float)C + 1e-5f);
+    float* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (i * 64 + lane) * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + (i * 64 + lane) * 4);
+        *reinterpret_cast<f32x4*>(yr + (i * 64 + lane) * 4) = v[i] * rstd * g + bb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ window pooling
+__global__ void window_pool_kernel(const float* __restrict__ x, const float* __restrict__ w45,
+                                   const float* __restrict__ bias1, float* __restrict__ pooled, int BT, int fh, int fw,
+                                   int C) {
+    const int cq = C / 4;
+    const int nWw = fw / 9, nWh = fh / 5;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)BT * nWh * nWw * cq) return;
+    const int c4 = (int)(idx % cq);
+    long long r = idx / cq;
+    const int wx = (int)(r % nWw);
+    r /= nWw;
+    const int wy = (int)(r % nWh);
+    const long long bt = r / nWh;
+    const float b = bias1[0];
+    f32x4 acc = {b, b, b, b};
+    for (int py = 0; py < 5; ++py)
+        for (int px = 0; px < 9; ++px) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((bt * fh + wy * 5 + py) * fw + wx * 9 + px) * C + c4 * 4);
+            acc = acc + v * w45[py * 9 + px];
+        }
+    *reinterpret_cast<f32x4*>(pooled + idx * 4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------ fold / unfold (7,3,3)
+// Patch channel order used by these kernels is [tap = ki*7+kj][c] (the Linear weights feeding /
+// consuming them are permuted accordingly at pack time), so a tap's C channels are contiguous.
+__device__ __forceinline__ void fold_range(int Y, int L, int& l_lo, int& l_hi) {
+    // l such that 0 <= Y + 3 - 3l <= 6
+    const int lo = Y - 3;                    // 3l >= Y-3
+    l_lo = lo <= 0 ? 0 : (lo + 2) / 3;
+    l_hi = min((Y + 3) / 3, L - 1);
+}
+
+template <bool NORMALISE>
+__global__ void fold_kernel(const float* __restrict__ emb, const float* __restrict__ bias_hwc,
+                            const float* __restrict__ residual, float* __restrict__ dst, int F, int fh, int fw, int H,
+                            int W, int C) {
+    const int cq = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)F * H * W * cq) return;
+    const int c4 = (int)(idx % cq);
+    long long r = idx / cq;
+    const int X = (int)(r % W);
+    r /= W;
+    const int Y = (int)(r % H);
+    const long long f = r / H;
+    int ly0, ly1, lx0, lx1;
+    fold_range(Y, fh, ly0, ly1);
+    fold_range(X, fw, lx0, lx1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int row_len = 49 * C;
+    for (int ly = ly0; ly <= ly1; ++ly) {
+        const int ki = Y + 3 - 3 * ly;
+        for (int lx = lx0; lx <= lx1; ++lx) {
+            const int kj = X + 3 - 3 * lx;
+            acc = acc + *reinterpret_cast<const f32x4*>(emb + ((f * fh + ly) * fw + lx) * row_len + (ki * 7 + kj) * C + c4 * 4);
+        }
+    }
+    if (NORMALISE) {
+        const float cnt = (float)((ly1 - ly0 + 1) * (lx1 - lx0 + 1));
+        acc = acc / cnt;
+    }
+    const long long o = ((f * H + Y) * W + X) * C + c4 * 4;
+    if (bias_hwc) acc = acc + *reinterpret_cast<const f32x4*>(bias_hwc + ((long long)Y * W + X) * C + c4 * 4);
+    if (residual) acc = acc + *reinterpret_cast<const f32x4*>(residual + o);
+    *reinterpret_cast<f32x4*>(dst + o) = acc;
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+__global__ void unfold_gelu_kernel(const float* __restrict__ folded, float* __restrict__ out, int F, int fh, int fw,
+                                   int H, int W, int C) {
+    const int cq = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)F * fh * fw * 49 * cq) return;
+    const int c4 = (int)(idx % cq);
+    long long r = idx / cq;
+    const int tap = (int)(r % 49);
+    r /= 49;
+    const int lx = (int)(r % fw);
+    r /= fw;
+    const int ly = (int)(r % fh);
+    const long long f = r / fh;
+    const int Y = 3 * ly - 3 + tap / 7, X = 3 * lx - 3 + tap % 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        v = *reinterpret_cast<const f32x4*>(folded + ((f * H + Y) * W + X) * C + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + idx * 4) = v;
+}
+
+inline unsigned blocks_for(long long total) { return (unsigned)cdiv64(total, NTH); }
+
+}  // namespace
+
+extern "C" int e2fgvi_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
+                                   float scale, float shift, void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, E2FGVI_EINVAL, "nchw_to_nhwc: bad arguments");
+    dim3 grid(cdiv(H * W, 32), cdiv(ld, 32), N), block(32, 8);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, src, dst, C, H * W, ld, scale, shift);
+    E2_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int e2fgvi_nhwc_to_nchw(const float* src, int32_t ld, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                                   void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, E2FGVI_EINVAL, "nhwc_to_nchw: bad arguments");
+    dim3 grid(cdiv(H * W, 32), cdiv(C, 32), N), block(32, 8);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, block, 0, (hipStream_t)stream, src, ld, dst, C, H * W);
+    E2_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_t src_ld, float* dst, int32_t dst_ld,
+                                      int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                      int32_t align_corners, const float* scale, const float* shift, void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && dst_ld >= C &&
+                   (src_nchw || src_ld >= C),
+               E2FGVI_EINVAL, "resize_bilinear: bad arguments");
+    float sh, sw;
+    if (align_corners) {
+        sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+        sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    } else {
+        sh = (float)H / (float)Ho;
+        sw = (float)W / (float)Wo;
+    }
+    const long long total = (long long)N * Ho * Wo * C;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src, src_nchw,
+                       src_ld, dst, dst_ld, N, C, H, W, Ho, Wo, align_corners, sh, sw, scale, shift, total);
+    E2_LAUNCH_CHECK("resize_bilinear");
+    return 0;
+}
+
+extern "C" int e2fgvi_avgpool2_nhwc(const float* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, E2FGVI_EINVAL,
+               "avgpool2: bad arguments");
+    const long long total = (long long)N * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src, dst, H, W, C, total);
+    E2_LAUNCH_CHECK("avgpool2");
+    return 0;
+}
+
+extern "C" int e2fgvi_spynet_level_input(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx,
+                                         const float* flow_prev, float* out, int32_t Np, int32_t h, int32_t w,
+                                         void* stream) {
+    E2_REQUIRE(pyr && ref_idx && supp_idx && out && Np > 0 && h > 0 && w > 0, E2FGVI_EINVAL, "spynet_level_input: bad arguments");
+    E2_REQUIRE(!flow_prev || (h % 2 == 0 && w % 2 == 0), E2FGVI_EINVAL, "spynet_level_input: odd level size");
+    const long long total = (long long)Np * h * w;
+    hipLaunchKernelGGL(spynet_level_input_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, pyr, ref_idx,
+                       supp_idx, flow_prev, out, Np, h, w);
+    E2_LAUNCH_CHECK("spynet_level_input");
+    return 0;
+}
+
+extern "C" int e2fgvi_prop_cond(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,
+                                const float* flow_a, const float* flow_b, int64_t flow_img_stride, float* cond,
+                                float* flows, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(feat_prop && flow_a && cond && flows && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && fp_ld % 4 == 0,
+               E2FGVI_EINVAL, "prop_cond: bad arguments");
+    E2_REQUIRE(!flow_b || (feat_n2 && f2_ld % 4 == 0), E2FGVI_EINVAL, "prop_cond: flow_b needs feat_n2");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(prop_cond_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
+                       feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, cond, flows, N, H, W, C);
+    E2_LAUNCH_CHECK("prop_cond");
+    return 0;
+}
+
+extern "C" int e2fgvi_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t C,
+                                void* stream) {
+    E2_REQUIRE(x && gamma && beta && y && rows > 0, E2FGVI_EINVAL, "layernorm: bad arguments");
+    E2_REQUIRE(C == 256 || C == 512 || C == 768 || C == 1024, E2FGVI_EUNSUP, "layernorm: C must be 256/512/768/1024");
+    const int wpb = 4;
+    dim3 grid((unsigned)cdiv64(rows, wpb)), block(64 * wpb);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C / 256) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+    }
+    E2_LAUNCH_CHECK("layernorm");
+    return 0;
+}
+
+extern "C" int e2fgvi_window_pool(const float* x, const float* w45, const float* bias1, float* pooled, int32_t BT,
+                                  int32_t fh, int32_t fw, int32_t C, void* stream) {
+    E2_REQUIRE(x && w45 && bias1 && pooled && BT > 0 && fh > 0 && fw > 0 && fh % 5 == 0 && fw % 9 == 0 && C % 4 == 0,
+               E2FGVI_EINVAL, "window_pool: bad arguments");
+    const long long total = (long long)BT * (fh / 5) * (fw / 9) * (C / 4);
+    hipLaunchKernelGGL(window_pool_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, x, w45, bias1, pooled,
+                       BT, fh, fw, C);
+    E2_LAUNCH_CHECK("window_pool");
+    return 0;
+}
+
+static int check_fold(const char* name, int F, int fh, int fw, int H, int W, int C) {
+    E2_REQUIRE(F > 0 && C > 0 && C % 4 == 0, E2FGVI_EINVAL, "%s: bad arguments", name);
+    E2_REQUIRE(fh == (H + 6 - 7) / 3 + 1 && fw == (W + 6 - 7) / 3 + 1, E2FGVI_EINVAL,
+               "%s: token grid %dx%d inconsistent with %dx%d", name, fh, fw, H, W);
+    return 0;
+}
+
+extern "C" int e2fgvi_ffn_fold(const float* hid, float* folded, int32_t F, int32_t fh, int32_t fw, int32_t H, int32_t W,
+                               int32_t C, void* stream) {
+    E2_REQUIRE(hid && folded, E2FGVI_EINVAL, "ffn_fold: null pointer");
+    if (int rc = check_fold("ffn_fold", F, fh, fw, H, W, C)) return rc;
+    const long long total = (long long)F * H * W * (C / 4);
+    hipLaunchKernelGGL(fold_kernel<true>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, hid,
+                       (const float*)nullptr, (const float*)nullptr, folded, F, fh, fw, H, W, C);
+    E2_LAUNCH_CHECK("ffn_fold");
+    return 0;
+}
+
+extern "C" int e2fgvi_ffn_unfold_gelu(const float* folded, float* out, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                                      int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(folded && out, E2FGVI_EINVAL, "ffn_unfold_gelu: null pointer");
+    if (int rc = check_fold("ffn_unfold_gelu", F, fh, fw, H, W, C)) return rc;
+    const long long total = (long long)F * fh * fw * 49 * (C / 4);
+    hipLaunchKernelGGL(unfold_gelu_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, folded, out, F, fh,
+                       fw, H, W, C);
+    E2_LAUNCH_CHECK("ffn_unfold_gelu");
+    return 0;
+}
+
+extern "C" int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* residual, float* dst, int32_t F,
+                                    int32_t fh, int32_t fw, int32_t H, int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(emb && dst, E2FGVI_EINVAL, "softcomp_fold: null pointer");
+    if (int rc = check_fold("softcomp_fold", F, fh, fw, H, W, C)) return rc;
+    const long long total = (long long)F * H * W * (C / 4);
+    hipLaunchKernelGGL(fold_kernel<false>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, emb, bias_hwc,
+                       residual, dst, F, fh, fw, H, W, C);
+    E2_LAUNCH_CHECK("softcomp_fold");
+    return 0;
+}

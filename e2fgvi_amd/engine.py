@@ -1,0 +1,353 @@
+"""Device-side execution plan of the E2FGVI / E2FGVI-HQ inference forward on MI355X.
+
+``Engine`` is built once from a checkpoint-format ``state_dict`` (reference format):
+it re-lays-out every weight for the HIP kernels and then runs the forward as a sequence of
+C-ABI kernel launches (ops.py).  The staging mirrors the reference's module boundaries so each
+stage can be checked against the oracle on the same inputs:
+
+    flows()      e2fgvi.py:210-234 + flow_comp.py:84-169      SPyNet, both directions batched
+    encode()     e2fgvi.py:96-109                             9 convs, grouped concat by pointers
+    propagate()  feat_prop.py:81-149, :35-58                  2 x l_t sequential steps
+    transformer()tfocal_transformer.py:466-536, :210-399      8 blocks, fused focal attention
+    compose()    tfocal_transformer.py:65-72 (+ e2fgvi.py:258)
+    decode()     e2fgvi.py:126-150, :261-262
+
+All activations are NHWC fp32; nothing here computes on the CPU or through torch ops -- torch only
+owns the buffers (and does index-only copies when clips are batched).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedDcn, PackedLinear
+
+WIN = (5, 9)
+
+
+def token_grid(h, w):
+    """Unfold(7, stride 3, pad 3) output grid (tfocal_transformer.py:30-37)."""
+    return (h + 6 - 7) // 3 + 1, (w + 6 - 7) // 3 + 1
+
+
+def build_key_table(fh, fw, valid_ind_rolled):
+    """Per-window key references for the fused attention kernel.
+
+    Row ``win`` lists, for one frame, the keys window ``win`` attends to besides nothing else:
+    its own 45 tokens, the 120 ring tokens of the four circularly rolled maps (positions from
+    ``valid_ind_rolled``; wrap-around and the 12 duplicates kept exactly as torch.roll +
+    window_partition produce them, tfocal_transformer.py:235-273) as ``y*fw+x`` >= 0, then the
+    valid pooled windows of the 5x9 neighbourhood (:328-333) as ``-(index+1)``.  ``nkeys`` is the
+    count; the other pooled slots are the zero-padded ones (score -100).
+    """
+    nwh, nww = fh // WIN[0], fw // WIN[1]
+    ex = (WIN[0] // 2, WIN[1] // 2)
+    shifts = ((-ex[0], -ex[1]), (-ex[0], ex[1]), (ex[0], -ex[1]), (ex[0], ex[1]))   # tl, tr, bl, br
+    vi = [int(v) for v in valid_ind_rolled]
+    tab = np.zeros((nwh * nww, 212), np.int32)
+    nk = np.zeros((nwh * nww,), np.int32)
+    for wy in range(nwh):
+        for wx in range(nww):
+            refs = []
+            for p in range(45):
+                refs.append((wy * 5 + p // 9) * fw + wx * 9 + p % 9)
+            for v in vi:
+                n, p = divmod(v, 45)
+                sy, sx = shifts[n]
+                # rolled[y,x] = k[(y - sy) % fh, (x - sx) % fw]
+                y = (wy * 5 + p // 9 - sy) % fh
+                x = (wx * 9 + p % 9 - sx) % fw
+                refs.append(y * fw + x)
+            for ki in range(5):
+                for kj in range(9):
+                    py, px = wy - 2 + ki, wx - 4 + kj
+                    if 0 <= py < nwh and 0 <= px < nww:
+                        refs.append(-(py * nww + px + 1))
+            w = wy * nww + wx
+            nk[w] = len(refs)
+            tab[w, :len(refs)] = refs
+    return tab, nk
+
+
+class Engine:
+    def __init__(self, state_dict, model="e2fgvi", device="cuda"):
+        self.hq = model == "e2fgvi_hq"
+        self.device = torch.device(device)
+        sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
+        self.sd = sd
+        f = lambda k: sd[k].float().contiguous()
+
+        # ---- encoder (e2fgvi.py:75-94)
+        w0 = torch.zeros(64, 4, 3, 3, device=self.device)
+        w0[:, :3] = f("encoder.layers.0.weight")
+        enc = [PackedConv(w0, f("encoder.layers.0.bias"), [4], stride=2, pad=1)]
+        for i, (cpg, g, s) in zip((2, 4, 6, 8, 10, 12, 14, 16),
+                                  (([64], 1, 1), ([64], 1, 2), ([128], 1, 1), ([256], 1, 1), ([128, 192], 2, 1),
+                                   ([64, 96], 4, 1), ([32, 48], 8, 1), ([256, 256], 1, 1))):
+            enc.append(PackedConv(f("encoder.layers.%d.weight" % i), f("encoder.layers.%d.bias" % i), cpg, groups=g,
+                                  stride=s, pad=1))
+        self.enc = enc
+
+        # ---- decoder (e2fgvi.py:143-150)
+        self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1),
+                    PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1),
+                    PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1),
+                    PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
+
+        # ---- propagation (feat_prop.py:61-79, :15-33)
+        self.prop = {}
+        for d, nparts in (("backward_", 2), ("forward_", 3)):
+            p = "feat_prop_module.deform_align.%s." % d
+            # conv_offset.0 input = cat(cond_n1, cur, cond_n2, flow_1, flow_2): sources (cond|0), cur, (cond|128), flows4
+            off = [PackedConv(f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias"), [128, 128, 128, 4], pad=1),
+                   PackedConv(f(p + "conv_offset.2.weight"), f(p + "conv_offset.2.bias"), [128], pad=1),
+                   PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1),
+                   PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1)]
+            dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1)
+            b = "feat_prop_module.backbone.%s." % d
+            bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1),
+                  PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1)]
+            self.prop[d] = (off, dcn, bb)
+        self.fusion = PackedConv(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128])
+
+        # ---- soft split / composite (tfocal_transformer.py:19-72)
+        self.ss = PackedConv(f("ss.embedding.weight").view(512, 128, 7, 7), f("ss.embedding.bias"), [128], stride=3, pad=3)
+        # patch channel order c*49+tap -> tap*128+c (private layout of the fold kernels)
+        wsc = f("sc.embedding.weight").view(128, 49, 512).permute(1, 0, 2).reshape(6272, 512).contiguous()
+        bsc = f("sc.embedding.bias").view(128, 49).t().reshape(6272).contiguous()
+        self.sc = PackedLinear(wsc, bsc)
+        if self.hq:
+            self.sc_bias_conv = PackedConv(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1)
+            self.sc_bias_hwc = None
+        else:
+            self.sc_bias_hwc = f("sc.bias").permute(1, 2, 0).contiguous()
+
+        # ---- transformer blocks
+        self.blocks = []
+        for i in range(8):
+            p = "transformer.%d." % i
+            w1 = f(p + "mlp.conv1.0.weight").view(40, 49, 512).permute(1, 0, 2).reshape(1960, 512).contiguous()
+            b1 = f(p + "mlp.conv1.0.bias").view(40, 49).t().reshape(1960).contiguous()
+            w2 = f(p + "mlp.conv2.1.weight").view(512, 40, 49).permute(0, 2, 1).reshape(512, 1960).contiguous()
+            self.blocks.append(dict(
+                pool_w=f(p + "pool_layers.0.weight").view(45), pool_b=f(p + "pool_layers.0.bias"),
+                n1w=f(p + "norm1.weight"), n1b=f(p + "norm1.bias"), n2w=f(p + "norm2.weight"), n2b=f(p + "norm2.bias"),
+                qkv=PackedLinear(f(p + "attn.qkv.weight"), f(p + "attn.qkv.bias")),
+                proj=PackedLinear(f(p + "attn.proj.weight"), f(p + "attn.proj.bias")),
+                fc1=PackedLinear(w1, b1), fc2=PackedLinear(w2, f(p + "mlp.conv2.1.bias")),
+                valid=sd[p + "attn.valid_ind_rolled"].cpu().tolist()))
+
+        # ---- SPyNet (flow_comp.py:49-82,172-215)
+        self.spy = []
+        for lv in range(6):
+            convs = []
+            for j, cin in enumerate((8, 32, 64, 32, 16)):
+                p = "update_spynet.basic_module.%d.basic_module.%d.conv." % (lv, j)
+                convs.append(PackedConv(f(p + "weight"), f(p + "bias"), [cin], pad=3))
+            self.spy.append(convs)
+        mean = f("update_spynet.mean").view(3)
+        std = f("update_spynet.std").view(3)
+        one = torch.ones(1, device=self.device)
+        self.spy_scale = torch.cat([1.0 / std, one]).contiguous()
+        self.spy_shift = torch.cat([-mean / std, 0 * one]).contiguous()
+        self.half = torch.full((4,), 0.5, device=self.device)
+        self._tables = {}
+        self._zeros = {}
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def _zero(self, shape):
+        key = tuple(shape)
+        if key not in self._zeros:
+            self._zeros[key] = torch.zeros(key, dtype=torch.float32, device=self.device)
+        return self._zeros[key]
+
+    def _table(self, fh, fw, blk):
+        key = (fh, fw, tuple(blk["valid"]))
+        if key not in self._tables:
+            tab, nk = build_key_table(fh, fw, blk["valid"])
+            self._tables[key] = (torch.from_numpy(tab).to(self.device), torch.from_numpy(nk).to(self.device))
+        return self._tables[key]
+
+    # ------------------------------------------------------------------ flows
+    def flows(self, frames, l_t):
+        """frames: [b,t,3,H,W] in [-1,1].  Returns (fwd, bwd) NHWC [b, l_t-1, h, w, 2]."""
+        b, t, c, H, W = frames.shape
+        h, w = H // 4, W // 4
+        local = frames[:, :l_t].reshape(b * l_t, c, H, W)
+        if not local.is_contiguous():
+            local = local.contiguous()
+        small = ops.resize_bilinear(local, (h, w), True, src_nchw=True, out_ld=4, scale=self.half, shift=self.half)
+        w_up = w if w % 32 == 0 else 32 * (w // 32 + 1)
+        h_up = h if h % 32 == 0 else 32 * (h // 32 + 1)
+        pyr = [ops.resize_bilinear(small, (h_up, w_up), False, channels=3, out_ld=4, scale=self.spy_scale,
+                                   shift=self.spy_shift)]
+        for _ in range(5):
+            pyr.append(ops.avgpool2(pyr[-1]))
+        pyr = pyr[::-1]
+        ref, supp = [], []
+        for bi in range(b):
+            for i in range(l_t - 1):
+                ref.append(bi * l_t + i); supp.append(bi * l_t + i + 1)
+        nf = len(ref)
+        ref, supp = ref + supp, supp + ref
+        ref_idx = torch.tensor(ref, dtype=torch.int32, device=self.device)
+        supp_idx = torch.tensor(supp, dtype=torch.int32, device=self.device)
+        flow = None
+        for lv in range(6):
+            inp = ops.spynet_level_input(pyr[lv], ref_idx, supp_idx, flow)
+            cv = self.spy[lv]
+            x = cv[0]([inp], act=ACT_RELU)
+            x = cv[1]([x], act=ACT_RELU)
+            x = cv[2]([x], act=ACT_RELU)
+            x = cv[3]([x], act=ACT_RELU)
+            flow = cv[4]([x], residual=inp, res_coff=6)
+        sc = torch.tensor([float(w) / float(w_up), float(h) / float(h_up)], dtype=torch.float32, device=self.device)
+        flow = ops.resize_bilinear(flow, (h, w), False, scale=sc)
+        fwd = flow[:nf].view(b, l_t - 1, h, w, 2)
+        bwd = flow[nf:].view(b, l_t - 1, h, w, 2)
+        return fwd, bwd
+
+    # ------------------------------------------------------------------ encoder
+    def encode(self, frames):
+        b, t, c, H, W = frames.shape
+        x = ops.nchw_to_nhwc(frames.reshape(b * t, c, H, W).contiguous(), ld=4)
+        e = self.enc
+        lr = dict(act=ACT_LRELU, slope=0.2)
+        x = e[0]([x], **lr)
+        x = e[1]([x], **lr)
+        x = e[2]([x], **lr)
+        x0 = e[3]([x], **lr)
+        x = e[4]([x0], **lr)
+        for k in (5, 6, 7, 8):
+            x = e[k]([x0, x], **lr)
+        return x                                            # [b*t, h, w, 128]
+
+    # ------------------------------------------------------------------ propagation
+    def propagate(self, loc, flows_a, flows_b):
+        """loc: [l_t, b, h, w, 128] frame-major local features.  flows_a / flows_b: NHWC [b,l_t-1,h,w,2]; they are
+        bound positionally like the reference (e2fgvi.py:249-250): flows_a drives 'backward_', flows_b 'forward_'.
+        Returns the propagated features [l_t, b, h, w, 128]."""
+        l_t, b, h, w, ch = loc.shape
+        dev = loc.device
+        feats = {}
+        zero = self._zero((b, h, w, ch))
+        lk = dict(act=ACT_LRELU, slope=0.1)
+        for name, flows in (("backward_", flows_a), ("forward_", flows_b)):
+            off_convs, dcn, bb = self.prop[name]
+            store = torch.empty((l_t, b, h, w, ch), dtype=torch.float32, device=dev)
+            order = list(range(l_t))
+            if name == "backward_":
+                order = order[::-1]
+            img_stride = (l_t - 1) * h * w * 2
+            hist = []                       # feature tensors in processing order
+            feat_prop = zero
+            for i, idx in enumerate(order):
+                cur = loc[idx]
+                if i > 0:
+                    flow_a = flows[0, i - 1]
+                    flow_b = flows[0, i - 2] if i > 1 else None
+                    feat_n2 = hist[-2] if i > 1 else None
+                    cond, fl = ops.prop_cond(feat_prop, feat_n2, flow_a, flow_b, img_stride)
+                    x = off_convs[0]([(cond, 0), cur, (cond, ch), fl], **lk)
+                    x = off_convs[1]([x], **lk)
+                    x = off_convs[2]([x], **lk)
+                    raw = off_convs[3]([x])
+                    feat_prop = dcn([feat_prop, feat_n2 if feat_n2 is not None else zero], raw, flows=fl,
+                                    max_residue=10.0)
+                srcs = [cur, feats["backward_"][idx], feat_prop] if name == "forward_" else [cur, feat_prop]
+                y = bb[0](srcs, **lk)
+                feat_prop = bb[1]([y], residual=feat_prop, out=store[idx])
+                hist.append(feat_prop)
+            feats[name] = store
+        out = self.fusion([feats["backward_"].view(l_t * b, h, w, ch), feats["forward_"].view(l_t * b, h, w, ch)],
+                          residual=loc.view(l_t * b, h, w, ch))
+        return out.view(l_t, b, h, w, ch)
+
+    # ------------------------------------------------------------------ transformer
+    def soft_split(self, feat):
+        return self.ss([feat])                               # [b*t, fh, fw, 512]
+
+    def block(self, i, x, b, t, fh, fw, hw):
+        """x: [b*t*fh*fw, 512] tokens in (b,t,y,x) order."""
+        blk = self.blocks[i]
+        H, W = hw
+        tab, nk = self._table(fh, fw, blk)
+        n1 = ops.layernorm(x, blk["n1w"], blk["n1b"])
+        pooled = ops.window_pool(n1, blk["pool_w"], blk["pool_b"], b * t, fh, fw)
+        qkv = blk["qkv"](n1)
+        kvp = blk["qkv"](pooled)
+        att = ops.focal_attention(qkv, kvp, tab, nk, b, t, fh, fw)
+        x1 = blk["proj"](att, residual=x)
+        n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"])
+        hid = blk["fc1"](n2)
+        folded = ops.ffn_fold(hid, b * t, fh, fw, H, W, 40)
+        unf = ops.ffn_unfold_gelu(folded, fh, fw, out=hid)
+        return blk["fc2"](unf, residual=x1), x1
+
+    def compose(self, tokens, enc, b, t, fh, fw):
+        """SoftComp + residual with the encoder features (tfocal_transformer.py:65-72, e2fgvi.py:258)."""
+        _, h, w, ch = enc.shape
+        emb = self.sc(tokens)
+        if self.hq:
+            folded = ops.softcomp_fold(emb, b * t, fh, fw, h, w, ch)
+            return self.sc_bias_conv([folded], residual=enc)
+        return ops.softcomp_fold(emb, b * t, fh, fw, h, w, ch, bias_hwc=self.sc_bias_hwc, residual=enc)
+
+    # ------------------------------------------------------------------ decoder
+    def decode(self, x):
+        n, h, w, _ = x.shape
+        lr = dict(act=ACT_LRELU, slope=0.2)
+        d = self.dec
+        x = ops.resize_bilinear(x, (2 * h, 2 * w), True)
+        x = d[0]([x], **lr)
+        x = d[1]([x], **lr)
+        x = ops.resize_bilinear(x, (4 * h, 4 * w), True)
+        x = d[2]([x], **lr)
+        return d[3]([x], act=ACT_TANH, out_nchw=True)
+
+    # ------------------------------------------------------------------ whole forward
+    def forward(self, frames, l_t, trace=None):
+        b, t, c, H, W = frames.shape
+        if H % 4 or W % 4:
+            raise ValueError("H and W must be multiples of 4")
+        h, w = H // 4, W // 4
+        fh, fw = token_grid(h, w)
+        if fh % 5 or fw % 9:
+            raise ValueError("token grid %dx%d is not a multiple of (5,9): pad H to a multiple of 60 and W to a "
+                             "multiple of 108 (reference test.py:156-165)" % (fh, fw))
+        if not self.hq and (h, w) != (60, 108):
+            raise ValueError("model 'e2fgvi' is fixed to 432x240 inputs (sc.bias is [128,60,108]); use e2fgvi_hq")
+        if not (2 <= l_t <= t):
+            raise ValueError("num_local_frames must be in [2, t]")
+        frames = ops._chk(frames.float().contiguous(), "masked_frames")
+        fwd, bwd = self.flows(frames, l_t)
+        enc = self.encode(frames)
+        ch = enc.shape[3]
+        if trace is not None:
+            trace["flow_fwd"], trace["flow_bwd"], trace["enc"] = fwd, bwd, enc.clone()
+        enc5 = enc.view(b, t, h, w, ch)
+        if b == 1:
+            loc = enc5[0, :l_t].unsqueeze(1)                 # view: [l_t, 1, h, w, C]
+            prop = self.propagate(loc, fwd, bwd)
+            enc5[0, :l_t].copy_(prop[:, 0])
+        else:
+            loc = enc5[:, :l_t].permute(1, 0, 2, 3, 4).contiguous()
+            prop = self.propagate(loc, fwd, bwd)
+            enc5[:, :l_t].copy_(prop.permute(1, 0, 2, 3, 4))
+        if trace is not None:
+            trace["prop"] = enc.clone()
+        tok = self.soft_split(enc).view(b * t * fh * fw, 512)
+        if trace is not None:
+            trace["tokens0"] = tok.clone()
+        for i in range(8):
+            tok, x1 = self.block(i, tok, b, t, fh, fw, (h, w))
+            if trace is not None:
+                trace["block%d_attn_out" % i] = x1
+                trace["tokens%d" % (i + 1)] = tok
+        dec_in = self.compose(tok, enc, b, t, fh, fw)
+        if trace is not None:
+            trace["dec_in"] = dec_in
+        out = self.decode(dec_in)
+        flows_out = (ops.nhwc_to_nchw(fwd.reshape(b * (l_t - 1), h, w, 2)).view(b, l_t - 1, 2, h, w),
+                     ops.nhwc_to_nchw(bwd.reshape(b * (l_t - 1), h, w, 2)).view(b, l_t - 1, 2, h, w))
+        return out, flows_out

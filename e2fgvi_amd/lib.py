@@ -1,0 +1,101 @@
+"""ctypes binding of libe2fgvi_hip.so -- the C ABI declared in include/e2fgvi_hip.h.
+
+There is deliberately NO fallback: if the HIP library is missing the import of the product path
+fails loudly (build it with ``python -m e2fgvi_amd.build`` or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libe2fgvi_hip.so")
+
+MAX_SRC = 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+_fp = C.c_void_p   # device pointers travel as plain addresses
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src", _fp * MAX_SRC), ("src_ld", C.c_int32 * MAX_SRC), ("src_coff", C.c_int32 * MAX_SRC),
+        ("src_cpg", C.c_int32 * MAX_SRC), ("nsrc", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("groups", C.c_int32), ("Cout", C.c_int32), ("bk", C.c_int32),
+        ("wpacked", _fp), ("bias", _fp), ("residual", _fp), ("res_ld", C.c_int32), ("res_coff", C.c_int32),
+        ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("dst_nchw", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32),
+    ]
+
+
+class MdcnDesc(C.Structure):
+    _fields_ = [
+        ("src", _fp * 2), ("src_ld", C.c_int32 * 2), ("src_c", C.c_int32 * 2), ("nsrc", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+        ("deform_groups", C.c_int32), ("Cout", C.c_int32),
+        ("offset", _fp), ("off_ld", C.c_int32), ("mask", _fp), ("mask_ld", C.c_int32),
+        ("flows", _fp), ("max_residue", C.c_float),
+        ("wpacked", _fp), ("bias", _fp),
+        ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/e2fgvi_hip.h declares
+_i32, _i64, _f = C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "e2fgvi_last_error": (C.c_char_p, []),
+    "e2fgvi_abi_version": (C.c_int, []),
+    "e2fgvi_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "e2fgvi_packed_conv_weight_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32]),
+    "e2fgvi_pack_conv_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _fp]),
+    "e2fgvi_mdcn_nhwc": (C.c_int, [C.POINTER(MdcnDesc), _fp]),
+    "e2fgvi_packed_dcn_weight_size": (_i64, [_i32, _i32, _i32, _i32]),
+    "e2fgvi_pack_dcn_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_focal_attention": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_nchw_to_nhwc": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
+    "e2fgvi_nhwc_to_nchw": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_resize_bilinear": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp]),
+    "e2fgvi_avgpool2_nhwc": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_spynet_level_input": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
+    "e2fgvi_prop_cond": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i64, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_layernorm": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _fp]),
+    "e2fgvi_window_pool": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_ffn_fold": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_ffn_unfold_gelu": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_softcomp_fold": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "libe2fgvi_hip.so not found at %s -- the MI355X kernels are mandatory (no CPU / eager "
+            "fallback exists).  Build them: python -m e2fgvi_amd.build" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().e2fgvi_last_error()
+        raise HipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

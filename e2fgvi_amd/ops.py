@@ -1,0 +1,361 @@
+"""Host-side operator layer: torch tensors in, libe2fgvi_hip.so kernels out.
+
+torch is used only as device-memory owner and stream provider; all arithmetic happens in the
+hand-written HIP kernels behind the C ABI (include/e2fgvi_hip.h).  Activations are NHWC
+``[N, H, W, ld]`` fp32 contiguous CUDA tensors.  Every wrapper validates device / dtype / layout
+and raises on error -- there is no eager fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _L
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = _L.ACT_NONE, _L.ACT_RELU, _L.ACT_LRELU, _L.ACT_TANH
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA (ROCm) tensor -- the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def empty_nhwc(n, h, w, c, device):
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------ conv / linear
+class PackedConv:
+    """A conv / linear layer with weights re-laid-out once for the MFMA kernel.
+
+    weight: torch OIHW ``[Cout, sum(cpg), KH, KW]`` (a Linear weight ``[Cout, Cin]`` is 1x1).
+    cpg:    channels per group contributed by each source of the virtual input concat.
+    """
+
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None):
+        lib = _L.load()
+        if weight.dim() == 2:
+            weight = weight[:, :, None, None]
+        w = _chk(weight.detach().float().contiguous(), "weight")
+        self.Cout, cin_g, self.KH, self.KW = w.shape
+        self.cpg = [int(c) for c in cpg]
+        if sum(self.cpg) != cin_g:
+            raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
+        self.groups, self.stride, self.pad = groups, stride, pad
+        if bk is None:
+            bk = 32 if all(c % 32 == 0 for c in self.cpg) else 16
+        self.bk = bk
+        arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+        n = lib.e2fgvi_packed_conv_weight_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, bk)
+        if n < 0:
+            _L.check(int(n), "packed_conv_weight_size")
+        self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
+        _L.check(lib.e2fgvi_pack_conv_weight(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
+                                             len(self.cpg), arr, bk, _stream()), "pack_conv_weight")
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+    def __call__(self, sources, out=None, out_coff=0, residual=None, res_coff=0, act=ACT_NONE, slope=0.0,
+                 out_nchw=False, tile=0):
+        """sources: list of NHWC tensors or (tensor, channel_offset) pairs, one per cpg entry."""
+        lib = _L.load()
+        d = _L.ConvDesc()
+        srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
+        if len(srcs) != len(self.cpg):
+            raise ValueError("expected %d sources, got %d" % (len(self.cpg), len(srcs)))
+        N, H, W, _ = srcs[0][0].shape
+        for i, (t, coff) in enumerate(srcs):
+            _chk(t, "source %d" % i)
+            if t.dim() != 4 or tuple(t.shape[:3]) != (N, H, W):
+                raise ValueError("source %d shape %s does not match [%d,%d,%d,*]" % (i, tuple(t.shape), N, H, W))
+            d.src[i] = t.data_ptr()
+            d.src_ld[i] = t.shape[3]
+            d.src_coff[i] = coff
+            d.src_cpg[i] = self.cpg[i]
+        d.nsrc = len(srcs)
+        Ho, Wo = self.out_hw(H, W)
+        d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
+        d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
+        d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
+        d.wpacked = self.wpacked.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        dev = srcs[0][0].device
+        if out is None:
+            out = (torch.empty((N, self.Cout, Ho, Wo), dtype=torch.float32, device=dev) if out_nchw
+                   else empty_nhwc(N, Ho, Wo, self.Cout, dev))
+        _chk(out, "out")
+        if out_nchw:
+            if tuple(out.shape) != (N, self.Cout, Ho, Wo):
+                raise ValueError("NCHW out shape %s != %s" % (tuple(out.shape), (N, self.Cout, Ho, Wo)))
+            d.dst_ld, d.dst_coff, d.dst_nchw = 0, 0, 1
+        else:
+            if out.dim() != 4 or tuple(out.shape[:3]) != (N, Ho, Wo):
+                raise ValueError("out shape %s != [%d,%d,%d,*]" % (tuple(out.shape), N, Ho, Wo))
+            d.dst_ld, d.dst_coff, d.dst_nchw = out.shape[3], out_coff, 0
+        d.dst = out.data_ptr()
+        if residual is not None:
+            _chk(residual, "residual")
+            if residual.dim() != 4 or tuple(residual.shape[:3]) != (N, Ho, Wo):
+                raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
+            d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
+        d.act, d.slope, d.tile = act, slope, tile
+        _L.check(lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+        return out
+
+
+class PackedLinear(PackedConv):
+    """y[rows, Cout] = x[rows, Cin] @ W^T + b (+ residual), rows treated as 1x1 images."""
+
+    def __init__(self, weight, bias, bk=None):
+        super().__init__(weight, bias, [weight.shape[1]], bk=bk)
+
+    def __call__(self, x, out=None, residual=None, act=ACT_NONE, slope=0.0, tile=0):
+        _chk(x, "x")
+        rows = x.numel() // x.shape[-1]
+        x4 = x.view(rows, 1, 1, x.shape[-1])
+        if out is None:
+            out = torch.empty((rows, self.Cout), dtype=torch.float32, device=x.device)
+        o4 = out.view(rows, 1, 1, out.shape[-1])
+        r4 = None if residual is None else residual.view(rows, 1, 1, residual.shape[-1])
+        super().__call__([x4], out=o4, residual=r4, act=act, slope=slope, tile=tile)
+        return out
+
+
+# ------------------------------------------------------------------------------------------ deformable conv
+class PackedDcn:
+    def __init__(self, weight, bias, deform_groups, stride=1, pad=0, dil=1):
+        lib = _L.load()
+        w = _chk(weight.detach().float().contiguous(), "weight")
+        self.Cout, self.C, self.KH, self.KW = w.shape
+        self.dg, self.stride, self.pad, self.dil = deform_groups, stride, pad, dil
+        n = lib.e2fgvi_packed_dcn_weight_size(self.Cout, self.C, self.KH, self.KW)
+        if n < 0:
+            _L.check(int(n), "packed_dcn_weight_size")
+        self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
+        _L.check(lib.e2fgvi_pack_dcn_weight(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
+                                            deform_groups, _stream()), "pack_dcn_weight")
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+
+    def __call__(self, sources, offset, mask=None, off_cols=None, flows=None, max_residue=10.0, out=None, tile=0):
+        """sources: 1 or 2 NHWC tensors (virtual concat).  offset: [N,Ho,Wo,*] pixel-major; if ``mask`` is None
+        the mask words live in the same tensor starting at column dg*2*K (raw conv_offset layout)."""
+        lib = _L.load()
+        d = _L.MdcnDesc()
+        N, H, W, _ = sources[0].shape
+        ctot = 0
+        for i, t in enumerate(sources):
+            _chk(t, "source %d" % i)
+            d.src[i], d.src_ld[i], d.src_c[i] = t.data_ptr(), t.shape[3], t.shape[3]
+            ctot += t.shape[3]
+        if ctot != self.C:
+            raise ValueError("sources carry %d channels, weight expects %d" % (ctot, self.C))
+        d.nsrc = len(sources)
+        Ho = (H + 2 * self.pad - (self.dil * (self.KH - 1) + 1)) // self.stride + 1
+        Wo = (W + 2 * self.pad - (self.dil * (self.KW - 1) + 1)) // self.stride + 1
+        d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
+        d.KH, d.KW, d.stride, d.pad, d.dil = self.KH, self.KW, self.stride, self.pad, self.dil
+        d.deform_groups, d.Cout = self.dg, self.Cout
+        K = self.KH * self.KW
+        _chk(offset, "offset")
+        if tuple(offset.shape[:3]) != (N, Ho, Wo):
+            raise ValueError("offset shape %s" % (tuple(offset.shape),))
+        d.offset, d.off_ld = offset.data_ptr(), offset.shape[3]
+        if mask is None:
+            if offset.shape[3] < self.dg * 3 * K:
+                raise ValueError("fused offset tensor too narrow")
+            d.mask, d.mask_ld = offset.data_ptr() + 4 * self.dg * 2 * K, offset.shape[3]
+        else:
+            _chk(mask, "mask")
+            d.mask, d.mask_ld = mask.data_ptr(), mask.shape[3]
+        if flows is not None:
+            _chk(flows, "flows")
+            if tuple(flows.shape) != (N, Ho, Wo, 4):
+                raise ValueError("flows must be [N,Ho,Wo,4]")
+            d.flows = flows.data_ptr()
+        d.max_residue = max_residue
+        d.wpacked = self.wpacked.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        if out is None:
+            out = empty_nhwc(N, Ho, Wo, self.Cout, sources[0].device)
+        _chk(out, "out")
+        d.dst, d.dst_ld, d.dst_coff, d.tile = out.data_ptr(), out.shape[3], 0, tile
+        _L.check(lib.e2fgvi_mdcn_nhwc(C.byref(d), _stream()), "mdcn_nhwc")
+        return out
+
+
+# ------------------------------------------------------------------------------------------ attention
+def focal_attention(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, waves=0):
+    lib = _L.load()
+    _chk(qkv, "qkv"); _chk(kv_pool, "kv_pool")
+    _chk(key_tab, "key_tab", torch.int32); _chk(nkeys, "nkeys", torch.int32)
+    rows = B * T * fh * fw
+    if tuple(qkv.shape) != (rows, 1536):
+        raise ValueError("qkv must be [%d,1536], got %s" % (rows, tuple(qkv.shape)))
+    nwin = (fh // 5) * (fw // 9)
+    if tuple(kv_pool.shape) != (B * T * nwin, 1536):
+        raise ValueError("kv_pool must be [%d,1536], got %s" % (B * T * nwin, tuple(kv_pool.shape)))
+    if key_tab.shape[0] != nwin or nkeys.shape[0] != nwin:
+        raise ValueError("key table must have %d rows" % nwin)
+    if out is None:
+        out = torch.empty((rows, 512), dtype=torch.float32, device=qkv.device)
+    _chk(out, "out")
+    _L.check(lib.e2fgvi_focal_attention(_ptr(qkv), _ptr(kv_pool), _ptr(key_tab), key_tab.shape[1], _ptr(nkeys),
+                                        _ptr(out), B, T, fh, fw, waves, _stream()), "focal_attention")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ small kernels
+def nchw_to_nhwc(x, ld=None, scale=1.0, shift=0.0):
+    lib = _L.load()
+    _chk(x, "x")
+    N, Cc, H, W = x.shape
+    ld = Cc if ld is None else ld
+    out = empty_nhwc(N, H, W, ld, x.device)
+    _L.check(lib.e2fgvi_nchw_to_nhwc(_ptr(x), _ptr(out), N, Cc, H, W, ld, scale, shift, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, channels=None):
+    lib = _L.load()
+    _chk(x, "x")
+    N, H, W, ld = x.shape
+    Cc = ld if channels is None else channels
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    _L.check(lib.e2fgvi_nhwc_to_nchw(_ptr(x), ld, _ptr(out), N, Cc, H, W, _stream()), "nhwc_to_nchw")
+    return out
+
+
+def resize_bilinear(x, out_hw, align_corners, src_nchw=False, channels=None, out_ld=None, scale=None, shift=None):
+    lib = _L.load()
+    _chk(x, "x")
+    if src_nchw:
+        N, Cc, H, W = x.shape
+        src_ld = 0
+    else:
+        N, H, W, src_ld = x.shape
+        Cc = src_ld if channels is None else channels
+    Ho, Wo = out_hw
+    out_ld = Cc if out_ld is None else out_ld
+    if out_ld > Cc:
+        out = torch.zeros((N, Ho, Wo, out_ld), dtype=torch.float32, device=x.device)
+    else:
+        out = empty_nhwc(N, Ho, Wo, out_ld, x.device)
+    for v, nm in ((scale, "scale"), (shift, "shift")):
+        if v is not None:
+            _chk(v, nm)
+            if v.numel() < Cc:
+                raise ValueError("%s needs %d entries" % (nm, Cc))
+    _L.check(lib.e2fgvi_resize_bilinear(_ptr(x), int(src_nchw), src_ld, _ptr(out), out_ld, N, Cc, H, W, Ho, Wo,
+                                        int(align_corners), _ptr(scale), _ptr(shift), _stream()), "resize_bilinear")
+    return out
+
+
+def avgpool2(x):
+    lib = _L.load()
+    _chk(x, "x")
+    N, H, W, Cc = x.shape
+    out = empty_nhwc(N, H // 2, W // 2, Cc, x.device)
+    _L.check(lib.e2fgvi_avgpool2_nhwc(_ptr(x), _ptr(out), N, H, W, Cc, _stream()), "avgpool2")
+    return out
+
+
+def spynet_level_input(pyr, ref_idx, supp_idx, flow_prev):
+    lib = _L.load()
+    _chk(pyr, "pyr"); _chk(ref_idx, "ref_idx", torch.int32); _chk(supp_idx, "supp_idx", torch.int32)
+    F_, h, w, c = pyr.shape
+    if c != 4:
+        raise ValueError("pyramid images must be NHWC4")
+    Np = ref_idx.numel()
+    if flow_prev is not None:
+        _chk(flow_prev, "flow_prev")
+        if tuple(flow_prev.shape) != (Np, h // 2, w // 2, 2):
+            raise ValueError("flow_prev must be [%d,%d,%d,2], got %s" % (Np, h // 2, w // 2, tuple(flow_prev.shape)))
+    out = empty_nhwc(Np, h, w, 8, pyr.device)
+    _L.check(lib.e2fgvi_spynet_level_input(_ptr(pyr), _ptr(ref_idx), _ptr(supp_idx), _ptr(flow_prev), _ptr(out), Np, h, w,
+                                           _stream()), "spynet_level_input")
+    return out
+
+
+def prop_cond(feat_prop, feat_n2, flow_a, flow_b, flow_img_stride, cond=None, flows=None):
+    """flow_a / flow_b: tensors whose data_ptr is image 0's [H,W,2] flow; image n is at +n*flow_img_stride floats."""
+    lib = _L.load()
+    _chk(feat_prop, "feat_prop")
+    N, H, W, Cc = feat_prop.shape
+    if cond is None:
+        cond = empty_nhwc(N, H, W, 2 * Cc, feat_prop.device)
+    if flows is None:
+        flows = empty_nhwc(N, H, W, 4, feat_prop.device)
+    f2_ld = 0
+    if flow_b is not None:
+        _chk(feat_n2, "feat_n2")
+        f2_ld = feat_n2.shape[3]
+    _L.check(lib.e2fgvi_prop_cond(_ptr(feat_prop), Cc, _ptr(feat_n2) if flow_b is not None else None, f2_ld,
+                                  C.c_void_p(flow_a.data_ptr()),
+                                  C.c_void_p(flow_b.data_ptr()) if flow_b is not None else None,
+                                  flow_img_stride, _ptr(cond), _ptr(flows), N, H, W, Cc, _stream()), "prop_cond")
+    return cond, flows
+
+
+def layernorm(x, gamma, beta, out=None):
+    lib = _L.load()
+    _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    _L.check(lib.e2fgvi_layernorm(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, Cc, _stream()), "layernorm")
+    return out
+
+
+def window_pool(x, w45, bias1, BT, fh, fw):
+    lib = _L.load()
+    _chk(x, "x"); _chk(w45, "w45"); _chk(bias1, "bias1")
+    Cc = x.shape[-1]
+    out = torch.empty((BT * (fh // 5) * (fw // 9), Cc), dtype=torch.float32, device=x.device)
+    _L.check(lib.e2fgvi_window_pool(_ptr(x), _ptr(w45), _ptr(bias1), _ptr(out), BT, fh, fw, Cc, _stream()), "window_pool")
+    return out
+
+
+def ffn_fold(hid, F_, fh, fw, H, W, Cc):
+    lib = _L.load()
+    _chk(hid, "hid")
+    out = empty_nhwc(F_, H, W, Cc, hid.device)
+    _L.check(lib.e2fgvi_ffn_fold(_ptr(hid), _ptr(out), F_, fh, fw, H, W, Cc, _stream()), "ffn_fold")
+    return out
+
+
+def ffn_unfold_gelu(folded, fh, fw, out=None):
+    lib = _L.load()
+    _chk(folded, "folded")
+    F_, H, W, Cc = folded.shape
+    if out is None:
+        out = torch.empty((F_ * fh * fw, 49 * Cc), dtype=torch.float32, device=folded.device)
+    _L.check(lib.e2fgvi_ffn_unfold_gelu(_ptr(folded), _ptr(out), F_, fh, fw, H, W, Cc, _stream()), "ffn_unfold_gelu")
+    return out
+
+
+def softcomp_fold(emb, F_, fh, fw, H, W, Cc, bias_hwc=None, residual=None):
+    lib = _L.load()
+    _chk(emb, "emb")
+    out = empty_nhwc(F_, H, W, Cc, emb.device)
+    if bias_hwc is not None:
+        _chk(bias_hwc, "bias_hwc")
+    if residual is not None:
+        _chk(residual, "residual")
+    _L.check(lib.e2fgvi_softcomp_fold(_ptr(emb), _ptr(bias_hwc), _ptr(residual), _ptr(out), F_, fh, fw, H, W, Cc,
+                                      _stream()), "softcomp_fold")
+    return out

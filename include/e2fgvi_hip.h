@@ -1,0 +1,205 @@
+/* e2fgvi_hip.h -- C ABI of libe2fgvi_hip.so (MI355X / gfx950 kernels for the E2FGVI forward).
+ *
+ * The reference (MCG-NKU/E2FGVI) is pure Python: every native instruction it executes is reached
+ * through torch / mmcv operator calls.  This header is the replacement for that operator boundary
+ * on the inference hot path: one entry point per fused stage.  Each entry
+ * cites the reference operator call it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - raw device pointers (fp32 unless stated), explicit int dims, caller-owned buffers: no
+ *     allocation, no synchronisation, no host<->device copies inside;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - activations are NHWC ("channels last"): element (n,y,x,c) at ((n*H+y)*W+x)*ld + c, where the
+ *     pixel stride `ld` (in floats) may exceed C so that callers can address channel slices;
+ *   - returns 0 on success, a negative E2FGVI_E* code on bad arguments, a positive hipError_t on a
+ *     launch failure; e2fgvi_last_error() gives the thread-local message;
+ *   - re-entrant; no global mutable state.
+ */
+#ifndef E2FGVI_HIP_H
+#define E2FGVI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2FGVI_EINVAL (-1)   /* bad argument */
+#define E2FGVI_EUNSUP (-2)   /* valid but unsupported configuration */
+
+#define E2FGVI_ACT_NONE 0
+#define E2FGVI_ACT_RELU 1
+#define E2FGVI_ACT_LRELU 2   /* slope in desc */
+#define E2FGVI_ACT_TANH 3
+
+#define E2FGVI_MAX_SRC 4
+
+const char* e2fgvi_last_error(void);
+int e2fgvi_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces torch.nn.functional.conv2d / linear at: encoder model/e2fgvi.py:75-109, decoder
+ * :143-150, SPyNet 7x7 stacks model/modules/flow_comp.py:180-215, conv_offset / backbone / fusion
+ * model/modules/feat_prop.py:20-28,73-79, SoftSplit unfold+linear tfocal_transformer.py:40-45
+ * (= 7x7 stride-3 conv), qkv/proj :221,398, FFN linears :80-81, SoftComp linear :68.
+ *
+ * The input is the *virtual channel concat* of up to 4 NHWC sources (so torch.cat copies at
+ * e2fgvi.py:101-107, feat_prop.py:36,126-136 never exist).  With `groups` > 1, group g reads
+ * channels [coff[s] + g*cpg[s], +cpg[s]) of every source s, in source order.
+ * Weights must be pre-packed with e2fgvi_pack_conv_weight using the same cpg[] / bk.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* src[E2FGVI_MAX_SRC];
+    int32_t src_ld[E2FGVI_MAX_SRC];    /* pixel stride of each source, floats (multiple of 4)      */
+    int32_t src_coff[E2FGVI_MAX_SRC];  /* first channel used by group 0 (multiple of 4)            */
+    int32_t src_cpg[E2FGVI_MAX_SRC];   /* channels per group taken from this source (mult. of 4)   */
+    int32_t nsrc;
+    int32_t N, H, W;                   /* input batch / height / width                             */
+    int32_t Ho, Wo;                    /* output height / width                                    */
+    int32_t KH, KW, stride, pad;
+    int32_t groups;
+    int32_t Cout;                      /* total output channels                                    */
+    int32_t bk;                        /* K-chunk the weights were packed for: 16 or 32            */
+    const float* wpacked;
+    const float* bias;                 /* [Cout] or NULL                                           */
+    const float* residual;             /* NHWC [N,Ho,Wo,*] added before the activation, or NULL    */
+    int32_t res_ld, res_coff;
+    float* dst;
+    int32_t dst_ld, dst_coff;
+    int32_t dst_nchw;                  /* 1: dst is plain NCHW [N,Cout,Ho,Wo] (ld/coff ignored)     */
+    int32_t act;
+    float slope;
+    int32_t tile;                      /* 0 = auto; otherwise force a tile config (tests/bench)    */
+} e2fgvi_conv_desc;
+
+int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream);
+
+/* number of floats of the packed weight buffer for the given geometry */
+int64_t e2fgvi_packed_conv_weight_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
+                                       int32_t nsrc, const int32_t* src_cpg, int32_t bk);
+/* w: reference layout [Cout, sum(cpg), KH, KW] (torch OIHW; Linear = [Cout, Cin, 1, 1]) */
+int e2fgvi_pack_conv_weight(const float* w, float* wpacked, int32_t Cout, int32_t groups,
+                            int32_t KH, int32_t KW, int32_t nsrc, const int32_t* src_cpg,
+                            int32_t bk, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Modulated deformable convolution (DCNv2), im2col-free: bilinear gather straight into LDS + MFMA.
+ * Replaces mmcv.ops.modulated_deform_conv2d (mmcv-full 1.4.8) called at
+ * model/modules/feat_prop.py:55-58.  x is the virtual concat of two NHWC sources (feat_prop |
+ * feat_n2, feat_prop.py:127).  offset: [P, dg*2*K] with (dy,dx) interleaved per tap, mask:
+ * [P, dg*K] (both pixel-major, the NHWC image of mmcv's NCHW tensors).
+ * If `flows` != NULL the kernel also applies SecondOrderDeformableAlignment's post-processing
+ * (feat_prop.py:38-53) on the fly: offset/mask are then the raw conv_offset output (o1|o2|mask),
+ * offset = max_residue * tanh(raw) + flow.flip (flow_1 for the first dg/2 groups, flow_2 for the
+ * rest), mask = sigmoid(raw); flows is [P,4] = (u1,v1,u2,v2).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* src[2];
+    int32_t src_ld[2];
+    int32_t src_c[2];                  /* channels of each source; C = sum; C/dg multiple of 16    */
+    int32_t nsrc;
+    int32_t N, H, W, Ho, Wo;
+    int32_t KH, KW, stride, pad, dil;
+    int32_t deform_groups;
+    int32_t Cout;
+    const float* offset; int32_t off_ld;
+    const float* mask;   int32_t mask_ld;
+    const float* flows;                /* optional [P,4]                                           */
+    float max_residue;
+    const float* wpacked;              /* e2fgvi_pack_dcn_weight                                   */
+    const float* bias;
+    float* dst; int32_t dst_ld, dst_coff;
+    int32_t tile;
+} e2fgvi_mdcn_desc;
+
+int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream);
+int64_t e2fgvi_packed_dcn_weight_size(int32_t Cout, int32_t C, int32_t KH, int32_t KW);
+/* w: [Cout, C, KH, KW] */
+int e2fgvi_pack_dcn_weight(const float* w, float* wpacked, int32_t Cout, int32_t C, int32_t KH,
+                           int32_t KW, int32_t deform_groups, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal focal window attention, fused (flash-style, fp32 MFMA, online softmax).
+ * Replaces WindowAttention.forward's roll/partition/cat/bmm/softmax/bmm chain,
+ * model/modules/tfocal_transformer.py:226-396 (window 5x9, 4 heads of 128).
+ *   qkv    [B*T*fh*fw, 1536]  rows in (b,t,y,x) order, columns q|k|v (tfocal_transformer.py:221-223)
+ *   kv_pool[B*T*nWin, 1536]   qkv Linear applied to the pooled window tokens (:319), rows (b,t,win)
+ *   key_tab[nWin, tab_ld]     per window: `nkeys[win]` key references per frame:
+ *                             v >= 0 : token y*fw+x of the same frame (own window + rolled ring,
+ *                                      duplicates included, :235-283);  v < 0 : pooled window -(v+1)
+ *   nkeys  [nWin]             valid references per frame; the remaining (210 - nkeys) pooled slots
+ *                             are the zero-padded ones that score exactly -100 (:301-316,378-380)
+ *   out    [B*T*fh*fw, 512]   attention output in token order (window_reverse :132 is implicit)
+ * ---------------------------------------------------------------------------------------------- */
+int e2fgvi_focal_attention(const float* qkv, const float* kv_pool, const int32_t* key_tab,
+                           int32_t tab_ld, const int32_t* nkeys, float* out, int32_t B, int32_t T,
+                           int32_t fh, int32_t fw, int32_t waves, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small HBM-bound kernels
+ * ---------------------------------------------------------------------------------------------- */
+/* [N,C,H,W] -> NHWC with pixel stride ld (channels C..ld-1 zero-filled); y = x*scale + shift */
+int e2fgvi_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t ld, float scale, float shift, void* stream);
+int e2fgvi_nhwc_to_nchw(const float* src, int32_t ld, float* dst, int32_t N, int32_t C, int32_t H,
+                        int32_t W, void* stream);
+
+/* Bilinear resize (torch F.interpolate semantics, align_corners 0/1), NHWC or NCHW source ->
+ * NHWC destination, followed by a per-channel affine y = v*scale[c] + shift[c] (scale/shift may be
+ * NULL).  Replaces e2fgvi.py:214-219 (1/4 downsample), flow_comp.py:150-167 (SPyNet resizes and
+ * flow rescale), :121-124 (flow x2) and e2fgvi.py:126-129 (decoder x2). */
+int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_t src_ld, float* dst,
+                           int32_t dst_ld, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho,
+                           int32_t Wo, int32_t align_corners, const float* scale,
+                           const float* shift, void* stream);
+
+/* 2x2 mean pooling, NHWC (flow_comp.py:101-111) */
+int e2fgvi_avgpool2_nhwc(const float* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t C,
+                         void* stream);
+
+/* SPyNet level input (flow_comp.py:117-132): for pair n, out[n,y,x,0:8] =
+ * [ref(3), warp_border(supp, flow_up)(3), flow_up(2)], flow_up = 2 * up2x_align_corners(flow_prev)
+ * (zeros when flow_prev == NULL).  pyr: [F,h,w,4] per-frame pyramid level; ref_idx/supp_idx: [Np]
+ * frame indices; flow_prev: [Np,h/2,w/2,2]. */
+int e2fgvi_spynet_level_input(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx,
+                              const float* flow_prev, float* out, int32_t Np, int32_t h, int32_t w,
+                              void* stream);
+
+/* Propagation step conditions (feat_prop.py:110-123): given feat_prop, feat_n2 [N,H,W,C] and the
+ * flow fields flow_a (=flows[:,i-1]) and flow_b (=flows[:,i-2] or NULL), all NHWC, writes
+ *   cond  [N,H,W,2C] = warp0(feat_prop, flow_n1) | warp0(feat_n2, flow_n2)   (zeros padding)
+ *   flows [N,H,W,4]  = flow_n1 | flow_n2,  flow_n2 = flow_n1 + warp0(flow_b, flow_n1) (0 if NULL)
+ * Each of the N images has its own flow image: flow_x + n*flow_img_stride. */
+int e2fgvi_prop_cond(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,
+                     const float* flow_a, const float* flow_b, int64_t flow_img_stride,
+                     float* cond, float* flows, int32_t N, int32_t H, int32_t W, int32_t C,
+                     void* stream);
+
+/* LayerNorm over the last dim (C multiple of 64, eps 1e-5, biased variance); tfocal_transformer.py
+ * :452,463,470,533 */
+int e2fgvi_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                     int32_t C, void* stream);
+
+/* Window pooling Linear(45->1) (tfocal_transformer.py:508-516): x [B*T,fh,fw,C] tokens ->
+ * pooled [B*T, fh/5, fw/9, C] */
+int e2fgvi_window_pool(const float* x, const float* w45, const float* bias1, float* pooled,
+                       int32_t BT, int32_t fh, int32_t fw, int32_t C, void* stream);
+
+/* FusionFeedForward middle (tfocal_transformer.py:92-97): hid [F*fh*fw, C*49] ->
+ * fold(7,3,3) / overlap count -> folded [F,H,W,C];  then unfold + exact GELU -> [F*fh*fw, C*49] */
+int e2fgvi_ffn_fold(const float* hid, float* folded, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                    int32_t W, int32_t C, void* stream);
+int e2fgvi_ffn_unfold_gelu(const float* folded, float* out, int32_t F, int32_t fh, int32_t fw,
+                           int32_t H, int32_t W, int32_t C, void* stream);
+
+/* SoftComp fold (tfocal_transformer.py:70-71): emb [F*fh*fw, C*49] -> overlap-ADD fold ->
+ * [F,H,W,C] + bias_hwc[H,W,C] (optional) + residual (optional, NHWC ld = C) */
+int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* residual,
+                         float* dst, int32_t F, int32_t fh, int32_t fw, int32_t H, int32_t W,
+                         int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2FGVI_HIP_H */

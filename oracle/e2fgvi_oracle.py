@@ -254,9 +254,10 @@ def rolled_valid_index():
     return torch.stack((m_tl, m_tr, m_bl, m_br), 0).flatten(0).nonzero(as_tuple=False).view(-1)
 
 
-def window_attention(sd, p, x, x_pooled):
+def window_attention(sd, p, x, x_pooled, preproj=False):
     """tfocal_transformer.py:210-399.  x: [B,T,H,W,C] (already LayerNorm'ed);
-    x_pooled: [B,nWh,nWw,T,C]."""
+    x_pooled: [B,nWh,nWw,T,C].  ``preproj`` returns the attention output before self.proj
+    ([B*nWin, T*45, C], window-major) for kernel-level tests."""
     B, T, nH, nW, C = x.shape
     ws, ex, nh = WIN, (WIN[0] // 2, WIN[1] // 2), HEADS
     hd = C // nh
@@ -308,7 +309,27 @@ def window_attention(sd, p, x, x_pooled):
     attn[:, :, :wa, off:off + wa] = attn[:, :, :wa, off:off + wa] + add
     attn = attn.softmax(-1)
     out = (attn @ v_all).transpose(1, 2).reshape(attn.shape[0], wa, C)
+    if preproj:
+        return out
     return F.linear(out, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def window_reverse(a, B, T, H, W):
+    """tfocal_transformer.py:132-147 for [B*nWin, T*45, C] window-major tokens."""
+    ws = WIN
+    a = a.view(-1, T, ws[0], ws[1], a.shape[-1])
+    return a.view(B, H // ws[0], W // ws[1], T, ws[0], ws[1], -1).permute(0, 3, 1, 4, 2, 5, 6).contiguous() \
+        .view(B, T, H, W, -1)
+
+
+def pool_windows(sd, p, xn):
+    """tfocal_transformer.py:508-516: Linear(45->1) over each window's tokens -> [B,nWh,nWw,T,C]."""
+    B, T, H, W, C = xn.shape
+    ws = WIN
+    xw = xn.view(B, T, H // ws[0], ws[0], W // ws[1], ws[1], C).permute(0, 2, 4, 1, 3, 5, 6).contiguous()
+    nWh, nWw = xw.shape[1:3]
+    xw = xw.view(B, nWh, nWw, T, ws[0] * ws[1], C).transpose(4, 5)
+    return F.linear(xw, sd[p + "pool_layers.0.weight"], sd[p + "pool_layers.0.bias"]).flatten(-2)
 
 
 def transformer_block(sd, i, x, out_hw, trace=None):
@@ -320,15 +341,9 @@ def transformer_block(sd, i, x, out_hw, trace=None):
     assert H % ws[0] == 0 and W % ws[1] == 0
     shortcut = x
     xn = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
-    xw = xn.view(B, T, H // ws[0], ws[0], W // ws[1], ws[1], C).permute(0, 2, 4, 1, 3, 5, 6).contiguous()
-    nWh, nWw = xw.shape[1:3]
-    xw = xw.view(B, nWh, nWw, T, ws[0] * ws[1], C).transpose(4, 5)
-    x_pooled = F.linear(xw, sd[p + "pool_layers.0.weight"], sd[p + "pool_layers.0.bias"]).flatten(-2)
+    x_pooled = pool_windows(sd, p, xn)
     a = window_attention(sd, p + "attn.", xn, x_pooled)
-    a = a.view(-1, T, ws[0], ws[1], C)
-    a = a.view(B, H // ws[0], W // ws[1], T, ws[0], ws[1], -1).permute(0, 3, 1, 4, 2, 5, 6).contiguous() \
-        .view(B, T, H, W, -1)
-    x = shortcut + a
+    x = shortcut + window_reverse(a, B, T, H, W)
     if trace is not None:
         trace["block%d_attn_out" % i] = x
     y = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)

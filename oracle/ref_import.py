@@ -27,21 +27,27 @@ def load_reference(name="e2fgvi"):
     if not available():
         raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
     if _REPO not in sys.path:
-        sys.path.insert(0, _REPO)          # so the shim can import oracle.dcn
+        sys.path.insert(0, _REPO)
+    import oracle.dcn  # noqa: F401  (the shim imports it; load it while the repo root is on sys.path)
     saved = {k: v for k, v in sys.modules.items() if k == "model" or k.startswith("model.")}
     saved_mmcv = {k: v for k, v in sys.modules.items() if k == "mmcv" or k.startswith("mmcv.")}
     for k in list(saved) + list(saved_mmcv):
         del sys.modules[k]
-    sys.path.insert(0, REFERENCE_ROOT)
-    sys.path.insert(0, _SHIM)
+    # The reference's ``model`` directory is a namespace package (no __init__.py); this repo's
+    # ``model`` is a regular package and would win regardless of order, so the repo root (and the
+    # implicit cwd entry) must be off sys.path while the reference is imported.
+    saved_path = list(sys.path)
+    here = {os.path.realpath(_REPO), os.path.realpath(os.getcwd())}
+    sys.path[:] = [_SHIM, REFERENCE_ROOT] + [q for q in saved_path
+                                             if q not in ("", ".") and os.path.realpath(q) not in here]
     try:
         import io, contextlib
         with contextlib.redirect_stdout(io.StringIO()):
             mod = importlib.import_module("model." + name)
         ref_mods = {k: v for k, v in sys.modules.items() if k == "model" or k.startswith("model.")}
+        assert os.path.realpath(mod.__file__).startswith(os.path.realpath(REFERENCE_ROOT)), mod.__file__
     finally:
-        sys.path.remove(REFERENCE_ROOT)
-        sys.path.remove(_SHIM)
+        sys.path[:] = saved_path
         for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
             del sys.modules[k]
         sys.modules.update(saved)

@@ -1,0 +1,122 @@
+"""Stage-level and end-to-end parity of the HIP forward against the CPU oracle (oracle/e2fgvi_oracle.py),
+on identical synthetic weights and clips.  Tolerances: the north star's fp32 max-abs 1e-3 on the output
+frames, plus scale-free per-stage checks (max err relative to the rms of the oracle tensor) that still
+bite at the reference's tiny default init."""
+import pytest
+import torch
+
+from tests.util import assert_close, err, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _setup(model, kind, hw, t, lt, b=1, seed=1):
+    key = (model, kind, hw, t, lt, b, seed)
+    if key not in _CACHE:
+        from e2fgvi_amd.synth import synth_clip, synth_state_dict
+        from oracle import e2fgvi_oracle as O
+        torch.set_num_threads(max(1, torch.get_num_threads()))
+        sd = synth_state_dict(model, kind, 0)
+        x, _ = synth_clip(b, t, hw[0], hw[1], seed=seed, moving=True)
+        tr = {}
+        out, flows = O.forward(sd, x, lt, model, tr)
+        _CACHE[key] = (sd, x, tr, out, flows)
+    return _CACHE[key]
+
+
+def _engine(model, kind, dev):
+    key = ("eng", model, kind)
+    if key not in _CACHE:
+        from e2fgvi_amd.engine import Engine
+        from e2fgvi_amd.synth import synth_state_dict
+        _CACHE[key] = Engine(synth_state_dict(model, kind, 0), model, dev)
+    return _CACHE[key]
+
+
+CFG = [("e2fgvi", "stress", (240, 432), 3, 3), ("e2fgvi_hq", "stress", (120, 216), 4, 3)]
+
+
+@pytest.mark.parametrize("model,kind,hw,t,lt", CFG)
+def test_stage_flows(dev, model, kind, hw, t, lt):
+    sd, x, tr, out, flows = _setup(model, kind, hw, t, lt)
+    eng = _engine(model, kind, dev)
+    fwd, bwd = eng.flows(x.to(dev), lt)
+    b = x.shape[0]
+    h, w = hw[0] // 4, hw[1] // 4
+    assert_close(fwd.cpu().permute(0, 1, 4, 2, 3), flows[0], 1e-3, "flow fwd")
+    assert_close(bwd.cpu().permute(0, 1, 4, 2, 3), flows[1], 1e-3, "flow bwd")
+
+
+@pytest.mark.parametrize("model,kind,hw,t,lt", CFG)
+def test_stage_encoder(dev, model, kind, hw, t, lt):
+    sd, x, tr, out, flows = _setup(model, kind, hw, t, lt)
+    eng = _engine(model, kind, dev)
+    enc = eng.encode(x.to(dev))
+    assert_close(nchw(enc.cpu()), tr["enc"], 1e-4, "encoder")
+
+
+@pytest.mark.parametrize("model,kind,hw,t,lt", CFG)
+def test_stage_propagation(dev, model, kind, hw, t, lt):
+    """fed with the oracle's encoder features and flows"""
+    sd, x, tr, out, flows = _setup(model, kind, hw, t, lt)
+    eng = _engine(model, kind, dev)
+    b = x.shape[0]
+    enc = tr["enc"]
+    _, c, h, w = enc.shape
+    loc = enc.view(b, t, c, h, w)[:, :lt].permute(1, 0, 3, 4, 2).contiguous().to(dev)     # [l_t,b,h,w,C]
+    fa = flows[0].permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    fb = flows[1].permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    prop = eng.propagate(loc, fa, fb)
+    ref = tr["prop"].view(b, t, c, h, w)[:, :lt].permute(1, 0, 3, 4, 2)
+    assert_close(prop.cpu(), ref, 2e-4, "propagation")
+
+
+@pytest.mark.parametrize("model,kind,hw,t,lt", CFG)
+def test_stage_transformer(dev, model, kind, hw, t, lt):
+    sd, x, tr, out, flows = _setup(model, kind, hw, t, lt)
+    eng = _engine(model, kind, dev)
+    from e2fgvi_amd.engine import token_grid
+    b = x.shape[0]
+    prop = tr["prop"]                                                     # [b,t,C,h,w]
+    _, _, c, h, w = prop.shape
+    fh, fw = token_grid(h, w)
+    feat = nhwc(prop.reshape(b * t, c, h, w)).to(dev)
+    tok = eng.soft_split(feat).view(-1, 512)
+    assert_close(tok.cpu(), tr["tokens0"].reshape(-1, 512), 1e-4, "soft split")
+    for i in range(8):
+        tin = tr["tokens%d" % i].reshape(-1, 512).contiguous().to(dev)
+        tout, x1 = eng.block(i, tin, b, t, fh, fw, (h, w))
+        assert_close(x1.cpu(), tr["block%d_attn_out" % i].reshape(-1, 512), 1e-4, "block %d attention" % i)
+        assert_close(tout.cpu(), tr["tokens%d" % (i + 1)].reshape(-1, 512), 1e-4, "block %d" % i)
+    dec_in = eng.compose(tr["tokens8"].reshape(-1, 512).contiguous().to(dev), feat, b, t, fh, fw)
+    assert_close(nchw(dec_in.cpu()), tr["dec_in"].reshape(b * t, c, h, w), 1e-4, "soft composite")
+    dec = eng.decode(nhwc(tr["dec_in"].reshape(b * t, c, h, w)).to(dev))
+    assert_close(dec.cpu(), out, 1e-4, "decoder")
+
+
+E2E = [("e2fgvi", "stress", (240, 432), 3, 3, 1), ("e2fgvi", "default", (240, 432), 3, 3, 1),
+       ("e2fgvi", "stress", (240, 432), 5, 3, 1), ("e2fgvi_hq", "stress", (120, 216), 4, 3, 1),
+       ("e2fgvi_hq", "default", (120, 216), 4, 4, 1), ("e2fgvi_hq", "stress", (120, 216), 3, 2, 2)]
+
+
+@pytest.mark.parametrize("model,kind,hw,t,lt,b", E2E)
+def test_end_to_end(dev, model, kind, hw, t, lt, b):
+    """the drop-in module, loaded through load_state_dict, against the oracle: max|d| <= 1e-3 (north star)"""
+    import importlib
+    sd, x, tr, out, flows = _setup(model, kind, hw, t, lt, b)
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        got, (ff, fb) = net(x.to(dev), lt)
+    assert tuple(got.shape) == (b * t, 3, hw[0], hw[1])
+    d, r = err(got, out)
+    df, rf = err(ff, flows[0])
+    db, rb = err(fb, flows[1])
+    print("e2e %s %s: out max abs %.3e (%.2e x rms), flows %.3e / %.3e" % (model, kind, d, r, df, db))
+    assert torch.isfinite(got).all()
+    assert d <= 1e-3, "output max abs err %.3e" % d
+    assert df <= 1e-3 * max(1.0, flows[0].abs().max().item()) and db <= 1e-3 * max(1.0, flows[1].abs().max().item())
+    assert r <= 2e-2, "output err relative to rms %.3e" % r

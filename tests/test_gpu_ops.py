@@ -1,0 +1,322 @@
+"""Kernel-level parity: every C-ABI kernel against plain torch fp32 CPU ops / the oracle pieces."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5      # fp32 MFMA accumulation vs CPU fp32, relative to the rms of the reference output
+
+
+def _gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def _act_ref(x, act, slope):
+    from e2fgvi_amd import ops
+    if act == ops.ACT_RELU:
+        return F.relu(x)
+    if act == ops.ACT_LRELU:
+        return F.leaky_relu(x, slope)
+    if act == ops.ACT_TANH:
+        return torch.tanh(x)
+    return x
+
+
+CONV_CASES = [
+    # N, H, W, cpg list, groups, Cout, k, stride, pad, act, residual, tile, bk
+    (2, 20, 28, [32], 1, 64, 3, 1, 1, 2, False, 0, None),
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 0, True, 1, None),
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 0, True, 1, 16),
+    (1, 30, 54, [128], 1, 128, 3, 1, 1, 2, True, 3, None),
+    (1, 30, 54, [128], 1, 128, 3, 1, 1, 2, False, 6, None),
+    (2, 24, 40, [64], 1, 64, 3, 2, 1, 2, False, 2, None),
+    (1, 30, 54, [128, 128, 128, 4], 1, 128, 3, 1, 1, 2, False, 0, None),     # conv_offset.0
+    (1, 30, 54, [128, 128], 1, 432, 3, 1, 1, 0, False, 0, None),
+    (3, 16, 24, [32, 48], 8, 256, 3, 1, 1, 2, False, 0, None),               # encoder g8
+    (2, 16, 24, [64, 96], 4, 384, 3, 1, 1, 2, False, 0, None),               # encoder g4
+    (2, 16, 24, [128, 192], 2, 512, 3, 1, 1, 2, False, 0, None),             # encoder g2
+    (2, 24, 32, [4], 1, 64, 3, 2, 1, 2, False, 0, None),                     # encoder first conv (3->4 padded)
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 0, None),                     # spynet conv 1
+    (3, 16, 32, [32], 1, 64, 7, 1, 3, 1, False, 0, None),
+    (3, 16, 32, [64], 1, 32, 7, 1, 3, 1, False, 4, None),
+    (3, 16, 32, [64], 1, 32, 7, 1, 3, 1, False, 5, None),
+    (3, 16, 32, [32], 1, 16, 7, 1, 3, 1, False, 0, None),
+    (3, 4, 8, [16], 1, 2, 7, 1, 3, 0, True, 0, None),                        # spynet last conv + residual
+    (2, 30, 54, [128], 1, 512, 7, 3, 3, 0, False, 0, None),                  # soft split
+    (2, 9, 13, [256], 1, 128, 1, 1, 0, 0, True, 0, None),                    # fusion 1x1
+    (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 0, None),                     # decoder last conv (tanh)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
+def test_conv(dev, case):
+    from e2fgvi_amd import ops
+    N, H, W, cpg, groups, Cout, k, stride, pad, act, use_res, tile, bk = case
+    g = _gen(1)
+    srcs = [torch.randn(N, groups * c, H, W, generator=g) for c in cpg]
+    cin_g = sum(cpg)
+    w = torch.randn(Cout, cin_g, k, k, generator=g) / math.sqrt(cin_g * k * k)
+    b = torch.randn(Cout, generator=g)
+    # reference: per-group interleaved concat (reference e2fgvi.py:101-107 for the encoder)
+    xcat = torch.cat([s.view(N, groups, c, H, W) for s, c in zip(srcs, cpg)], 2).view(N, groups * cin_g, H, W)
+    ref = F.conv2d(xcat, w, b, stride=stride, padding=pad, groups=groups)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res
+    ref = _act_ref(ref, act, 0.2)
+
+    layer = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=stride, pad=pad, bk=bk)
+    out = layer([nhwc(s).to(dev) for s in srcs], residual=None if res is None else nhwc(res).to(dev), act=act,
+                slope=0.2, tile=tile)
+    assert_close(nchw(out.cpu()), ref, REL, "conv")
+
+
+def test_conv_slices_and_nchw_out(dev):
+    """channel-offset sources, output into a slice of a wider buffer, NCHW store."""
+    from e2fgvi_amd import ops
+    g = _gen(2)
+    N, H, W = 2, 12, 20
+    wide = torch.randn(N, H, W, 96, generator=g)
+    w = torch.randn(40, 32, 3, 3, generator=g) / 17
+    b = torch.randn(40, generator=g)
+    ref = F.conv2d(nchw(wide)[:, 32:64], w, b, padding=1)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), [32], pad=1)
+    dst = torch.zeros(N, H, W, 64, device=dev)
+    layer([(wide.to(dev), 32)], out=dst, out_coff=16)
+    assert_close(nchw(dst.cpu())[:, 16:56], ref, REL, "slice out")
+    assert dst.cpu()[..., :16].abs().max() == 0 and dst.cpu()[..., 56:].abs().max() == 0
+    o2 = layer([(wide.to(dev), 32)], out_nchw=True)
+    assert_close(o2.cpu(), ref, REL, "nchw out")
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(450, 512, 1536), (77, 512, 512), (300, 1960, 512), (130, 512, 1960),
+                                           (64, 512, 6272)])
+def test_linear(dev, rows, cin, cout):
+    from e2fgvi_amd import ops
+    g = _gen(3)
+    x = torch.randn(rows, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(rows, cout, generator=g)
+    lin = ops.PackedLinear(w.to(dev), b.to(dev))
+    out = lin(x.to(dev), residual=r.to(dev))
+    assert_close(out.cpu(), F.linear(x, w, b) + r, REL, "linear")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("mag", [0.0, 3.0, 40.0])
+def test_mdcn_generic(dev, tile, mag):
+    """mmcv semantics with explicit offset/mask tensors (oracle/dcn.py), incl. far out-of-bounds offsets."""
+    from e2fgvi_amd import ops
+    from oracle.dcn import modulated_deform_conv2d
+    g = _gen(4)
+    N, C, H, W, Co, dg = 2, 64, 13, 19, 48, 4
+    x = torch.randn(N, C, H, W, generator=g)
+    off = torch.randn(N, dg * 18, H, W, generator=g) * mag
+    msk = torch.rand(N, dg * 9, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / 24
+    b = torch.randn(Co, generator=g)
+    ref = modulated_deform_conv2d(x, off, msk, w, b, 1, 1, 1, 1, dg)
+    layer = ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)
+    out = layer([nhwc(x).to(dev)], nhwc(off).to(dev), mask=nhwc(msk).to(dev), tile=tile)
+    assert_close(nchw(out.cpu()), ref, 5e-5, "mdcn generic")
+
+
+def test_mdcn_e2fgvi_fused(dev):
+    """the fused form used by the propagation: two sources, raw conv_offset output + flows (feat_prop.py:38-58)."""
+    from e2fgvi_amd import ops
+    from oracle.dcn import modulated_deform_conv2d
+    g = _gen(5)
+    N, H, W, dg = 1, 30, 54, 16
+    a = torch.randn(N, 128, H, W, generator=g)
+    c = torch.randn(N, 128, H, W, generator=g)
+    raw = torch.randn(N, 432, H, W, generator=g) * 0.5
+    f1 = torch.randn(N, 2, H, W, generator=g) * 2
+    f2 = torch.randn(N, 2, H, W, generator=g) * 2
+    w = torch.randn(128, 256, 3, 3, generator=g) / 48
+    b = torch.randn(128, generator=g)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    offset = 10 * torch.tanh(torch.cat((o1, o2), 1))
+    q1, q2 = torch.chunk(offset, 2, 1)
+    q1 = q1 + f1.flip(1).repeat(1, 72, 1, 1)
+    q2 = q2 + f2.flip(1).repeat(1, 72, 1, 1)
+    ref = modulated_deform_conv2d(torch.cat([a, c], 1), torch.cat([q1, q2], 1), torch.sigmoid(m), w, b, 1, 1, 1, 1, dg)
+    layer = ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)
+    flows = nhwc(torch.cat([f1, f2], 1)).to(dev)
+    for tile in (1, 2):
+        out = layer([nhwc(a).to(dev), nhwc(c).to(dev)], nhwc(raw).to(dev), flows=flows, max_residue=10.0, tile=tile)
+        assert_close(nchw(out.cpu()), ref, 5e-5, "mdcn fused tile %d" % tile)
+
+
+@pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 2, 15, 45)])
+def test_focal_attention(dev, B, T, fh, fw):
+    """fused attention vs the oracle's roll/partition/cat/softmax chain (pre-projection output)."""
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.engine import build_key_table
+    from e2fgvi_amd.synth import rolled_valid_index
+    from oracle import e2fgvi_oracle as O
+    g = _gen(6)
+    Cc = 512
+    xn = torch.randn(B, T, fh, fw, Cc, generator=g)
+    sd = {"a.qkv.weight": torch.randn(1536, Cc, generator=g) / math.sqrt(Cc) * 2.0,
+          "a.qkv.bias": torch.randn(1536, generator=g) * 0.1,
+          "pool_layers.0.weight": torch.full((1, 45), 1 / 45.) + 0.02 * torch.randn(1, 45, generator=g),
+          "pool_layers.0.bias": torch.zeros(1)}
+    xp = O.pool_windows(sd, "", xn)                                         # [B,nWh,nWw,T,C]
+    pre = O.window_attention(sd, "a.", xn, xp, preproj=True)
+    ref = O.window_reverse(pre, B, T, fh, fw).reshape(-1, Cc)
+    qkv = F.linear(xn.reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
+    kvp = F.linear(xp.permute(0, 3, 1, 2, 4).reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
+    tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
+    for waves in (0, 2, 4):
+        out = ops.focal_attention(qkv.to(dev), kvp.to(dev), torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev),
+                                  B, T, fh, fw, waves=waves)
+        assert_close(out.cpu(), ref, 5e-5, "attention waves=%d" % waves)
+
+
+def test_layout_roundtrip(dev):
+    from e2fgvi_amd import ops
+    g = _gen(7)
+    x = torch.randn(3, 37, 21, 45, generator=g)
+    y = ops.nchw_to_nhwc(x.to(dev), ld=40, scale=0.5, shift=0.25)
+    ref = F.pad(nhwc(x * 0.5 + 0.25), (0, 3))
+    assert_close(y.cpu(), ref, 1e-7, "nchw_to_nhwc")
+    z = ops.nhwc_to_nchw(y, channels=37)
+    assert_close(z.cpu(), x * 0.5 + 0.25, 1e-7, "nhwc_to_nchw")
+
+
+@pytest.mark.parametrize("align,size_in,size_out", [(True, (240, 432), (60, 108)), (False, (60, 108), (64, 128)),
+                                                    (False, (64, 128), (60, 108)), (True, (30, 54), (60, 108)),
+                                                    (False, (30, 54), (32, 64))])
+def test_resize(dev, align, size_in, size_out):
+    from e2fgvi_amd import ops
+    g = _gen(8)
+    x = torch.rand(2, 3, *size_in, generator=g)
+    sc = torch.tensor([2.0, 0.5, 1.5])
+    sh = torch.tensor([0.1, -0.2, 0.3])
+    ref = F.interpolate(x, size=size_out, mode="bilinear", align_corners=align) * sc.view(1, 3, 1, 1) + sh.view(1, 3, 1, 1)
+    out = ops.resize_bilinear(x.to(dev), size_out, align, src_nchw=True, out_ld=4, scale=sc.to(dev), shift=sh.to(dev))
+    assert_close(out.cpu()[..., :3], nhwc(ref), 2e-6, "resize nchw src")
+    assert out.cpu()[..., 3].abs().max() == 0
+    out2 = ops.resize_bilinear(nhwc(x).to(dev), size_out, align, scale=sc.to(dev), shift=sh.to(dev))
+    assert_close(out2.cpu(), nhwc(ref), 2e-6, "resize nhwc src")
+
+
+def test_avgpool(dev):
+    from e2fgvi_amd import ops
+    x = torch.randn(3, 4, 16, 24, generator=_gen(9))
+    assert_close(ops.avgpool2(nhwc(x).to(dev)).cpu(), nhwc(F.avg_pool2d(x, 2, 2)), 1e-6, "avgpool")
+
+
+def test_spynet_level_input(dev):
+    from e2fgvi_amd import ops
+    from oracle import e2fgvi_oracle as O
+    g = _gen(10)
+    Fr, h, w = 4, 16, 32
+    pyr = torch.randn(Fr, 3, h, w, generator=g)
+    ref_idx, supp_idx = [0, 1, 2, 1, 2, 3], [1, 2, 3, 0, 1, 2]
+    flow_prev = torch.randn(6, 2, h // 2, w // 2, generator=g) * 3
+    flow_up = F.interpolate(flow_prev, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
+    warped = O.flow_warp(pyr[supp_idx], flow_up.permute(0, 2, 3, 1), padding_mode="border")
+    ref = torch.cat([pyr[ref_idx], warped, flow_up], 1)
+    p4 = F.pad(nhwc(pyr), (0, 1)).to(dev)
+    out = ops.spynet_level_input(p4, torch.tensor(ref_idx, dtype=torch.int32, device=dev),
+                                 torch.tensor(supp_idx, dtype=torch.int32, device=dev), nhwc(flow_prev).to(dev))
+    assert_close(out.cpu(), nhwc(ref), 2e-5, "spynet level input")
+    out0 = ops.spynet_level_input(p4, torch.tensor(ref_idx, dtype=torch.int32, device=dev),
+                                  torch.tensor(supp_idx, dtype=torch.int32, device=dev), None)
+    ref0 = torch.cat([pyr[ref_idx], pyr[supp_idx], torch.zeros(6, 2, h, w)], 1)
+    assert_close(out0.cpu(), nhwc(ref0), 1e-6, "spynet level 0 input")
+
+
+def test_prop_cond(dev):
+    from e2fgvi_amd import ops
+    from oracle import e2fgvi_oracle as O
+    g = _gen(11)
+    b, lt, h, w, Cc = 2, 4, 15, 27, 128
+    fp = torch.randn(b, Cc, h, w, generator=g)
+    f2 = torch.randn(b, Cc, h, w, generator=g)
+    flows = torch.randn(b, lt - 1, 2, h, w, generator=g) * 4
+    i = 2
+    f_n1 = flows[:, i - 1]
+    c1 = O.flow_warp(fp, f_n1.permute(0, 2, 3, 1))
+    f_n2 = f_n1 + O.flow_warp(flows[:, i - 2], f_n1.permute(0, 2, 3, 1))
+    c2 = O.flow_warp(f2, f_n2.permute(0, 2, 3, 1))
+    fl_nhwc = flows.permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    cond, fl = ops.prop_cond(nhwc(fp).to(dev), nhwc(f2).to(dev), fl_nhwc[0, i - 1], fl_nhwc[0, i - 2], (lt - 1) * h * w * 2)
+    assert_close(cond.cpu(), nhwc(torch.cat([c1, c2], 1)), 1e-5, "cond")
+    assert_close(fl.cpu(), nhwc(torch.cat([f_n1, f_n2], 1)), 1e-5, "flows")
+    cond1, fl1 = ops.prop_cond(nhwc(fp).to(dev), None, fl_nhwc[0, 0], None, (lt - 1) * h * w * 2)
+    c1b = O.flow_warp(fp, flows[:, 0].permute(0, 2, 3, 1))
+    assert_close(cond1.cpu(), nhwc(torch.cat([c1b, torch.zeros_like(c1b)], 1)), 1e-5, "cond i=1")
+    assert_close(fl1.cpu(), nhwc(torch.cat([flows[:, 0], torch.zeros_like(flows[:, 0])], 1)), 1e-5, "flows i=1")
+
+
+def test_layernorm_and_pool(dev):
+    from e2fgvi_amd import ops
+    from oracle import e2fgvi_oracle as O
+    g = _gen(12)
+    B, T, fh, fw, Cc = 2, 3, 10, 18, 512
+    x = torch.randn(B, T, fh, fw, Cc, generator=g) * 3 + 1
+    gm, bt = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    ref = F.layer_norm(x, (Cc,), gm, bt, 1e-5)
+    out = ops.layernorm(x.view(-1, Cc).to(dev), gm.to(dev), bt.to(dev))
+    assert_close(out.cpu(), ref.view(-1, Cc), 5e-6, "layernorm")
+    sd = {"pool_layers.0.weight": torch.randn(1, 45, generator=g) * 0.1, "pool_layers.0.bias": torch.randn(1, generator=g)}
+    refp = O.pool_windows(sd, "", ref).permute(0, 3, 1, 2, 4).reshape(-1, Cc)
+    outp = ops.window_pool(out, sd["pool_layers.0.weight"].view(45).to(dev), sd["pool_layers.0.bias"].to(dev), B * T, fh, fw)
+    assert_close(outp.cpu(), refp, 1e-5, "window_pool")
+
+
+@pytest.mark.parametrize("H,W", [(60, 108), (30, 54)])
+def test_fold_unfold(dev, H, W):
+    """FFN fold/normalise/unfold/GELU and SoftComp fold vs F.fold / F.unfold (tfocal_transformer.py:92-97,70-71)."""
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.engine import token_grid
+    g = _gen(13)
+    T2T = dict(kernel_size=(7, 7), stride=(3, 3), padding=(3, 3))
+    fh, fw = token_grid(H, W)
+    Fr, Cc = 2, 40
+    hid = torch.randn(Fr, fh * fw, Cc * 49, generator=g)                      # reference channel order c*49+tap
+    norm = F.fold(torch.ones(Fr, 49, fh * fw), output_size=(H, W), **T2T)
+    folded_ref = F.fold(hid.permute(0, 2, 1), output_size=(H, W), **T2T) / norm
+    unf_ref = F.gelu(F.unfold(folded_ref, **T2T).permute(0, 2, 1))              # [Fr, n, c*49+tap]
+    hid_p = hid.view(Fr, fh * fw, Cc, 49).permute(0, 1, 3, 2).reshape(Fr * fh * fw, 49 * Cc).contiguous()
+    folded = ops.ffn_fold(hid_p.to(dev), Fr, fh, fw, H, W, Cc)
+    assert_close(folded.cpu(), nhwc(folded_ref), 1e-5, "ffn_fold")
+    unf = ops.ffn_unfold_gelu(folded, fh, fw)
+    unf_ref_p = unf_ref.reshape(Fr, fh * fw, Cc, 49).permute(0, 1, 3, 2).reshape(Fr * fh * fw, 49 * Cc)
+    assert_close(unf.cpu(), unf_ref_p, 1e-5, "ffn_unfold_gelu")
+    C2 = 128
+    emb = torch.randn(Fr, fh * fw, C2 * 49, generator=g)
+    bias = torch.randn(C2, H, W, generator=g)
+    res = torch.randn(Fr, C2, H, W, generator=g)
+    sc_ref = F.fold(emb.permute(0, 2, 1), output_size=(H, W), **T2T) + bias[None] + res
+    emb_p = emb.view(Fr, fh * fw, C2, 49).permute(0, 1, 3, 2).reshape(Fr * fh * fw, 49 * C2).contiguous()
+    out = ops.softcomp_fold(emb_p.to(dev), Fr, fh, fw, H, W, C2, bias_hwc=bias.permute(1, 2, 0).contiguous().to(dev),
+                            residual=nhwc(res).to(dev))
+    assert_close(out.cpu(), nhwc(sc_ref), 1e-5, "softcomp_fold")
+
+
+def test_bad_arguments_raise(dev):
+    """error behaviour: wrong device / dtype / geometry raise instead of silently falling back."""
+    from e2fgvi_amd import lib, ops
+    w = torch.randn(16, 8, 3, 3, device=dev)
+    layer = ops.PackedConv(w, None, [8], pad=1)
+    with pytest.raises(TypeError):
+        layer([torch.zeros(1, 4, 4, 8)])                      # CPU tensor
+    with pytest.raises(TypeError):
+        layer([torch.zeros(1, 4, 4, 8, device=dev, dtype=torch.float16)])
+    with pytest.raises(ValueError):
+        ops.PackedConv(w, None, [6], pad=1)                    # channel count mismatch
+    with pytest.raises(lib.HipError):
+        ops.PackedConv(torch.randn(16, 6, 3, 3, device=dev), None, [6], pad=1)   # cpg not a multiple of 4
+    with pytest.raises(lib.HipError):
+        ops.PackedDcn(torch.randn(8, 24, 3, 3, device=dev), None, 3)             # 8 channels per deform group
