@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Headline benchmark: inpainted frames/sec at 432x240, T=10 (BASELINE.json), fp32, on N MI355X.
+
+One "step" = one InpaintGenerator forward over this rank's batch of synthetic 432x240 T=10 clips
+(all frames local, l_t = t: the configuration that maximises propagation work), inputs
+already resident in HBM.  With N > 1 the clips are sharded over ranks (one process per GPU, RCCL) and
+every step ends with the all-gather of the output frames over xGMI; per-GPU work is fixed (weak
+scaling).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 20 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+GFLOP_PER_CLIP = {  # algorithmic conv/linear/matmul work, 2 x MAC, e2fgvi 432x240
+    (10, 10): 2039.1, (5, 5): 932.5, (10, 5): 1718.8,
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+
+
+def flops_per_clip(t, lt):
+    """analytic GFLOP (2 x MAC) per clip of the base model at 432x240 (formulas of SURVEY.md 8d)."""
+    if (t, lt) in GFLOP_PER_CLIP:
+        return GFLOP_PER_CLIP[(t, lt)]
+    H, W = 240, 432
+    p4, p2, n = (H // 4) * (W // 4), (H // 2) * (W // 2), 720
+    nw = n // 45
+    enc = t * (p2 * (64 * 27 + 64 * 576) + p4 * (128 * 576 + 256 * 1152 + 384 * 2304 + 512 * 2880 + 384 * 1728 + 256 * 720 + 128 * 4608))
+    spy = 2 * (lt - 1) * 239904 * sum(64 * 128 // 4 ** l for l in range(6))
+    off = 2 * (lt - 1) * p4 * 9 * (388 * 128 + 2 * 128 * 128 + 128 * 432)
+    dcn = 2 * (lt - 1) * p4 * 128 * 2304
+    bb = lt * p4 * 9 * (256 * 128 + 384 * 128 + 2 * 128 * 128)
+    fus = lt * p4 * 128 * 256
+    ss = 2 * t * n * 6272 * 512
+    blk = 8 * (t * n * 512 * 2048 + nw * t * (512 * 1536 + 45 * 512) + nw * 4 * (45 * t) * (210 * t) * 128 * 2 + t * n * 512 * 1960 * 2)
+    dec = t * (p2 * 9 * (128 * 128 + 128 * 64) + 4 * p2 * 9 * (64 * 64 + 64 * 3))
+    return 2e-9 * (enc + spy + off + dcn + bb + fus + ss + blk + dec)
+
+
+def cpu_baseline(sd, t, lt):
+    """The CPU restatement of the reference forward (oracle/e2fgvi_oracle.py, kind "port": the reference's own
+    Python cannot travel to the GPU box) timed on this host's cores on a bounded sample of the same workload."""
+    from e2fgvi_amd.synth import synth_clip
+    from oracle import e2fgvi_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, _ = synth_clip(1, t, 240, 432, seed=100)
+    t0 = time.perf_counter()
+    O.forward(sd, x, lt, "e2fgvi")
+    dt = time.perf_counter() - t0
+    return {"value": round(t / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "one forward of one 432x240 T=%d l_t=%d clip (%.1f s, torch CPU fp32, %d threads, no warm-up)"
+                      % (t, lt, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips-per-gpu", type=int, default=1, help="clips per forward on each GPU (reference inference: 1)")
+    ap.add_argument("--t", type=int, default=10)
+    ap.add_argument("--lt", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import importlib
+    from e2fgvi_amd import runner
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+
+    b, t, lt = args.clips_per_gpu, args.t, args.lt
+    sd = synth_state_dict("e2fgvi", "default", 0)          # random-init distribution of the reference
+    net = importlib.import_module("model.e2fgvi").InpaintGenerator()
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x, _ = synth_clip(b, t, 240, 432, seed=100 + rank)
+    x = x.to(dev)
+
+    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=not args.no_graph)
+    for _ in range(args.warmup):
+        step.run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step.run()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    frames = world * b * t * args.steps
+    value = frames / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    gflop_clip = flops_per_clip(t, lt)
+    achieved = (b * gflop_clip * args.steps / (dev_ms * 1e-3)) / 1e3        # TFLOP/s of this rank, device-timed
+    out = {
+        "metric": "inpainted frames/sec at 432x240 T=%d" % t, "value": round(value, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "e2fgvi 432x240 T=%d l_t=%d, %d clip(s) per GPU per forward, random-init weights, box mask"
+                               % (t, lt, b), "clips_per_gpu": b, "parallelism": "clip-shard x%d + all-gather of frames" % world,
+                   "hip_graph": bool(step.graphed)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "note": "whole forward: %.1f algorithmic GFLOP per clip (SURVEY.md 8d) / device time of one forward "
+                             "(hip events on the launch stream)" % gflop_clip},
+    }
+    if rank == 0:
+        dom = runner.dominant_kernel_probe(net, dev)
+        out["roofline"]["dominant_kernel"] = dom
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, t, lt)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,7 +82,7 @@ class Engine:
         enc = [PackedConv(w0, f("encoder.layers.0.bias"), [4], stride=2, pad=1)]
         for i, (cpg, g, s) in zip((2, 4, 6, 8, 10, 12, 14, 16),
                                   (([64], 1, 1), ([64], 1, 2), ([128], 1, 1), ([256], 1, 1), ([128, 192], 2, 1),
-                                   ([64, 96], 4, 1), ([32, 48], 8, 1), ([256, 256], 1, 1))):
+                                   ([64, 128], 4, 1), ([32, 48], 8, 1), ([256, 256], 1, 1))):
             enc.append(PackedConv(f("encoder.layers.%d.weight" % i), f("encoder.layers.%d.bias" % i), cpg, groups=g,
                                   stride=s, pad=1))
         self.enc = enc
@@ -184,14 +184,19 @@ class Engine:
         for _ in range(5):
             pyr.append(ops.avgpool2(pyr[-1]))
         pyr = pyr[::-1]
-        ref, supp = [], []
-        for bi in range(b):
-            for i in range(l_t - 1):
-                ref.append(bi * l_t + i); supp.append(bi * l_t + i + 1)
-        nf = len(ref)
-        ref, supp = ref + supp, supp + ref
-        ref_idx = torch.tensor(ref, dtype=torch.int32, device=self.device)
-        supp_idx = torch.tensor(supp, dtype=torch.int32, device=self.device)
+        nf = b * (l_t - 1)
+        key = ("pairs", b, l_t, h, w)
+        if key not in self._tables:          # host->device uploads happen once (HIP-graph capture safe)
+            ref, supp = [], []
+            for bi in range(b):
+                for i in range(l_t - 1):
+                    ref.append(bi * l_t + i); supp.append(bi * l_t + i + 1)
+            ref, supp = ref + supp, supp + ref
+            self._tables[key] = (torch.tensor(ref, dtype=torch.int32, device=self.device),
+                                 torch.tensor(supp, dtype=torch.int32, device=self.device),
+                                 torch.tensor([float(w) / float(w_up), float(h) / float(h_up)], dtype=torch.float32,
+                                              device=self.device))
+        ref_idx, supp_idx, sc = self._tables[key]
         flow = None
         for lv in range(6):
             inp = ops.spynet_level_input(pyr[lv], ref_idx, supp_idx, flow)
@@ -201,7 +206,6 @@ class Engine:
             x = cv[2]([x], act=ACT_RELU)
             x = cv[3]([x], act=ACT_RELU)
             flow = cv[4]([x], residual=inp, res_coff=6)
-        sc = torch.tensor([float(w) / float(w_up), float(h) / float(h_up)], dtype=torch.float32, device=self.device)
         flow = ops.resize_bilinear(flow, (h, w), False, scale=sc)
         fwd = flow[:nf].view(b, l_t - 1, h, w, 2)
         bwd = flow[nf:].view(b, l_t - 1, h, w, 2)

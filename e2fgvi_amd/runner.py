@@ -1,0 +1,106 @@
+"""Clip-sharded execution: one process per GPU, clips partitioned over ranks, one RCCL all-gather
+of the output frames per step (the only collective: clips are independent).
+Also the HIP-graph replay of the forward (launch-bound at one clip per GPU: ~600 short kernels)."""
+import torch
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous balanced partition: ranks [0, n_items % world) get one extra item."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_frames(local_out, world, group=None, out=None):
+    """All-gather equal-sized per-rank outputs [n,3,H,W] into [world*n,3,H,W] (rank-major = clip order)."""
+    if world == 1:
+        return local_out
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty((world * local_out.shape[0],) + tuple(local_out.shape[1:]), dtype=local_out.dtype,
+                          device=local_out.device)
+    dist.all_gather_into_tensor(out, local_out.contiguous(), group=group)
+    return out
+
+
+def inpaint_sharded(net, clips, num_local_frames, rank, world, group=None):
+    """clips: [B,t,3,H,W] (same on every rank, or at least this rank's slice valid).  Every rank runs its
+    contiguous share and all ranks receive all output frames [B*t,3,H,W].  B must be divisible by world."""
+    B = clips.shape[0]
+    if B % world:
+        raise ValueError("number of clips (%d) must be divisible by the number of ranks (%d)" % (B, world))
+    lo, hi = shard_range(B, rank, world)
+    out, _ = net(clips[lo:hi], num_local_frames)
+    return gather_frames(out, world, group)
+
+
+class ShardedStep:
+    """One benchmark / serving step: forward of this rank's clips (+ all-gather)."""
+
+    def __init__(self, net, x, lt, group_world=1, use_graph=True):
+        self.net, self.x, self.lt, self.world = net, x, lt, group_world
+        self.graph = None
+        self.graphed = False
+        self.out = None
+        self.gathered = None
+        self.use_graph = use_graph
+        self._calls = 0
+
+    def _forward(self):
+        out, _ = self.net(self.x, self.lt)
+        return out
+
+    def run(self):
+        if self.use_graph and self.graph is None and self._calls >= 1:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._forward()                       # warm allocator on the side stream
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self.out = self._forward()
+                self.graph, self.graphed = g, True
+            except Exception as e:                         # capture unsupported -> stay eager, say so
+                print("HIP graph capture failed (%s); running eagerly" % (str(e).splitlines()[0],), flush=True)
+                self.use_graph = False
+                torch.cuda.synchronize()
+        self._calls += 1
+        if self.graph is not None:
+            self.graph.replay()
+            out = self.out
+        else:
+            out = self._forward()
+        if self.world > 1:
+            if self.gathered is None:
+                self.gathered = torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype,
+                                            device=out.device)
+            gather_frames(out, self.world, out=self.gathered)
+            return self.gathered
+        return out
+
+
+def dominant_kernel_probe(net, dev, iters=20):
+    """Device time of the dominant kernel family (conv_igemm, fp32 MFMA) on its heaviest single launch of the
+    north-star clip: encoder layer 8 (256 -> 384, 3x3, 10 frames of 60x108), hip events on the launch stream."""
+    from . import ops
+    eng = net.engine()
+    layer = eng.enc[4]
+    x = torch.randn(10, 60, 108, 256, device=dev)
+    out = layer([x], act=ops.ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        layer([x], out=out, act=ops.ACT_LRELU, slope=0.2)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    gflop = 2 * 10 * 60 * 108 * 9 * 256 * 384 * 1e-9
+    tf = gflop / (us * 1e-6) / 1e3
+    return {"kernel": "conv_igemm_kernel<128,128,32> (encoder.layers.8: 3x3 256->384 on 10x60x108)",
+            "avg_us": round(us, 2), "gflop_per_launch": round(gflop, 3), "achieved": round(tf, 2),
+            "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4)}

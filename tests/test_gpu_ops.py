@@ -40,7 +40,7 @@ CONV_CASES = [
     (1, 30, 54, [128, 128, 128, 4], 1, 128, 3, 1, 1, 2, False, 0, None),     # conv_offset.0
     (1, 30, 54, [128, 128], 1, 432, 3, 1, 1, 0, False, 0, None),
     (3, 16, 24, [32, 48], 8, 256, 3, 1, 1, 2, False, 0, None),               # encoder g8
-    (2, 16, 24, [64, 96], 4, 384, 3, 1, 1, 2, False, 0, None),               # encoder g4
+    (2, 16, 24, [64, 128], 4, 384, 3, 1, 1, 2, False, 0, None),              # encoder g4
     (2, 16, 24, [128, 192], 2, 512, 3, 1, 1, 2, False, 0, None),             # encoder g2
     (2, 24, 32, [4], 1, 64, 3, 2, 1, 2, False, 0, None),                     # encoder first conv (3->4 padded)
     (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 0, None),                     # spynet conv 1
@@ -251,12 +251,13 @@ def test_prop_cond(dev):
     c2 = O.flow_warp(f2, f_n2.permute(0, 2, 3, 1))
     fl_nhwc = flows.permute(0, 1, 3, 4, 2).contiguous().to(dev)
     cond, fl = ops.prop_cond(nhwc(fp).to(dev), nhwc(f2).to(dev), fl_nhwc[0, i - 1], fl_nhwc[0, i - 2], (lt - 1) * h * w * 2)
-    assert_close(cond.cpu(), nhwc(torch.cat([c1, c2], 1)), 1e-5, "cond")
-    assert_close(fl.cpu(), nhwc(torch.cat([f_n1, f_n2], 1)), 1e-5, "flows")
+    # grid_sample on the CPU side goes through normalise/unnormalise of the coordinates: ~1e-6 px of jitter
+    assert_close(cond.cpu(), nhwc(torch.cat([c1, c2], 1)), 3e-4, "cond")
+    assert_close(fl.cpu(), nhwc(torch.cat([f_n1, f_n2], 1)), 3e-4, "flows")
     cond1, fl1 = ops.prop_cond(nhwc(fp).to(dev), None, fl_nhwc[0, 0], None, (lt - 1) * h * w * 2)
     c1b = O.flow_warp(fp, flows[:, 0].permute(0, 2, 3, 1))
-    assert_close(cond1.cpu(), nhwc(torch.cat([c1b, torch.zeros_like(c1b)], 1)), 1e-5, "cond i=1")
-    assert_close(fl1.cpu(), nhwc(torch.cat([flows[:, 0], torch.zeros_like(flows[:, 0])], 1)), 1e-5, "flows i=1")
+    assert_close(cond1.cpu(), nhwc(torch.cat([c1b, torch.zeros_like(c1b)], 1)), 3e-4, "cond i=1")
+    assert_close(fl1.cpu(), nhwc(torch.cat([flows[:, 0], torch.zeros_like(flows[:, 0])], 1)), 1e-6, "flows i=1")
 
 
 def test_layernorm_and_pool(dev):
