@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    import torch
+    # the oracle runs on the host CPU: torch's intra-op pool collapses with hundreds of threads on small ops
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

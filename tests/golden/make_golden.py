@@ -1,0 +1,57 @@
+"""Generate the golden fixtures from the REAL reference (run in the build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference/model/*.py read-only through oracle/ref_import.py (mmcv shim), loads the
+deterministic synthetic weights of e2fgvi_amd.synth into the reference InpaintGenerator, runs its CPU
+forward on the deterministic synthetic clips and stores strided sub-samples of the outputs plus
+whole-tensor statistics.  The fixtures travel to the GPU box; the reference does not.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from e2fgvi_amd.synth import synth_clip, synth_state_dict  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+# name, model, weights kind, (H, W), t, l_t, clips, clip seed
+CASES = [
+    ("g1_e2fgvi_default_t5", "e2fgvi", "default", (240, 432), 5, 5, 1, 11),
+    ("g2_e2fgvi_stress_t4_lt3", "e2fgvi", "stress", (240, 432), 4, 3, 1, 12),
+    ("g3_hq_stress_120x216_t4_lt3", "e2fgvi_hq", "stress", (120, 216), 4, 3, 1, 13),
+    ("g4_hq_default_60x108_t3_lt2_b2", "e2fgvi_hq", "default", (60, 108), 3, 2, 2, 14),
+]
+OUT_STRIDE, FLOW_STRIDE = 8, 4
+
+
+def stats(t):
+    t = t.double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.pow(2).mean().sqrt().item(), t.abs().max().item()])
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name, model, kind, (H, W), t, lt, b, seed in CASES:
+        sd = synth_state_dict(model, kind, 0)
+        net = ref_import.build_reference_model(model, sd)
+        x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
+        with torch.no_grad():
+            out, (ff, fb) = net(x, lt)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            out_sub=out[:, :, ::OUT_STRIDE, ::OUT_STRIDE].numpy(), out_stats=stats(out),
+            out_frame_mean=out.double().mean(dim=(1, 2, 3)).numpy(),
+            flow_fwd_sub=ff[..., ::FLOW_STRIDE, ::FLOW_STRIDE].numpy(), flow_bwd_sub=fb[..., ::FLOW_STRIDE, ::FLOW_STRIDE].numpy(),
+            flow_fwd_stats=stats(ff), flow_bwd_stats=stats(fb),
+            meta=np.array([H, W, t, lt, b, seed, OUT_STRIDE, FLOW_STRIDE]), model=model, kind=kind)
+        print(name, tuple(out.shape), "out stats", stats(out))
+
+
+if __name__ == "__main__":
+    main()

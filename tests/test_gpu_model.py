@@ -120,3 +120,58 @@ def test_end_to_end(dev, model, kind, hw, t, lt, b):
     assert d <= 1e-3, "output max abs err %.3e" % d
     assert df <= 1e-3 * max(1.0, flows[0].abs().max().item()) and db <= 1e-3 * max(1.0, flows[1].abs().max().item())
     assert r <= 2e-2, "output err relative to rms %.3e" % r
+
+
+# --------------------------------------------------------------------------- golden fixtures (real reference)
+import glob
+import os
+
+import numpy as np
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=os.path.basename)
+def test_hip_matches_reference_golden(dev, path):
+    """HIP forward vs sub-sampled outputs of the REAL reference (tests/golden/make_golden.py), <= 1e-3."""
+    import importlib
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    z = np.load(path)
+    H, W, t, lt, b, seed, so, sf = [int(v) for v in z["meta"]]
+    model, kind = str(z["model"]), str(z["kind"])
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(synth_state_dict(model, kind, 0))
+    net = net.to(dev).eval()
+    x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
+    out, (ff, fb) = net(x.to(dev), lt)
+    out, ff, fb = out.cpu(), ff.cpu(), fb.cpu()
+    d = np.abs(out[:, :, ::so, ::so].numpy() - z["out_sub"]).max()
+    rms = float(z["out_stats"][2])
+    print("golden %s: max abs %.3e (rms of reference %.3e)" % (os.path.basename(path), d, rms))
+    assert d <= 1e-3 and d <= 2e-2 * rms
+    fmax = max(1.0, float(z["flow_fwd_stats"][3]))
+    assert np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max() <= 1e-3 * fmax
+    assert np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max() <= 1e-3 * fmax
+    assert np.abs(out.double().mean(dim=(1, 2, 3)).numpy() - z["out_frame_mean"]).max() <= 1e-4
+
+
+# --------------------------------------------------------------------------- full-size properties (T=10)
+def test_full_size_properties(dev):
+    """BASELINE config (432x240, T=10): determinism, clip independence (the sharding premise: a batch of two
+    clips == the two clips run alone) and l_t split consistency of the non-local frames' encoder path."""
+    import importlib
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    net = importlib.import_module("model.e2fgvi").InpaintGenerator()
+    net.load_state_dict(synth_state_dict("e2fgvi", "stress", 0))
+    net = net.to(dev).eval()
+    x, _ = synth_clip(2, 10, 240, 432, seed=31, moving=True)
+    x = x.to(dev)
+    o2, (f2, _) = net(x, 10)
+    oa, (fa, _) = net(x[:1], 10)
+    ob, _ = net(x[1:], 10)
+    oa2, _ = net(x[:1], 10)
+    assert tuple(o2.shape) == (20, 3, 240, 432) and torch.isfinite(o2).all()
+    assert torch.equal(oa, oa2), "forward is not deterministic"
+    assert (o2 - torch.cat([oa, ob])).abs().max().item() <= 1e-5, "clips are not independent"
+    assert (f2[:1] - fa).abs().max().item() <= 1e-5
+    assert o2.abs().max().item() <= 1.0            # tanh range

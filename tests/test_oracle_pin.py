@@ -1,0 +1,66 @@
+"""Pins the CPU oracle (oracle/e2fgvi_oracle.py): against the committed golden fixtures made from the real
+reference (tests/golden/make_golden.py) and, where /root/reference exists, against the reference itself."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from e2fgvi_amd.synth import synth_clip, synth_state_dict
+from oracle import e2fgvi_oracle as O
+from oracle import ref_import
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load_golden(path):
+    z = np.load(path)
+    H, W, t, lt, b, seed, so, sf = [int(v) for v in z["meta"]]
+    return z, str(z["model"]), str(z["kind"]), (H, W), t, lt, b, seed, so, sf
+
+
+def test_fixtures_present():
+    assert len(GOLD) >= 4
+
+
+@pytest.mark.parametrize("path", [p for p in GOLD if "g1_" not in p], ids=os.path.basename)
+def test_oracle_matches_golden(path):
+    """(g1, the 5-frame 432x240 clip, is checked on the GPU box and in test_oracle_vs_reference's big case)"""
+    z, model, kind, (H, W), t, lt, b, seed, so, sf = load_golden(path)
+    sd = synth_state_dict(model, kind, 0)
+    x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
+    out, (ff, fb) = O.forward(sd, x, lt, model)
+    assert np.abs(out[:, :, ::so, ::so].numpy() - z["out_sub"]).max() < 2e-5
+    assert np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max() < 1e-4
+    assert np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max() < 1e-4
+    assert np.abs(out.double().mean(dim=(1, 2, 3)).numpy() - z["out_frame_mean"]).max() < 1e-6
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("model,kind,hw,t,lt,b", [("e2fgvi_hq", "stress", (60, 108), 3, 2, 2),
+                                                  ("e2fgvi_hq", "default", (120, 216), 3, 3, 1),
+                                                  ("e2fgvi", "stress", (240, 432), 3, 2, 1)])
+def test_oracle_vs_reference(model, kind, hw, t, lt, b):
+    sd = synth_state_dict(model, kind, 0)
+    net = ref_import.build_reference_model(model, sd)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    x, _ = synth_clip(b, t, hw[0], hw[1], seed=21, moving=True)
+    with torch.no_grad():
+        ro, (rf, rb) = net(x, lt)
+    oo, (of, ob) = O.forward(sd, x, lt, model)
+    assert (ro - oo).abs().max() < 2e-5
+    assert (rf - of).abs().max() < 1e-5 and (rb - ob).abs().max() < 1e-5
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+def test_reference_batch_is_clip_independent():
+    """clips are independent units: b=2 == two b=1 calls -- the sharding premise."""
+    sd = synth_state_dict("e2fgvi_hq", "stress", 0)
+    net = ref_import.build_reference_model("e2fgvi_hq", sd)
+    x, _ = synth_clip(2, 3, 60, 108, seed=22, moving=True)
+    with torch.no_grad():
+        o2, _ = net(x, 2)
+        oa, _ = net(x[:1], 2)
+        ob, _ = net(x[1:], 2)
+    assert (o2 - torch.cat([oa, ob])).abs().max() < 1e-6
