@@ -321,3 +321,17 @@ def test_bad_arguments_raise(dev):
         ops.PackedConv(torch.randn(16, 6, 3, 3, device=dev), None, [6], pad=1)   # cpg not a multiple of 4
     with pytest.raises(lib.HipError):
         ops.PackedDcn(torch.randn(8, 24, 3, 3, device=dev), None, 3)             # 8 channels per deform group
+
+
+def test_mmcv_compatible_op(dev):
+    """NCHW-in / NCHW-out op with mmcv's signature"""
+    from e2fgvi_amd.mmcv_ops import ModulatedDeformConv2d
+    from oracle.dcn import modulated_deform_conv2d as ref_op
+    g = _gen(20)
+    m = ModulatedDeformConv2d(32, 24, 3, padding=1, deform_groups=2).to(dev)
+    x = torch.randn(2, 32, 10, 14, generator=g)
+    off = torch.randn(2, 36, 10, 14, generator=g) * 2
+    msk = torch.rand(2, 18, 10, 14, generator=g)
+    out = m(x.to(dev), off.to(dev), msk.to(dev))
+    ref = ref_op(x, off, msk, m.weight.detach().cpu(), m.bias.detach().cpu(), 1, 1, 1, 1, 2)
+    assert_close(out.cpu(), ref, 5e-5, "mmcv-compatible op")
