@@ -29,6 +29,8 @@ struct ConvParams {
     int M;
     int tilesM, tilesN;
     int chunks_per_tap;
+    unsigned src_bytes[E2FGVI_MAX_SRC];   // extent of each source (buffer bounds; < 4 GiB)
+    unsigned wgroup_bytes;
     long long wgroup_stride;   // floats per group in the packed weight
     const float* w;
     const float* bias;
@@ -40,36 +42,56 @@ struct ConvParams {
     float slope;
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvParams p) {
-    constexpr int NT = 64 * WGM * WGN;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer resource: out-of-range offsets (>= bytes) return 0 -- the hardware does the zero padding of the
+// convolution halo, of the padded channels and of the K tail, with no branch and no select on the loaded data
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, int D, int KS>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void conv_igemm_kernel(const ConvParams p) {
+    // KS > 1: intra-workgroup split-K.  KS groups of WGM x WGN waves work on the SAME output tile, group kg taking
+    // K-chunks kg, kg+KS, ... with its own LDS ring; partial sums are merged through LDS at the end.  It is how a
+    // small-M problem (one output tile per CU, e.g. the 6480-pixel propagation convs) gets more than one wave per
+    // SIMD, so that one group's loads / LDS traffic / barrier waits hide under the other's MFMAs.
+    constexpr int NG = 64 * WGM * WGN;    // threads per K-group
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int LDA = BK + 4;
     constexpr int CH = BK / 4;            // float4 chunks per A row
-    constexpr int RP = NT / CH;           // A rows covered per pass
+    constexpr int RP = NG / CH;           // A rows covered per pass
     constexpr int A_IT = (BM + RP - 1) / RP;
     constexpr int B_F4 = BK * BN / 4;
-    constexpr int B_IT = (B_F4 + NT - 1) / NT;
+    constexpr int B_IT = (B_F4 + NG - 1) / NG;
+    constexpr int STAGE = BM * LDA + BK * BN;      // floats of one LDS stage (A slab + B slab)
+    constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(TM >= 1 && TN >= 1, "tile");
-    static_assert(NT % CH == 0, "threads per row");
+    static_assert(NG % CH == 0, "threads per row");
+    static_assert(KS * 2 * STAGE >= (KS - 1) * NG * TM * TN * 16, "reduction scratch must fit in LDS");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM * LDA + BK * BN)];
-    float* sA0 = smem;
-    float* sB0 = smem + 2 * BM * LDA;
+    __shared__ __attribute__((aligned(16))) float smem[KS * 2 * STAGE];
 
-    const int tid = threadIdx.x;
+    // K-group: wave-uniform; readfirstlane tells the compiler so, which keeps the whole K-loop state (tap, source,
+    // channel) and the per-source parameters it indexes in SGPRs
+    const int kg = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NG));
+    const int tid = threadIdx.x - kg * NG;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int g = blockIdx.y;
+    float* sbase = smem + kg * (2 * STAGE);
 
     const int logical = xcd_remap(blockIdx.x, p.tilesM * p.tilesN);
     const int tile_m = logical / p.tilesN, tile_n = logical - tile_m * p.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread A-row bookkeeping (fixed for the whole K loop)
+    // ---- per-thread A-row bookkeeping (fixed for the whole K loop): pixel index of tap (0,0) and its coordinates;
+    //      rows outside the problem get coordinates that fail every bounds test
     const int c4 = tid % CH;
-    int a_by[A_IT], a_bx[A_IT], a_img[A_IT];
-    bool a_ok[A_IT];
+    int a_pix[A_IT], a_by[A_IT], a_bx[A_IT];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int ia = 0; ia < A_IT; ++ia) {
@@ -80,58 +102,64 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
         const int img = mm / HoWo;
         const int rem = mm - img * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_img[ia] = img * p.H;
-        a_by[ia] = oy * p.stride - p.pad;
+        a_by[ia] = ok ? oy * p.stride - p.pad : -(1 << 28);
         a_bx[ia] = ox * p.stride - p.pad;
-        a_ok[ia] = ok;
+        a_pix[ia] = (img * p.H + oy * p.stride - p.pad) * p.W + ox * p.stride - p.pad;
     }
+    // weights: this thread's fixed part of the byte offset, OOB for columns past Npad / rows past the slab
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int ib = 0; ib < B_IT; ++ib) {
+        const int f = tid + ib * NG;
+        const int kq = f / BN, n = f - kq * BN;
+        const bool ok = (B_F4 % NG == 0 || f < B_F4) && (n0 + n) < p.Npad;
+        b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_stride, p.wgroup_bytes);
+    const unsigned b_step = (unsigned)(BK / 4) * (unsigned)p.Npad * 16u;     // bytes per K-chunk
 
-    const float* wg = p.w + (long long)g * p.wgroup_stride;
-
-    // ---- K-loop state (wave-uniform)
+    // ---- K-loop state (wave-uniform): the next chunk this group will load
     int ky = 0, kx = 0, s = 0, c0 = 0;
     const int KT = p.KH * p.KW * p.chunks_per_tap;
 
-    f32x4 ra[A_IT], rb[B_IT];
+    // D register stages: this group's next D chunks are in flight while the current one is multiplied
+    f32x4 ra[D][A_IT], rb[D][B_IT];
 
-    auto load_tile = [&](int kt) {
-        const float* sp = p.src[s];
-        const int ld = p.ld[s];
-        const int cbase = p.coff[s] + g * p.cpg[s] + c0 + c4 * 4;
-        const bool cok = (c0 + c4 * 4) < p.cpg[s];
+    auto load_tile = [&](int kt, f32x4 (&qa)[A_IT], f32x4 (&qb)[B_IT]) {
+        const bool tile_ok = kt < KT;                                   // past the end: everything reads as zero
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
+        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
+        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0 + c4 * 4) * 4u;
+        const bool cok = tile_ok && (c0 + c4 * 4) < p.cpg[s];
+        const int tap = ky * p.W + kx;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
-            const int iy = a_by[ia] + ky, ix = a_bx[ia] + kx;
-            const bool ok = a_ok[ia] && cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(sp + ((long long)(a_img[ia] + iy) * p.W + ix) * ld + cbase);
-            ra[ia] = v;
+            const bool ok = cok && (unsigned)(a_by[ia] + ky) < (unsigned)p.H && (unsigned)(a_bx[ia] + kx) < (unsigned)p.W;
+            const unsigned off = (unsigned)(a_pix[ia] + tap) * ld4 + chan;
+            qa[ia] = buf_load4(arsrc, ok ? off : OOB);
         }
+        const unsigned wk = tile_ok ? (unsigned)kt * b_step : OOB;
 #pragma unroll
         for (int ib = 0; ib < B_IT; ++ib) {
-            const int f = tid + ib * NT;
-            const int kq = f / BN, n = f - kq * BN;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((B_F4 % NT == 0 || f < B_F4) && (n0 + n) < p.Npad)
-                v = *reinterpret_cast<const f32x4*>(wg + ((long long)(kt * (BK / 4) + kq) * p.Npad + n0 + n) * 4);
-            rb[ib] = v;
+            const unsigned off = b_off[ib] + wk;                         // OOB + x may wrap: keep it saturated
+            qb[ib] = buf_load4(wrsrc, (b_off[ib] == OOB || !tile_ok) ? OOB : off);
         }
     };
-    auto store_tile = [&](int buf) {
-        float* sA = sA0 + buf * (BM * LDA);
-        float* sB = sB0 + buf * (BK * BN);
+    auto store_tile = [&](int buf, const f32x4 (&qa)[A_IT], const f32x4 (&qb)[B_IT]) {
+        float* sA = sbase + buf * STAGE;
+        float* sB = sA + BM * LDA;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             const int row = tid / CH + ia * RP;
-            if (row < BM) *reinterpret_cast<f32x4*>(sA + row * LDA + c4 * 4) = ra[ia];
+            if (BM % RP == 0 || row < BM) *reinterpret_cast<f32x4*>(sA + row * LDA + c4 * 4) = qa[ia];
         }
 #pragma unroll
         for (int ib = 0; ib < B_IT; ++ib) {
-            const int f = tid + ib * NT;
-            if (B_F4 % NT == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[ib];
+            const int f = tid + ib * NG;
+            if (B_F4 % NG == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = qb[ib];
         }
     };
-    auto advance = [&]() {
+    auto advance1 = [&]() {
         c0 += BK;
         if (c0 >= p.cpg[s]) {
             c0 = 0;
@@ -143,6 +171,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
             }
         }
     };
+    auto advance = [&]() {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) advance1();
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -152,22 +184,61 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(const ConvPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    // this group's chunks are kt = kg + it*KS.  The loop below has NO guards: chunks past the end load zeros (buffer
+    // bounds) and multiply zeros, so the iteration count is simply rounded up to a multiple of D.
+    for (int q = 0; q < kg; ++q) advance1();
+    const int nIter = ((KT + KS - 1) / KS + D - 1) / D * D;
+
+    // prologue: chunk it=0 -> LDS[0]; chunks it=1..D-1 -> register stages 1..D-1 (stage index = it % D)
+    load_tile(kg, ra[0], rb[0]);
+    advance();
+    store_tile(0, ra[0], rb[0]);
+#pragma unroll
+    for (int j = 1; j < D; ++j) {
+        load_tile(kg + j * KS, ra[j], rb[j]);
+        advance();
+    }
     __syncthreads();
 
     int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool more = (kt + 1) < KT;
-        if (more) {
+    for (int it0 = 0; it0 < nIter; it0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int kt = kg + (it0 + j) * KS;
+            load_tile(kt + D * KS, ra[j], rb[j]);      // stage j held chunk kt (already in LDS): refill it
             advance();
-            load_tile(kt + 1);
+            mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
+                                           wn * TN * 32, lane);
+            store_tile(cur ^ 1, ra[(j + 1) % D], rb[(j + 1) % D]);
+            __syncthreads();
+            cur ^= 1;
         }
-        mma_ktile<TM, TN, BK, LDA, BN>(sA0 + cur * (BM * LDA), sB0 + cur * (BK * BN), acc,
-                                       wm * TM * 32, wn * TN * 32, lane);
-        if (more) store_tile(cur ^ 1);
+    }
+
+    // ---- merge the K-groups' partial sums through LDS (the rings are free after the last barrier)
+    if (KS > 1) {
+        constexpr int PART = NG * TM * TN * 16;
+        if (kg > 0) {
+            float* sq = smem + (kg - 1) * PART;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sq[((tm * TN + tn) * 16 + r) * NG + tid] = acc[tm][tn][r];
+        }
         __syncthreads();
-        cur ^= 1;
+        if (kg > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) {
+            const float* sq = smem + (q - 1) * PART;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += sq[((tm * TN + tn) * 16 + r) * NG + tid];
+        }
     }
 
     // ---- epilogue
@@ -258,32 +329,51 @@ bool geometry(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* cpg
     return true;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, int D, int KS>
 int launch_conv(ConvParams& p, int groups, hipStream_t st) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout_g, BN);
-    dim3 grid(p.tilesM * p.tilesN, groups, 1), block(64 * WGM * WGN, 1, 1);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN>), grid, block, 0, st, p);
+    dim3 grid(p.tilesM * p.tilesN, groups, 1), block(64 * WGM * WGN * KS, 1, 1);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WGM, WGN, D, KS>), grid, block, 0, st, p);
     E2_LAUNCH_CHECK("conv_igemm");
     return 0;
 }
 
-template <int BK>
-int dispatch_tile(ConvParams& p, int groups, int tile, hipStream_t st) {
-    switch (tile) {
-        case 1: return launch_conv<128, 128, BK, 2, 2>(p, groups, st);
-        case 2: return launch_conv<128, 64, BK, 2, 2>(p, groups, st);
-        case 3: return launch_conv<64, 64, BK, 2, 2>(p, groups, st);
-        case 4: return launch_conv<128, 32, BK, 4, 1>(p, groups, st);
-        case 5: return launch_conv<64, 32, BK, 2, 1>(p, groups, st);
-        case 6: return launch_conv<64, 128, BK, 2, 2>(p, groups, st);
+// tile code = shape + 10 * (kernel K-chunk: 1=16, 2=32, 3=64) + 100 * register stages + 1000 * (K-groups - 1)
+// shapes: 1 128x128  2 128x64  3 64x64  4 128x32  5 64x32  6 64x128  7 32x128
+#define E2_CONV_CONFIGS(X)                                                                                \
+    X(121, 128, 128, 32, 2, 2, 1, 1) X(221, 128, 128, 32, 2, 2, 2, 1) X(211, 128, 128, 16, 2, 2, 2, 1)     \
+    X(111, 128, 128, 16, 2, 2, 1, 1) X(1111, 128, 128, 16, 2, 2, 1, 2) X(1121, 128, 128, 32, 2, 2, 1, 2)   \
+    X(222, 128, 64, 32, 2, 2, 2, 1) X(212, 128, 64, 16, 2, 2, 2, 1) X(122, 128, 64, 32, 2, 2, 1, 1)        \
+    X(1122, 128, 64, 32, 2, 2, 1, 2) X(1222, 128, 64, 32, 2, 2, 2, 2)                                      \
+    X(123, 64, 64, 32, 2, 2, 1, 1) X(223, 64, 64, 32, 2, 2, 2, 1) X(233, 64, 64, 64, 2, 2, 2, 1)           \
+    X(213, 64, 64, 16, 2, 2, 2, 1) X(1223, 64, 64, 32, 2, 2, 2, 2) X(1123, 64, 64, 32, 2, 2, 1, 2)         \
+    X(2123, 64, 64, 32, 2, 2, 1, 3) X(2223, 64, 64, 32, 2, 2, 2, 3) X(3123, 64, 64, 32, 2, 2, 1, 4)        \
+    X(1233, 64, 64, 64, 2, 2, 2, 2) X(1133, 64, 64, 64, 2, 2, 1, 2)                                        \
+    X(1213, 64, 64, 16, 2, 2, 2, 2) X(2213, 64, 64, 16, 2, 2, 2, 3) X(3213, 64, 64, 16, 2, 2, 2, 4)        \
+    X(224, 128, 32, 32, 4, 1, 2, 1) X(214, 128, 32, 16, 4, 1, 2, 1) X(1224, 128, 32, 32, 4, 1, 2, 2)       \
+    X(225, 64, 32, 32, 2, 1, 2, 1) X(215, 64, 32, 16, 2, 1, 2, 1) X(1225, 64, 32, 32, 2, 1, 2, 2)          \
+    X(3225, 64, 32, 32, 2, 1, 2, 4) X(1215, 64, 32, 16, 2, 1, 2, 2) X(3215, 64, 32, 16, 2, 1, 2, 4)        \
+    X(226, 64, 128, 32, 2, 2, 2, 1) X(216, 64, 128, 16, 2, 2, 2, 1) X(1226, 64, 128, 32, 2, 2, 2, 2)       \
+    X(1126, 64, 128, 32, 2, 2, 1, 2) X(126, 64, 128, 32, 2, 2, 1, 1)                                       \
+    X(227, 32, 128, 32, 1, 4, 2, 1) X(217, 32, 128, 16, 1, 4, 2, 1) X(1227, 32, 128, 32, 1, 4, 2, 2)       \
+    X(2227, 32, 128, 32, 1, 4, 2, 3)
+
+int dispatch_tile(ConvParams& p, int groups, int code, hipStream_t st) {
+    switch (code) {
+#define X(id, bm, bn, bk, wm, wn, d, ks) \
+    case id: return launch_conv<bm, bn, bk, wm, wn, d, ks>(p, groups, st);
+        E2_CONV_CONFIGS(X)
+#undef X
         default: break;
     }
-    e2fgvi_set_error("conv2d: unknown tile %d", tile);
+    e2fgvi_set_error("conv2d: tile code %d is not instantiated", code);
     return E2FGVI_EINVAL;
 }
 
-int auto_tile(const ConvParams& p, int groups) {
+int kernel_bk_of(int code) { const int k = (code / 10) % 10; return k == 1 ? 16 : k == 2 ? 32 : k == 3 ? 64 : 0; }
+
+int auto_shape(const ConvParams& p, int groups) {
     auto blocks = [&](int bm, int bn) { return (long long)cdiv(p.M, bm) * cdiv(p.Cout_g, bn) * groups; };
     const long long want = 2 * 256;    // >= 2 workgroups per CU before growing the tile
     if (p.Cout_g <= 32) return blocks(128, 32) >= want ? 4 : 5;
@@ -340,7 +430,14 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
         E2_REQUIRE(d->src_coff[s] + d->groups * d->src_cpg[s] <= d->src_ld[s], E2FGVI_EINVAL,
                    "conv2d: source %d channel range exceeds its pixel stride", s);
         p.src[s] = d->src[s]; p.ld[s] = d->src_ld[s]; p.coff[s] = d->src_coff[s]; p.cpg[s] = d->src_cpg[s];
+        const long long bytes = (long long)d->N * d->H * d->W * d->src_ld[s] * 4;
+        E2_REQUIRE(bytes < 4294967295LL, E2FGVI_EUNSUP,
+                   "conv2d: source %d spans %lld bytes; buffer addressing needs < 4 GiB (split the batch)", s, bytes);
+        p.src_bytes[s] = (unsigned)bytes;
     }
+    for (int s = d->nsrc; s < E2FGVI_MAX_SRC; ++s) p.src_bytes[s] = 0;
+    E2_REQUIRE(q.wgroup_stride * 4 < 4294967295LL, E2FGVI_EUNSUP, "conv2d: packed weight group >= 4 GiB");
+    p.wgroup_bytes = (unsigned)(q.wgroup_stride * 4);
     E2_REQUIRE(((uintptr_t)d->wpacked & 15) == 0, E2FGVI_EINVAL, "conv2d: packed weight not 16-byte aligned");
     p.nsrc = d->nsrc;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -354,7 +451,36 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
     p.act = d->act; p.slope = d->slope;
     if (!d->dst_nchw)
         E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d: dst slice exceeds dst_ld");
-    int tile = d->tile ? d->tile : auto_tile(p, d->groups);
-    if (d->bk == 16) return dispatch_tile<16>(p, d->groups, tile, (hipStream_t)stream);
-    return dispatch_tile<32>(p, d->groups, tile, (hipStream_t)stream);
+    int code = d->tile;
+    if (code < 10) {     // shape only (or auto): pick K-chunk, register stages and K-groups from the measurements
+        const int shape = code ? code : auto_shape(p, d->groups);
+        bool all16 = true;
+        for (int s = 0; s < d->nsrc; ++s) all16 = all16 && (d->src_cpg[s] % 32 == 0);
+        int kb = d->bk;
+        // 128x128 tiles: a 16-deep K-chunk halves the LDS ring, so 4 workgroups fit per CU (+5 % measured)
+        if (shape == 1 && d->bk == 32 && all16) kb = 16;
+        int ks = 1;
+        if (shape == 3) {
+            // one output tile per CU or less (e.g. the 6480-pixel propagation convs): 3 K-groups per workgroup
+            // give every SIMD three waves to overlap loads / LDS / barriers with MFMAs (-20...30 % measured)
+            const long long blocks = (long long)cdiv(p.M, 64) * cdiv(p.Cout_g, 64) * d->groups;
+            int kt = 0;
+            for (int s = 0; s < d->nsrc; ++s) kt += cdiv(d->src_cpg[s], kb);
+            kt *= d->KH * d->KW;
+            if (blocks < 384 && kt >= 24) ks = 3;
+        }
+        code = (ks - 1) * 1000 + 200 + (kb == 16 ? 10 : 20) + shape;
+    }
+    const int kbk = kernel_bk_of(code);
+    E2_REQUIRE(kbk != 0, E2FGVI_EINVAL, "conv2d: bad tile code %d", code);
+    if (kbk != d->bk) {  // a different K-chunk is only legal when no source needs padding under either granule
+        for (int s = 0; s < d->nsrc; ++s)
+            E2_REQUIRE(d->src_cpg[s] % kbk == 0 && d->src_cpg[s] % d->bk == 0, E2FGVI_EINVAL,
+                       "conv2d: tile code %d (K-chunk %d) incompatible with source %d of %d channels", code, kbk, s,
+                       d->src_cpg[s]);
+    }
+    // chunks_per_tap follows the kernel's K-chunk
+    p.chunks_per_tap = 0;
+    for (int s = 0; s < d->nsrc; ++s) p.chunks_per_tap += cdiv(d->src_cpg[s], kbk);
+    return dispatch_tile(p, d->groups, code, (hipStream_t)stream);
 }
