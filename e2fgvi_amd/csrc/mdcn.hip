@@ -36,162 +36,185 @@ struct DcnParams {
     const float* bias;
     float* dst; int dst_ld, dst_coff;
     int tilesM, tilesN;
+    int units0;            // units (of 16 channels x tap) that live in source 0
+    unsigned src_bytes[2], off_bytes, msk_bytes, flw_bytes, w_bytes;
 };
 
-struct Sample {           // everything needed to fetch one (pixel, unit) x 4 channels
-    float w00, w01, w10, w11;
-    long long o00, o01, o10, o11;   // float offsets into the source (clamped, always valid)
-    const float* base;
-};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void mdcn_kernel(const DcnParams p) {
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 1 - 2/(1 + e^{2x}); saturates correctly for large |x| (exp2 -> inf / 0)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// KS K-groups of WGM x WGN waves share one output tile (intra-workgroup split-K, see conv.hip): group kg takes the
+// K-chunks kg, kg+KS, ... .  All loads are raw buffer loads: corners outside the image, rows outside the problem and
+// chunks past the end read as zero through the buffer bounds, so the loop has no branches.
+template <int BM, int BN, int WGM, int WGN, int KS>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnParams p) {
     constexpr int BK = 32;
-    constexpr int NT = 64 * WGM * WGN;
+    constexpr int NG = 64 * WGM * WGN;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int LDA = BK + 4;
     constexpr int A_ITEMS = BM * 8;                   // (row, unit-in-chunk, c4)
-    constexpr int A_IT = (A_ITEMS + NT - 1) / NT;
+    constexpr int A_IT = (A_ITEMS + NG - 1) / NG;
     constexpr int B_F4 = BK * BN / 4;
-    constexpr int B_IT = (B_F4 + NT - 1) / NT;
+    constexpr int B_IT = (B_F4 + NG - 1) / NG;
+    constexpr int STAGE = BM * LDA + BK * BN;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    static_assert(KS * 2 * STAGE >= (KS - 1) * NG * TM * TN * 16, "reduction scratch must fit in LDS");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM * LDA + BK * BN)];
-    float* sA0 = smem;
-    float* sB0 = smem + 2 * BM * LDA;
+    __shared__ __attribute__((aligned(16))) float smem[KS * 2 * STAGE];
 
-    const int tid = threadIdx.x;
+    const int kg = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NG));
+    const int tid = threadIdx.x - kg * NG;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
+    float* sbase = smem + kg * (2 * STAGE);
     const int logical = xcd_remap(blockIdx.x, p.tilesM * p.tilesN);
     const int tile_m = logical / p.tilesN, tile_n = logical - tile_m * p.tilesN;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HoWo = p.Ho * p.Wo;
     const int KT = (p.units + 1) / 2;
 
+    const __amdgpu_buffer_rsrc_t r_src0 = make_rsrc(p.src[0], p.src_bytes[0]);
+    const __amdgpu_buffer_rsrc_t r_src1 = make_rsrc(p.src[1], p.src_bytes[1]);
+    const __amdgpu_buffer_rsrc_t r_off = make_rsrc(p.off, p.off_bytes);
+    const __amdgpu_buffer_rsrc_t r_msk = make_rsrc(p.msk, p.msk_bytes);
+    const __amdgpu_buffer_rsrc_t r_flw = make_rsrc(p.flows ? p.flows : p.off, p.flows ? p.flw_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(p.w, p.w_bytes);
+
     // fixed per-thread item geometry
-    int it_row[A_IT], it_uu[A_IT], it_c4[A_IT], it_img[A_IT], it_by[A_IT], it_bx[A_IT];
-    long long it_pix[A_IT];
+    int it_row[A_IT], it_uu[A_IT], it_c4[A_IT], it_by[A_IT], it_bx[A_IT], it_imgrow[A_IT];
+    unsigned it_pix[A_IT];
     bool it_ok[A_IT];
 #pragma unroll
     for (int ia = 0; ia < A_IT; ++ia) {
-        const int f = tid + ia * NT;
+        const int f = tid + ia * NG;
         const int row = f >> 3;
         it_row[ia] = row;
         it_uu[ia] = (f >> 2) & 1;
         it_c4[ia] = f & 3;
         const int m = m0 + row;
-        const bool ok = (A_ITEMS % NT == 0 || f < A_ITEMS) && m < p.M;
+        const bool ok = (A_ITEMS % NG == 0 || f < A_ITEMS) && m < p.M;
         const int mm = ok ? m : 0;
         const int img = mm / HoWo;
         const int rem = mm - img * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        it_img[ia] = img;
+        it_imgrow[ia] = img * p.H;
         it_by[ia] = oy * p.stride - p.pad;
         it_bx[ia] = ox * p.stride - p.pad;
-        it_pix[ia] = mm;
+        it_pix[ia] = (unsigned)mm;
         it_ok[ia] = ok;
     }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int ib = 0; ib < B_IT; ++ib) {
+        const int f = tid + ib * NG;
+        const int kq = f / BN, n = f - kq * BN;
+        const bool ok = (B_F4 % NG == 0 || f < B_F4) && (n0 + n) < p.Npad;
+        b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
+    }
+    const unsigned b_step = (unsigned)(BK / 4) * (unsigned)p.Npad * 16u;
 
-    float r_dy[A_IT], r_dx[A_IT], r_mk[A_IT];      // raw offset words of the chunk after next
+    float r_dy[A_IT], r_dx[A_IT], r_mk[A_IT], r_fu[A_IT], r_fv[A_IT];   // raw words of the chunk after next
     f32x4 c00[A_IT], c01[A_IT], c10[A_IT], c11[A_IT];
     float w00[A_IT], w01[A_IT], w10[A_IT], w11[A_IT];
     f32x4 rb[B_IT];
 
     auto unit_of = [&](int kt, int uu, int& g, int& tap, int& cq) -> bool {
         const int u = kt * 2 + uu;
-        if (u >= p.units) { g = 0; tap = 0; cq = 0; return false; }
-        g = u / (p.KK * p.cgq);
-        const int rem = u - g * (p.KK * p.cgq);
+        const bool ok = kt < KT && u < p.units;
+        const int uc = ok ? u : 0;
+        g = uc / (p.KK * p.cgq);
+        const int rem = uc - g * (p.KK * p.cgq);
         tap = rem / p.cgq;
         cq = rem - tap * p.cgq;
-        return true;
+        return ok;
     };
     auto load_offsets = [&](int kt) {
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             int g, tap, cq;
-            const bool uok = unit_of(kt, it_uu[ia], g, tap, cq);
-            float dy = 0.f, dx = 0.f, mk = 0.f;
-            if (uok && it_ok[ia]) {
-                const float* po = p.off + it_pix[ia] * p.off_ld + (g * 2 * p.KK + 2 * tap);
-                dy = po[0];
-                dx = po[1];
-                mk = p.msk[it_pix[ia] * p.msk_ld + g * p.KK + tap];
-            }
-            r_dy[ia] = dy; r_dx[ia] = dx; r_mk[ia] = mk;
+            const bool ok = unit_of(kt, it_uu[ia], g, tap, cq) && it_ok[ia];
+            const unsigned po = (it_pix[ia] * (unsigned)p.off_ld + (unsigned)(g * 2 * p.KK + 2 * tap)) * 4u;
+            const unsigned pm = (it_pix[ia] * (unsigned)p.msk_ld + (unsigned)(g * p.KK + tap)) * 4u;
+            const unsigned pf = (it_pix[ia] * 4u + ((g * 2 >= p.dg) ? 2u : 0u)) * 4u;
+            r_dy[ia] = buf_load1(r_off, ok ? po : OOB);
+            r_dx[ia] = buf_load1(r_off, ok ? po + 4u : OOB);
+            r_mk[ia] = buf_load1(r_msk, ok ? pm : OOB);
+            r_fu[ia] = buf_load1(r_flw, ok ? pf : OOB);
+            r_fv[ia] = buf_load1(r_flw, ok ? pf + 4u : OOB);
         }
     };
     // turn the raw words (loaded for chunk kt) into corner fetches for chunk kt
     auto issue_corners = [&](int kt) {
+        // both units of a chunk read the same source (host guarantees an even unit count in source 0)
+        const bool second = (kt * 2) >= p.units0;
+        const __amdgpu_buffer_rsrc_t rs = second ? r_src1 : r_src0;
+        const int cbase = second ? p.c[0] : 0;
+        const unsigned ld4 = (unsigned)(second ? p.ld[1] : p.ld[0]) * 4u;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             int g, tap, cq;
-            const bool uok = unit_of(kt, it_uu[ia], g, tap, cq);
+            const bool uok = unit_of(kt, it_uu[ia], g, tap, cq) && it_ok[ia];
             float dy = r_dy[ia], dx = r_dx[ia], mk = r_mk[ia];
             if (p.flows) {
-                const float* fl = p.flows + it_pix[ia] * 4 + ((g * 2 >= p.dg) ? 2 : 0);
-                const float fu = (uok && it_ok[ia]) ? fl[0] : 0.f, fv = (uok && it_ok[ia]) ? fl[1] : 0.f;
-                dy = p.max_residue * tanhf(dy) + fv;     // flip: dy takes the v (y) component
-                dx = p.max_residue * tanhf(dx) + fu;
-                mk = 1.f / (1.f + expf(-mk));
+                // tanh / sigmoid through v_exp_f32 + v_rcp_f32 (abs error ~2e-7: <1e-5 px on the residual offset)
+                dy = p.max_residue * fast_tanh(dy) + r_fv[ia];     // flip: dy takes the v (y) component
+                dx = p.max_residue * fast_tanh(dx) + r_fu[ia];
+                mk = fast_sigmoid(mk);
             }
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
             const float py = (float)(it_by[ia] + ky * p.dil) + dy;
             const float px = (float)(it_bx[ia] + kx * p.dil) + dx;
-            const bool inside = uok && it_ok[ia] && py > -1.f && px > -1.f && py < (float)p.H && px < (float)p.W;
+            const bool inside = uok && py > -1.f && px > -1.f && py < (float)p.H && px < (float)p.W;
             const float fy = floorf(py), fx = floorf(px);
             const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
             const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-            const bool vy0 = y0 >= 0, vy1 = y1 <= p.H - 1, vx0 = x0 >= 0, vx1 = x1 <= p.W - 1;
+            const bool vy0 = inside && y0 >= 0, vy1 = inside && y1 <= p.H - 1, vx0 = x0 >= 0, vx1 = x1 <= p.W - 1;
             const float mm = inside ? mk : 0.f;
-            w00[ia] = (vy0 && vx0) ? hy * hx * mm : 0.f;
-            w01[ia] = (vy0 && vx1) ? hy * lx * mm : 0.f;
-            w10[ia] = (vy1 && vx0) ? ly * hx * mm : 0.f;
-            w11[ia] = (vy1 && vx1) ? ly * lx * mm : 0.f;
-            const int cy0 = min(max(y0, 0), p.H - 1), cy1 = min(max(y1, 0), p.H - 1);
-            const int cx0 = min(max(x0, 0), p.W - 1), cx1 = min(max(x1, 0), p.W - 1);
-            int ch = g * p.cg + cq * 16 + it_c4[ia] * 4;
-            const int s = (ch >= p.c[0]) ? 1 : 0;
-            ch -= s ? p.c[0] : 0;
-            const float* base = p.src[s] + ch;
-            const long long ld = p.ld[s];
-            const long long rowb = (long long)it_img[ia] * p.H;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (inside) {
-                c00[ia] = *reinterpret_cast<const f32x4*>(base + ((rowb + cy0) * p.W + cx0) * ld);
-                c01[ia] = *reinterpret_cast<const f32x4*>(base + ((rowb + cy0) * p.W + cx1) * ld);
-                c10[ia] = *reinterpret_cast<const f32x4*>(base + ((rowb + cy1) * p.W + cx0) * ld);
-                c11[ia] = *reinterpret_cast<const f32x4*>(base + ((rowb + cy1) * p.W + cx1) * ld);
-            } else {
-                c00[ia] = z; c01[ia] = z; c10[ia] = z; c11[ia] = z;
-            }
+            w00[ia] = hy * hx * mm; w01[ia] = hy * lx * mm; w10[ia] = ly * hx * mm; w11[ia] = ly * lx * mm;
+            const unsigned ch = (unsigned)(g * p.cg + cq * 16 + it_c4[ia] * 4 - cbase) * 4u;
+            const unsigned r0 = (unsigned)((it_imgrow[ia] + y0) * p.W), r1 = (unsigned)((it_imgrow[ia] + y1) * p.W);
+            c00[ia] = buf_load4(rs, (vy0 && vx0) ? (r0 + (unsigned)x0) * ld4 + ch : OOB);
+            c01[ia] = buf_load4(rs, (vy0 && vx1) ? (r0 + (unsigned)x1) * ld4 + ch : OOB);
+            c10[ia] = buf_load4(rs, (vy1 && vx0) ? (r1 + (unsigned)x0) * ld4 + ch : OOB);
+            c11[ia] = buf_load4(rs, (vy1 && vx1) ? (r1 + (unsigned)x1) * ld4 + ch : OOB);
         }
     };
     auto load_w = [&](int kt) {
+        const bool tile_ok = kt < KT;
 #pragma unroll
-        for (int ib = 0; ib < B_IT; ++ib) {
-            const int f = tid + ib * NT;
-            const int kq = f / BN, n = f - kq * BN;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((B_F4 % NT == 0 || f < B_F4) && (n0 + n) < p.Npad)
-                v = *reinterpret_cast<const f32x4*>(p.w + ((long long)(kt * (BK / 4) + kq) * p.Npad + n0 + n) * 4);
-            rb[ib] = v;
-        }
+        for (int ib = 0; ib < B_IT; ++ib)
+            rb[ib] = buf_load4(r_w, (b_off[ib] == OOB || !tile_ok) ? OOB : b_off[ib] + (unsigned)kt * b_step);
     };
     auto store_tile = [&](int buf) {
-        float* sA = sA0 + buf * (BM * LDA);
-        float* sB = sB0 + buf * (BK * BN);
+        float* sA = sbase + buf * STAGE;
+        float* sB = sA + BM * LDA;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
-            if (A_ITEMS % NT == 0 || (tid + ia * NT) < A_ITEMS) {
+            if (A_ITEMS % NG == 0 || (tid + ia * NG) < A_ITEMS) {
                 const f32x4 v = c00[ia] * w00[ia] + c01[ia] * w01[ia] + c10[ia] * w10[ia] + c11[ia] * w11[ia];
                 *reinterpret_cast<f32x4*>(sA + it_row[ia] * LDA + it_uu[ia] * 16 + it_c4[ia] * 4) = v;
             }
         }
 #pragma unroll
         for (int ib = 0; ib < B_IT; ++ib) {
-            const int f = tid + ib * NT;
-            if (B_F4 % NT == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[ib];
+            const int f = tid + ib * NG;
+            if (B_F4 % NG == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[ib];
         }
     };
 
@@ -203,27 +226,51 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mdcn_kernel(const DcnParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    // prologue: chunk 0 fully staged, offsets of chunk 1 in registers
-    load_offsets(0);
-    issue_corners(0);
-    load_w(0);
+    // this group's chunks: kt = kg + it*KS.  Chunks past the end read zeros, so no guards are needed.
+    const int nIter = (KT + KS - 1) / KS;
+    load_offsets(kg);
+    issue_corners(kg);
+    load_w(kg);
     store_tile(0);
-    if (KT > 1) load_offsets(1);
+    load_offsets(kg + KS);
     __syncthreads();
 
     int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool more = (kt + 1) < KT;
-        if (more) {
-            issue_corners(kt + 1);           // consumes r_* (offsets of chunk kt+1)
-            load_w(kt + 1);
-            if (kt + 2 < KT) load_offsets(kt + 2);
-        }
-        mma_ktile<TM, TN, BK, LDA, BN>(sA0 + cur * (BM * LDA), sB0 + cur * (BK * BN), acc,
-                                       wm * TM * 32, wn * TN * 32, lane);
-        if (more) store_tile(cur ^ 1);
+    for (int it = 0; it < nIter; ++it) {
+        const int kt = kg + it * KS;
+        issue_corners(kt + KS);              // consumes r_* (raw words of chunk kt+KS)
+        load_w(kt + KS);
+        load_offsets(kt + 2 * KS);
+        mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
+                                       wn * TN * 32, lane);
+        store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (KS > 1) {
+        constexpr int PART = NG * TM * TN * 16;
+        if (kg > 0) {
+            float* sq = smem + (kg - 1) * PART;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sq[((tm * TN + tn) * 16 + r) * NG + tid] = acc[tm][tn][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) {
+            const float* sq = smem + (q - 1) * PART;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += sq[((tm * TN + tn) * 16 + r) * NG + tid];
+        }
     }
 
     const int j = lane & 31, h = lane >> 5;
@@ -269,11 +316,11 @@ long long dcn_packed_size(int Cout, int C, int KH, int KW) {
     return (long long)KT * 32 * round_up(Cout, 32);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int KS>
 int launch_dcn(DcnParams& p, hipStream_t st) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout, BN);
-    hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN), 0, st, p);
+    hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
     E2_LAUNCH_CHECK("mdcn");
     return 0;
 }
@@ -335,14 +382,32 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     p.flows = d->flows; p.max_residue = d->max_residue;
     p.w = d->wpacked; p.bias = d->bias;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff;
+    // buffer bounds (all < 4 GiB) and the source split
+    {
+        const long long P = (long long)d->N * d->Ho * d->Wo;
+        const long long sb0 = (long long)d->N * d->H * d->W * p.ld[0] * 4, sb1 = (long long)d->N * d->H * d->W * p.ld[1] * 4;
+        const long long ob = P * d->off_ld * 4, mb = P * d->mask_ld * 4, wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * 4;
+        E2_REQUIRE(sb0 < 4294967295LL && sb1 < 4294967295LL && ob < 4294967295LL && mb < 4294967295LL && wb < 4294967295LL,
+                   E2FGVI_EUNSUP, "mdcn: a tensor spans >= 4 GiB; buffer addressing needs less (split the batch)");
+        p.src_bytes[0] = (unsigned)sb0; p.src_bytes[1] = (unsigned)sb1;
+        p.off_bytes = (unsigned)ob; p.msk_bytes = (unsigned)mb; p.flw_bytes = (unsigned)(P * 16); p.w_bytes = (unsigned)wb;
+        // the mask may alias the offset tensor (raw conv_offset layout): bound it by what is left behind its base
+        if (d->mask >= d->offset && (const char*)d->mask < (const char*)d->offset + ob)
+            p.msk_bytes = (unsigned)(ob - ((const char*)d->mask - (const char*)d->offset));
+        p.units0 = (d->nsrc == 2) ? (d->src_c[0] / 16) * p.KK : p.units;
+        E2_REQUIRE(d->nsrc == 1 || p.units0 % 2 == 0, E2FGVI_EUNSUP, "mdcn: odd number of 16-channel units in source 0");
+    }
     int tile = d->tile;
     if (!tile) {
         const long long b64 = (long long)cdiv(p.M, 64) * cdiv(p.Cout, 128);
-        tile = b64 >= 512 ? 1 : 2;
+        tile = b64 >= 512 ? 1 : (b64 >= 256 ? 2 : 5);
     }
-    if (tile == 1) return launch_dcn<64, 128, 2, 2>(p, (hipStream_t)stream);
-    if (tile == 2) return launch_dcn<32, 128, 1, 4>(p, (hipStream_t)stream);
-    if (tile == 3) return launch_dcn<32, 64, 1, 2>(p, (hipStream_t)stream);
+    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream);
+    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream);
+    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream);
+    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream);
+    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream);
+    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream);
     e2fgvi_set_error("mdcn: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }

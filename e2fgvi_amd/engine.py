@@ -278,8 +278,11 @@ class Engine:
         tab, nk = self._table(fh, fw, blk)
         n1 = ops.layernorm(x, blk["n1w"], blk["n1b"])
         pooled = ops.window_pool(n1, blk["pool_w"], blk["pool_b"], b * t, fh, fw)
-        qkv = blk["qkv"](n1)
-        kvp = blk["qkv"](pooled)
+        # qkv of the tokens and of the pooled windows share one allocation (one buffer resource in the attention kernel)
+        rows, prow = n1.shape[0], pooled.shape[0]
+        both = torch.empty((rows + prow, 1536), dtype=torch.float32, device=n1.device)
+        qkv = blk["qkv"](n1, out=both[:rows])
+        kvp = blk["qkv"](pooled, out=both[rows:])
         att = ops.focal_attention(qkv, kvp, tab, nk, b, t, fh, fw)
         x1 = blk["proj"](att, residual=x)
         n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"])

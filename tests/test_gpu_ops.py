@@ -175,7 +175,7 @@ def test_focal_attention(dev, B, T, fh, fw):
     qkv = F.linear(xn.reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
     kvp = F.linear(xp.permute(0, 3, 1, 2, 4).reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
     tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
-    for waves in (0, 2, 4):
+    for waves in (0, 2, 4, 12, 14):
         out = ops.focal_attention(qkv.to(dev), kvp.to(dev), torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev),
                                   B, T, fh, fw, waves=waves)
         assert_close(out.cpu(), ref, 5e-5, "attention waves=%d" % waves)
