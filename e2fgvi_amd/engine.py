@@ -152,9 +152,16 @@ class Engine:
         self.half = torch.full((4,), 0.5, device=self.device)
         self._tables = {}
         self._zeros = {}
+        self.overlap_flows = True
+        self._side = None
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ helpers
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     def _zero(self, shape):
         key = tuple(shape)
         if key not in self._zeros:
@@ -327,8 +334,20 @@ class Engine:
         if not (2 <= l_t <= t):
             raise ValueError("num_local_frames must be in [2, t]")
         frames = ops._chk(frames.float().contiguous(), "masked_frames")
-        fwd, bwd = self.flows(frames, l_t)
-        enc = self.encode(frames)
+        if self.overlap_flows:
+            # SPyNet (many short, small-channel launches) and the encoder (few large launches) are independent:
+            # run them on two HIP streams so the flow pyramid fills the gaps of the encoder (fork/join is
+            # captured as two branches when the forward is recorded into a HIP graph)
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fwd, bwd = self.flows(frames, l_t)
+            enc = self.encode(frames)
+            main.wait_stream(side)
+        else:
+            fwd, bwd = self.flows(frames, l_t)
+            enc = self.encode(frames)
         ch = enc.shape[3]
         if trace is not None:
             trace["flow_fwd"], trace["flow_bwd"], trace["enc"] = fwd, bwd, enc.clone()

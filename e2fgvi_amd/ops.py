@@ -55,7 +55,9 @@ class PackedConv:
             raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
         self.groups, self.stride, self.pad = groups, stride, pad
         if bk is None:
-            bk = 32 if all(c % 32 == 0 for c in self.cpg) else 16
+            # K-chunk granule: 32 unless padding every source up to a multiple of 32 wastes more than ~8 % of K
+            pad32 = sum((c + 31) // 32 * 32 for c in self.cpg)
+            bk = 32 if pad32 <= 1.08 * sum(self.cpg) else 16
         self.bk = bk
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         n = lib.e2fgvi_packed_conv_weight_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, bk)
