@@ -148,6 +148,18 @@ def main():
                      "note": "whole forward: %.1f algorithmic GFLOP per clip (SURVEY.md 8d) / device time of one forward "
                              "(hip events on the launch stream)" % gflop_clip},
     }
+    # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the
+    # summary of the last collection is committed under profiles/ and quoted here (bytes per forward of one clip)
+    tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tfile) and b == 1 and (t, lt) == (10, 10):
+        try:
+            tj = json.load(open(tfile))
+            out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
+            out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, "
+                                               "separate passes (profiles/r01_hbm_traffic.json); fabric-side, includes "
+                                               "Infinity-Cache hits; algorithmic minimum is 0.19 GB/clip")
+        except Exception:
+            pass
     if rank == 0:
         dom = runner.dominant_kernel_probe(net, dev)
         out["roofline"]["dominant_kernel"] = dom

@@ -1,0 +1,42 @@
+#!/bin/bash
+# HBM traffic of one forward from rocprofv3 PMC counters (separate passes, no trace domains besides kernel-trace),
+# corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+# half of a wide coalesced read stream, so the read side is doubled.
+#   bash tools/pmc.sh <tag>    -> gpurun_out/pmc_<tag>/traffic.json
+TAG=${1:-run}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > $OUT/$C.log 2>&1 || true
+done
+python - "$OUT" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+per_kernel = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(out + "/" + c + "/**/*counter_collection.csv", recursive=True)
+    tot = 0.0
+    pk = collections.Counter()
+    n = 0
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == c:
+                v = float(r["Counter_Value"]); tot += v; n += 1
+                pk[r["Kernel_Name"].split("(")[0][-60:]] += v
+    res[c] = tot
+    per_kernel[c] = pk.most_common(8)
+    res[c + "_dispatches"] = n
+forwards = 3   # 1 warm-up + 2 timed (plus the one-off weight packing, negligible)
+fetch_b = res["FETCH_SIZE"] * 1024 * 2 / forwards     # gfx950: x2 on the read side
+write_b = res["WRITE_SIZE"] * 1024 / forwards
+js = {"fetch_bytes_per_forward": fetch_b, "write_bytes_per_forward": write_b, "hbm_bytes_per_forward": fetch_b + write_b,
+      "raw_kib": res, "forwards": forwards,
+      "note": "FETCH_SIZE/WRITE_SIZE (KiB) summed over all dispatches of bench.py --steps 2 --warmup 1, / 3 forwards; "
+              "read side doubled per the gfx950 calibration in MI355X_MICROARCH.md",
+      "top_fetch_kernels_kib": per_kernel["FETCH_SIZE"], "top_write_kernels_kib": per_kernel["WRITE_SIZE"]}
+json.dump(js, open(out + "/traffic.json", "w"), indent=1)
+print(json.dumps(js)[:1500])
+PY
