@@ -53,12 +53,11 @@ def cpu_baseline(sd, t, lt):
     Python cannot travel to the GPU box) timed on this host's cores on a bounded sample of the same workload."""
     from e2fgvi_amd.synth import synth_clip
     from oracle import e2fgvi_oracle as O
-    # Bounded sample: a T=5 clip of the same resolution (the T=10 clip costs minutes on a busy host), on at
-    # most 16 threads -- torch's intra-op pool stops scaling (and with 256 threads collapses) on these small ops.
+    # Bounded sample: ONE clip of the same workload (about 10-15 s), on at most 16 threads -- torch's intra-op
+    # pool stops scaling on these small ops (with the box's 256 hardware threads it collapses to minutes).
     cores = max(1, min(os.cpu_count() or 1, 16))
     torch.set_num_threads(cores)
-    ts = min(t, 5)
-    ls = min(lt, ts)
+    ts, ls = t, lt
     x, _ = synth_clip(1, ts, 240, 432, seed=100)
     t0 = time.perf_counter()
     O.forward(sd, x, ls, "e2fgvi")

@@ -101,6 +101,6 @@ def dominant_kernel_probe(net, dev, iters=20):
     us = 1e3 * e0.elapsed_time(e1) / iters
     gflop = 2 * 10 * 60 * 108 * 9 * 256 * 384 * 1e-9
     tf = gflop / (us * 1e-6) / 1e3
-    return {"kernel": "conv_igemm_kernel<128,128,32> (encoder.layers.8: 3x3 256->384 on 10x60x108)",
+    return {"kernel": "conv_igemm_kernel<128,128,16,2,2,2,1> (encoder.layers.8: 3x3 256->384 on 10x60x108)",
             "avg_us": round(us, 2), "gflop_per_launch": round(gflop, 3), "achieved": round(tf, 2),
             "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4)}
