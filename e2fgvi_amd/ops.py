@@ -80,6 +80,21 @@ class PackedConv:
         if len(srcs) != len(self.cpg):
             raise ValueError("expected %d sources, got %d" % (len(self.cpg), len(srcs)))
         N, H, W, _ = srcs[0][0].shape
+        # the kernel addresses each source through a 32-bit buffer resource: batches whose sources span >= 4 GiB
+        # are processed in image chunks (images are independent)
+        per_img = max(H * W * t.shape[3] * 4 for t, _ in srcs)
+        if N > 1 and N * per_img >= (1 << 32) - 1:
+            step = max(1, ((1 << 32) - 2) // per_img)
+            Ho, Wo = self.out_hw(H, W)
+            if out is None:
+                out = (torch.empty((N, self.Cout, Ho, Wo), dtype=torch.float32, device=srcs[0][0].device) if out_nchw
+                       else empty_nhwc(N, Ho, Wo, self.Cout, srcs[0][0].device))
+            for n0 in range(0, N, step):
+                n1 = min(N, n0 + step)
+                self([(t[n0:n1], c) for t, c in srcs], out=out[n0:n1], out_coff=out_coff,
+                     residual=None if residual is None else residual[n0:n1], res_coff=res_coff, act=act, slope=slope,
+                     out_nchw=out_nchw, tile=tile)
+            return out
         for i, (t, coff) in enumerate(srcs):
             _chk(t, "source %d" % i)
             if t.dim() != 4 or tuple(t.shape[:3]) != (N, H, W):

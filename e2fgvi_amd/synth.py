@@ -175,7 +175,7 @@ def synth_clip(b=1, t=10, h=240, w=432, seed=0, moving=False, smooth=True):
     if smooth:
         low = torch.rand(b, 3, h // 8 + 2, w // 8 + 2, generator=g)
         base = torch.nn.functional.interpolate(low, size=(h + 32, w + 32), mode="bilinear", align_corners=True)
-        frames = torch.stack([base[:, :, 2 * i:2 * i + h, 3 * i % 32:3 * i % 32 + w] for i in range(t)], 1)
+        frames = torch.stack([base[:, :, 2 * i % 32:2 * i % 32 + h, 3 * i % 32:3 * i % 32 + w] for i in range(t)], 1)
         frames = frames + 0.1 * torch.rand(b, t, 3, h, w, generator=g)
         frames = (frames / 1.1) * 2 - 1
     else:
