@@ -106,7 +106,9 @@ def main():
     x, _ = synth_clip(b, t, 240, 432, seed=100 + rank)
     x = x.to(dev)
 
-    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=not args.no_graph)
+    # HIP-graph replay only for the single-process run: with RCCL's watchdog thread alive, stream capture is an
+    # avoidable risk, and the forward is device-bound anyway (eager = graph within 1 %)
+    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=(not args.no_graph) and world == 1)
     for _ in range(args.warmup):
         step.run()
     torch.cuda.synchronize()

@@ -61,7 +61,7 @@ class ShardedStep:
                     self._forward()                       # warm allocator on the side stream
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.out = self._forward()
                 self.graph, self.graphed = g, True
             except Exception as e:                         # capture unsupported -> stay eager, say so

@@ -26,23 +26,15 @@ SHAPES = {
     "dec0": (10, 120, 216, [128], 1, 128, 3, 1, 1, 32),
 }
 CODES = {
-    "prop128": [0, 123, 223, 233, 1223, 1123, 2123, 2223, 3123, 1233, 1133, 1227, 2227, 1226],
-    "off0_bk16": [0, 213, 1213, 2213, 3213],
-    "off0_bk32": [0, 223, 1223, 1123, 2123, 2223, 3123, 1227, 2227],
-    "off6": [0, 223, 1223, 1123, 2123, 1226, 1126, 1227, 1121],
-    "bbf0": [0, 223, 233, 1223, 1123, 2123, 2223, 3123, 1233, 1133, 1227, 2227],
-    "enc8": [0, 121, 221, 111, 211, 1111, 1121, 226, 126, 1226, 1126],
-    "enc2": [0, 222, 122, 1122, 1222, 223, 1223, 1123],
-    "qkv": [0, 121, 221, 111, 1111, 1121, 226, 126, 1226, 1126],
-    "proj": [0, 226, 126, 1226, 1126, 223, 1223, 1123, 2123],
-    "fc2_bk16": [0, 211, 213, 1213],
-    "fc2_bk32": [0, 121, 221, 1121, 223, 1223, 1123, 226, 126, 1226, 1126],
-    "fc1": [0, 121, 221, 1121, 226, 126, 1226, 1126],
-    "spy2": [0, 222, 122, 1122, 1222, 223, 1223, 1123],
-    "spy3": [0, 224, 1224, 225, 1225, 3225],
-    "dec4": [0, 222, 122, 1122, 1222, 223],
-    "dec0": [0, 121, 221, 111, 1111, 1121, 226, 126, 1126],
+    "enc8": [211, 218, 228, 118, 219, 119],
+    "enc2": [0, 218, 219],
+    "qkv": [111, 211, 218, 118, 219, 119],
+    "fc1": [211, 218, 219],
+    "fc2_bk32": [223, 218],
+    "dec0": [211, 218, 219],
+    "dec4": [223, 222],
 }
+SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 g = torch.Generator(); g.manual_seed(0)
 res = {}
