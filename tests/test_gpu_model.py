@@ -98,7 +98,12 @@ def test_stage_transformer(dev, model, kind, hw, t, lt):
 
 E2E = [("e2fgvi", "stress", (240, 432), 3, 3, 1), ("e2fgvi", "default", (240, 432), 3, 3, 1),
        ("e2fgvi", "stress", (240, 432), 5, 3, 1), ("e2fgvi_hq", "stress", (120, 216), 4, 3, 1),
-       ("e2fgvi_hq", "default", (120, 216), 4, 4, 1), ("e2fgvi_hq", "stress", (120, 216), 3, 2, 2)]
+       ("e2fgvi_hq", "default", (120, 216), 4, 4, 1), ("e2fgvi_hq", "stress", (120, 216), 3, 2, 2),
+       # minimum local window (l_t = 2) with many reference frames; two clips with reference frames
+       ("e2fgvi", "stress", (240, 432), 6, 2, 1), ("e2fgvi", "stress", (240, 432), 3, 2, 2),
+       # non-square window grids: 3x2 windows (token grid 15x18), 1x2 windows, a single window
+       ("e2fgvi_hq", "stress", (180, 216), 3, 3, 1), ("e2fgvi_hq", "stress", (60, 216), 4, 2, 1),
+       ("e2fgvi_hq", "default", (60, 108), 2, 2, 3)]
 
 
 @pytest.mark.parametrize("model,kind,hw,t,lt,b", E2E)
@@ -175,3 +180,40 @@ def test_full_size_properties(dev):
     assert (o2 - torch.cat([oa, ob])).abs().max().item() <= 1e-5, "clips are not independent"
     assert (f2[:1] - fa).abs().max().item() <= 1e-5
     assert o2.abs().max().item() <= 1.0            # tanh range
+
+
+def test_argument_errors(dev):
+    """the drop-in raises where the reference would fail or silently mis-compute"""
+    import importlib
+    from e2fgvi_amd.synth import synth_state_dict
+    base = importlib.import_module("model.e2fgvi").InpaintGenerator().to(dev).eval()
+    hq = importlib.import_module("model.e2fgvi_hq").InpaintGenerator().to(dev).eval()
+    x = torch.zeros(1, 3, 3, 240, 432, device=dev)
+    with pytest.raises(ValueError):
+        base(x, 1)                                   # l_t must be >= 2 (flows of l_t-1 pairs)
+    with pytest.raises(ValueError):
+        base(x, 4)                                   # l_t > t
+    with pytest.raises(ValueError):
+        base(torch.zeros(1, 3, 3, 120, 216, device=dev), 2)      # base model is fixed to 432x240
+    with pytest.raises(ValueError):
+        hq(torch.zeros(1, 3, 3, 100, 216, device=dev), 2)        # H not a multiple of 60 (caller must pad)
+    with pytest.raises(RuntimeError):
+        hq(torch.zeros(1, 3, 3, 60, 108), 2)                     # CPU tensor
+
+
+def test_graph_replay_equals_eager(dev):
+    """the HIP-graph replay used by bench.py returns exactly the eager result, run after run"""
+    import importlib
+    from e2fgvi_amd import runner
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    net = importlib.import_module("model.e2fgvi_hq").InpaintGenerator()
+    net.load_state_dict(synth_state_dict("e2fgvi_hq", "stress", 0))
+    net = net.to(dev).eval()
+    x = synth_clip(1, 4, 120, 216, seed=41, moving=True)[0].to(dev)
+    eager, _ = net(x, 3)
+    step = runner.ShardedStep(net, x, 3, use_graph=True)
+    a = step.run().clone()
+    b = step.run().clone()
+    c = step.run().clone()
+    assert step.graphed
+    assert torch.equal(a, eager) and torch.equal(b, eager) and torch.equal(c, eager)
