@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--lt", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (self-test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,9 +90,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import importlib
@@ -108,7 +112,8 @@ def main():
 
     # HIP-graph replay only for the single-process run: with RCCL's watchdog thread alive, stream capture is an
     # avoidable risk, and the forward is device-bound anyway (eager = graph within 1 %)
-    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=(not args.no_graph) and world == 1)
+    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=(not args.no_graph) and dist is None,
+                              force_gather=args.force_dist)
     for _ in range(args.warmup):
         step.run()
     torch.cuda.synchronize()

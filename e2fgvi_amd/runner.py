@@ -11,9 +11,9 @@ def shard_range(n_items, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_frames(local_out, world, group=None, out=None):
+def gather_frames(local_out, world, group=None, out=None, force=False):
     """All-gather equal-sized per-rank outputs [n,3,H,W] into [world*n,3,H,W] (rank-major = clip order)."""
-    if world == 1:
+    if world == 1 and not force:
         return local_out
     import torch.distributed as dist
     if out is None:
@@ -37,8 +37,9 @@ def inpaint_sharded(net, clips, num_local_frames, rank, world, group=None):
 class ShardedStep:
     """One benchmark / serving step: forward of this rank's clips (+ all-gather)."""
 
-    def __init__(self, net, x, lt, group_world=1, use_graph=True):
+    def __init__(self, net, x, lt, group_world=1, use_graph=True, force_gather=False):
         self.net, self.x, self.lt, self.world = net, x, lt, group_world
+        self.force_gather = force_gather
         self.graph = None
         self.graphed = False
         self.out = None
@@ -74,11 +75,11 @@ class ShardedStep:
             out = self.out
         else:
             out = self._forward()
-        if self.world > 1:
+        if self.world > 1 or self.force_gather:
             if self.gathered is None:
                 self.gathered = torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype,
                                             device=out.device)
-            gather_frames(out, self.world, out=self.gathered)
+            gather_frames(out, self.world, out=self.gathered, force=self.force_gather)
             return self.gathered
         return out
 
