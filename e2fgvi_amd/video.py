@@ -54,9 +54,13 @@ def mirror_pad(x, mod_h=60, mod_w=108):
 
 @torch.no_grad()
 def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, num_ref=-1, dilate=True,
-                  device=None, pad=True):
+                  device=None, pad=True, batch_windows=1):
     """frames_u8: uint8 [L,H,W,3]; masks_u8: [L,H,W] (non-zero = hole).  Returns uint8 [L,H,W,3] composited
-    frames, computed like test.py:129-179.  ``model(masked[1,t,3,H',W'], n_local) -> (pred[t,3,H',W'], _)``."""
+    frames, computed like test.py:129-179.  ``model(masked[b,t,3,H',W'], n_local) -> (pred[b*t,3,H',W'], _)``.
+
+    ``batch_windows`` > 1 runs windows of equal shape (same number of local and reference frames) as one forward of
+    b clips -- clips are independent, so the predictions are the same; the compositing / blending below is still
+    applied in the reference's window order (the 0.5/0.5 blend is order dependent)."""
     frames_u8 = torch.as_tensor(np.asarray(frames_u8))
     masks_u8 = torch.as_tensor(np.asarray(masks_u8))
     if device is None:
@@ -69,17 +73,40 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
     imgs = (frames_d.permute(0, 3, 1, 2).float() / 255.0).unsqueeze(0) * 2 - 1            # to_tensors()*2-1
     masks = binary.float().view(1, L, 1, h, w)
     bmask = binary.view(L, h, w, 1)
-    comp = [None] * L
+
+    windows = []
     for f in range(0, L, neighbor_stride):
         neighbor_ids = list(range(max(0, f - neighbor_stride), min(L, f + neighbor_stride + 1)))
-        ref_ids = get_ref_index(f, neighbor_ids, L, ref_length, num_ref)
-        ids = neighbor_ids + ref_ids
-        masked = imgs[:, ids] * (1 - masks[:, ids])
-        if pad:
-            masked = mirror_pad(masked)
-        pred, _ = model(masked.contiguous(), len(neighbor_ids))
+        windows.append((neighbor_ids, get_ref_index(f, neighbor_ids, L, ref_length, num_ref)))
+
+    def predict(group):
+        clips = []
+        for neighbor_ids, ref_ids in group:
+            ids = neighbor_ids + ref_ids
+            masked = imgs[:, ids] * (1 - masks[:, ids])
+            clips.append(mirror_pad(masked) if pad else masked)
+        x = torch.cat(clips, 0).contiguous()
+        n_local = len(group[0][0])
+        pred, _ = model(x, n_local)
+        t = x.shape[1]
         pred = (pred[:, :, :h, :w] + 1) / 2
-        pred = (pred.permute(0, 2, 3, 1) * 255)                                           # [t,h,w,3] float
+        pred = (pred.permute(0, 2, 3, 1) * 255).view(len(group), t, h, w, 3)             # float, [b,t,h,w,3]
+        return [pred[i, :n_local] for i in range(len(group))]
+
+    preds = [None] * len(windows)
+    if batch_windows <= 1:
+        order = [[i] for i in range(len(windows))]
+    else:
+        by_shape = {}
+        for i, (nb, rf) in enumerate(windows):
+            by_shape.setdefault((len(nb), len(rf)), []).append(i)
+        order = [idx[k:k + batch_windows] for idx in by_shape.values() for k in range(0, len(idx), batch_windows)]
+    for grp in order:
+        for i, p in zip(grp, predict([windows[i] for i in grp])):
+            preds[i] = p
+
+    comp = [None] * L
+    for (neighbor_ids, _), pred in zip(windows, preds):
         for i, idx in enumerate(neighbor_ids):
             # np.array(pred).astype(uint8) * mask + frame * (1 - mask)   (test.py:171-174)
             img = torch.where(bmask[idx], pred[i].to(torch.uint8), frames_d[idx])

@@ -48,6 +48,21 @@ def test_driver_logic_matches_reference_loop(L, stride, num_ref):
     assert np.abs(out.astype(int) - ref.astype(int)).max() == 0
 
 
+def test_batched_windows_equal_sequential():
+    frames, masks = _toy_video(41, 40, 60, seed=5)
+    a = video.inpaint_video(_fake_model_batch, np.stack(frames), np.stack(masks), 5, 10, -1, device=torch.device("cpu"))
+    b = video.inpaint_video(_fake_model_batch, np.stack(frames), np.stack(masks), 5, 10, -1, device=torch.device("cpu"),
+                            batch_windows=3)
+    assert (a == b).all()
+
+
+def _fake_model_batch(x, n_local):
+    # per-clip (batch independent) stand-in
+    b, t, c, H, W = x.shape
+    y = torch.tanh(x * 0.7 + 0.1 * x.mean(dim=(1, 2, 3, 4), keepdim=True)).reshape(b * t, c, H, W)
+    return y, None
+
+
 def test_ref_index_selection():
     assert video.get_ref_index(10, list(range(5, 16)), 40) == [0, 20, 30]
     assert video.get_ref_index(10, list(range(5, 16)), 40, 10, 2) == video_ref.get_ref_index(10, list(range(5, 16)), 40, 10, 2)
