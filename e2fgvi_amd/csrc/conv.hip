@@ -476,6 +476,15 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
             kt *= d->KH * d->KW;
             if (blocks < 384 && kt >= 24) ks = 3;
         }
+        if (shape == 5) {
+            // narrow, tiny-M layers (the low SPyNet pyramid levels: 144 ... 9216 pixels): a handful of workgroups
+            // walking up to 98 K-chunks each -- pure latency; 4 K-groups cut the serial chain by 4
+            const long long blocks = (long long)cdiv(p.M, 64) * cdiv(p.Cout_g, 32) * d->groups;
+            int kt = 0;
+            for (int s = 0; s < d->nsrc; ++s) kt += cdiv(d->src_cpg[s], kb);
+            kt *= d->KH * d->KW;
+            if (blocks < 384 && kt >= 24) ks = 4;
+        }
         code = (ks - 1) * 1000 + 200 + (kb == 16 ? 10 : 20) + shape;
     }
     const int kbk = kernel_bk_of(code);
