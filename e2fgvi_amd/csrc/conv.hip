@@ -464,8 +464,8 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
         bool all16 = true;
         for (int s = 0; s < d->nsrc; ++s) all16 = all16 && (d->src_cpg[s] % 32 == 0);
         int kb = d->bk;
-        // 128x128 tiles: a 16-deep K-chunk halves the LDS ring, so 4 workgroups fit per CU (+5 % measured)
-        if ((shape == 1 || shape == 8) && d->bk == 32 && all16) kb = 16;
+        // >= 128-wide tiles: a 16-deep K-chunk halves the LDS ring, so 4 workgroups fit per CU (+4...7 % measured)
+        if ((shape == 1 || shape == 2 || shape == 6 || shape == 8) && d->bk == 32 && all16) kb = 16;
         int ks = 1;
         if (shape == 3) {
             // one output tile per CU or less (e.g. the 6480-pixel propagation convs): 3 K-groups per workgroup

@@ -24,15 +24,18 @@ SHAPES = {
     "spy3": (18, 64, 128, [64], 1, 32, 7, 1, 3, 32),
     "dec4": (10, 240, 432, [64], 1, 64, 3, 1, 1, 32),
     "dec0": (10, 120, 216, [128], 1, 128, 3, 1, 1, 32),
+    "ss": (10, 60, 108, [128], 1, 512, 7, 3, 3, 32),
+    "sc": (7200, 1, 1, [512], 1, 6272, 1, 1, 0, 32),
+    "dec2": (10, 120, 216, [128], 1, 64, 3, 1, 1, 32),
 }
 CODES = {
-    "enc8": [211, 218, 228, 118, 219, 119],
-    "enc2": [0, 218, 219],
-    "qkv": [111, 211, 218, 118, 219, 119],
-    "fc1": [211, 218, 219],
-    "fc2_bk32": [223, 218],
-    "dec0": [211, 218, 219],
-    "dec4": [223, 222],
+    "fc2_bk32": [0, 223, 222, 226, 1122, 1222, 211, 221],
+    "proj": [0, 223, 222, 226, 211],
+    "qkv": [0, 211, 226, 222, 216],
+    "ss": [0, 223, 226, 211, 221, 222],
+    "sc": [0, 218, 211, 219],
+    "dec2": [0, 222, 212, 223],
+    "dec4": [0, 222, 212, 223],
 }
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
