@@ -209,6 +209,15 @@ def test_resize(dev, align, size_in, size_out):
     assert_close(out2.cpu(), nhwc(ref), 2e-6, "resize nhwc src")
 
 
+def test_resize_vec4_path(dev):
+    """C % 4 == 0 NHWC sources take the 16-byte vectorised kernel (decoder x2 upsample, e2fgvi.py:126-129)"""
+    from e2fgvi_amd import ops
+    x = torch.randn(2, 64, 30, 54, generator=_gen(21))
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    out = ops.resize_bilinear(nhwc(x).to(dev), (60, 108), True)
+    assert_close(out.cpu(), nhwc(ref), 2e-6, "resize vec4")
+
+
 def test_avgpool(dev):
     from e2fgvi_amd import ops
     x = torch.randn(3, 4, 16, 24, generator=_gen(9))
