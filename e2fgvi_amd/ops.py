@@ -230,6 +230,15 @@ def focal_attention(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, waves=
     if out is None:
         out = torch.empty((rows, 512), dtype=torch.float32, device=qkv.device)
     _chk(out, "out")
+    # 32-bit buffer addressing inside the kernel: batches whose qkv spans >= 4 GiB go clip by clip
+    if B > 1 and rows * 1536 * 4 >= (1 << 32) - 1:
+        rpc, ppc = T * fh * fw, T * nwin
+        step = max(1, ((1 << 32) - 2) // (rpc * 1536 * 4))
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            focal_attention(qkv[b0 * rpc:b1 * rpc], kv_pool[b0 * ppc:b1 * ppc], key_tab, nkeys, b1 - b0, T, fh, fw,
+                            out=out[b0 * rpc:b1 * rpc], waves=waves)
+        return out
     _L.check(lib.e2fgvi_focal_attention(_ptr(qkv), _ptr(kv_pool), _ptr(key_tab), key_tab.shape[1], _ptr(nkeys),
                                         _ptr(out), B, T, fh, fw, waves, _stream()), "focal_attention")
     return out

@@ -1,0 +1,23 @@
+"""End-to-end throughput of the sliding-window driver (e2fgvi_amd/video.py) on a synthetic 432x240 video:
+upload of the uint8 frames, all windows (11 local + reference frames each), compositing, download.
+    python tools/video_bench.py [L=100] [batch_windows=1]"""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, importlib
+from e2fgvi_amd import video
+from e2fgvi_amd.synth import synth_state_dict
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+bw = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dev = torch.device("cuda:0")
+net = importlib.import_module("model.e2fgvi").InpaintGenerator()
+net.load_state_dict(synth_state_dict("e2fgvi", "default", 0)); net = net.to(dev).eval()
+rng = np.random.RandomState(0)
+frames = rng.randint(0, 256, (L, 240, 432, 3)).astype(np.uint8)
+masks = np.zeros((L, 240, 432), np.uint8); masks[:, 60:120, 108:216] = 255
+video.inpaint_video(net, frames[:12], masks[:12])            # warm-up (engine build, allocator)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+out = video.inpaint_video(net, frames, masks, batch_windows=bw)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+nwin = len(range(0, L, 5))
+print(json.dumps({"video_frames": L, "windows": nwin, "batch_windows": bw, "seconds": round(dt, 3),
+                  "video_frames_per_s": round(L / dt, 1), "ms_per_window": round(1e3 * dt / nwin, 2)}))
