@@ -270,6 +270,243 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void conv_igemm_kernel(const C
     }
 }
 
+// ---- halo-staged variant ---------------------------------------------------------------------------
+// Stride-1 KxK convolutions on large images re-read every input pixel K*K times through the implicit-GEMM path; the
+// re-reads miss the 4 MiB L2 (a layer's weights alone fill it) and show up as fabric traffic.  Here a workgroup owns
+// a TH x 16 pixel tile of ONE image: per channel block the (TH+K-1) x (16+K-1) input patch is staged once in LDS and
+// all K*K taps take their A operand from it at a shifted pixel offset (one scalar add per tap); only the weight slab
+// of each tap streams through the 2-deep LDS ring.  Global A traffic drops ~6x (3x3) / ~20x (7x7), the per-chunk
+// address arithmetic disappears, the MFMA work and the packed weights are unchanged (chunk (tap, block) of the
+// [tap][channel] packing is simply visited in (block, tap) order).
+template <int KK_, int TH, int BN, int CB, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvParams p) {
+    constexpr int TW = 16;
+    constexpr int PH = TH + KK_ - 1, PW = TW + KK_ - 1, NPIX = PH * PW;
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int TM = (TH / 2) / WGM, TN = BN / (32 * WGN);
+    constexpr int LDP = CB + 4;
+    constexpr int CH = CB / 4;
+    constexpr int P_F4 = NPIX * CH;
+    constexpr int P_IT = (P_F4 + NT - 1) / NT;
+    constexpr int B_F4 = CB * BN / 4;
+    constexpr int B_IT = (B_F4 + NT - 1) / NT;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    static_assert(TM >= 1 && TN >= 1 && (TH / 2) % WGM == 0, "tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * NPIX * LDP + 2 * CB * BN];
+    float* sP0 = smem;
+    float* sB0 = smem + 2 * NPIX * LDP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int g = blockIdx.y;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nsp = p.N * tiles_y * tiles_x;
+    const int logical = xcd_remap(blockIdx.x, nsp * p.tilesN);
+    const int tile_n = logical % p.tilesN;
+    int sp = logical / p.tilesN;
+    const int txi = sp % tiles_x;
+    sp /= tiles_x;
+    const int tyi = sp % tiles_y;
+    const int img = sp / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW, n0 = tile_n * BN;
+
+    // patch staging: this thread's float4s (pixel of the patch, channel quad): input pixel index or "outside"
+    int pp_pix[P_IT];         // (img*H + iy)*W + ix, or -1
+    int pp_lds[P_IT];         // float offset inside the patch buffer
+    int pp_c4[P_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int f = tid + it * NT;
+        const int pp = f / CH, c4 = f - pp * CH;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = y0 - p.pad + py, ix = x0 - p.pad + px;
+        const bool ok = (P_F4 % NT == 0 || f < P_F4) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pp_pix[it] = ok ? (img * p.H + iy) * p.W + ix : -1;
+        pp_lds[it] = pp * LDP + c4 * 4;
+        pp_c4[it] = c4;
+    }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int ib = 0; ib < B_IT; ++ib) {
+        const int f = tid + ib * NT;
+        const int kq = f / BN, n = f - kq * BN;
+        const bool ok = (B_F4 % NT == 0 || f < B_F4) && (n0 + n) < p.Npad;
+        b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_stride, p.wgroup_bytes);
+    const unsigned b_step = (unsigned)(CB / 4) * (unsigned)p.Npad * 16u;
+
+    // MFMA A operand: lane (i,h) of sub-tile (wm*TM+tm) is output pixel (2*(wm*TM+tm) + (i>>4), i&15) of the tile
+    const int i = lane & 31, h = lane >> 5;
+    int a_base[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a_base[tm] = ((2 * (wm * TM + tm) + (i >> 4)) * PW + (i & 15)) * LDP + h * 4;
+
+    f32x4 rp[P_IT], rb[B_IT];
+    const int nblk = p.chunks_per_tap;       // channel blocks over all sources
+    int s = 0, c0 = 0;                       // source / first channel of the block being LOADED
+
+    auto load_patch = [&](bool valid) {
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
+        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
+        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u;
+        const int cpg = p.cpg[s];
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const bool ok = valid && pp_pix[it] >= 0 && (c0 + pp_c4[it] * 4) < cpg;
+            rp[it] = buf_load4(arsrc, ok ? (unsigned)pp_pix[it] * ld4 + chan + (unsigned)pp_c4[it] * 16u : OOB);
+        }
+    };
+    auto store_patch = [&](float* dst) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (P_F4 % NT == 0 || (tid + it * NT) < P_F4) *reinterpret_cast<f32x4*>(dst + pp_lds[it]) = rp[it];
+    };
+    auto advance_blk = [&]() {
+        c0 += CB;
+        if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
+    };
+    auto load_b = [&](int kt, bool valid) {
+        const unsigned wk = (unsigned)kt * b_step;
+#pragma unroll
+        for (int ib = 0; ib < B_IT; ++ib) rb[ib] = buf_load4(wrsrc, (b_off[ib] == OOB || !valid) ? OOB : b_off[ib] + wk);
+    };
+    auto store_b = [&](float* dst) {
+#pragma unroll
+        for (int ib = 0; ib < B_IT; ++ib) {
+            const int f = tid + ib * NT;
+            if (B_F4 % NT == 0 || f < B_F4) *reinterpret_cast<f32x4*>(dst + f * 4) = rb[ib];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    constexpr int NTAP = KK_ * KK_;
+    // prologue: patch of block 0 and the weight slab of (block 0, tap 0)
+    load_patch(true);
+    advance_blk();
+    load_b(0, true);
+    store_patch(sP0);
+    store_b(sB0);
+    __syncthreads();
+
+    int pcur = 0, bcur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        load_patch(blk + 1 < nblk);            // next block's patch is in flight during this block's taps
+        advance_blk();
+        const float* sP = sP0 + pcur * (NPIX * LDP);
+        int tap = 0;
+        for (int ky = 0; ky < KK_; ++ky)
+            for (int kx = 0; kx < KK_; ++kx, ++tap) {
+                // next weight slab: (blk, tap+1) or (blk+1, 0); chunk index in the packing is tap*nblk + blk
+                const bool last_tap = tap == NTAP - 1;
+                const int ntap = last_tap ? 0 : tap + 1, nb = last_tap ? blk + 1 : blk;
+                load_b(ntap * nblk + nb, nb < nblk);
+                const float* sB = sB0 + bcur * (CB * BN);
+                const int tapoff = (ky * PW + kx) * LDP;
+#pragma unroll
+                for (int m8 = 0; m8 < CB / 8; ++m8) {
+                    f32x4 a[TM], b[TN];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const f32x4*>(sP + a_base[tm] + tapoff + m8 * 8);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        b[tn] = *reinterpret_cast<const f32x4*>(sB + ((2 * m8 + h) * BN + (wn * TN + tn) * 32 + i) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+                }
+                store_b(sB0 + (bcur ^ 1) * (CB * BN));
+                if (last_tap) store_patch(sP0 + (pcur ^ 1) * (NPIX * LDP));
+                __syncthreads();
+                bcur ^= 1;
+            }
+        pcur ^= 1;
+    }
+
+    // ---- epilogue
+    const int j = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + j;
+        if (n >= p.Cout_g) continue;
+        const int co = g * p.Cout_g + n;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;            // pixel of the 2x16 sub-tile
+                const int oy = y0 + 2 * (wm * TM + tm) + (row >> 4), ox = x0 + (row & 15);
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                const long long m = ((long long)img * p.Ho + oy) * p.Wo + ox;
+                float v = acc[tm][tn][r] + bv;
+                if (p.res) v += p.res[m * p.res_ld + p.res_coff + co];
+                v = apply_act(v, p.act, p.slope);
+                if (p.dst_nchw)
+                    p.dst[((long long)img * p.Cout + co) * ((long long)p.Ho * p.Wo) + (long long)oy * p.Wo + ox] = v;
+                else
+                    p.dst[m * p.dst_ld + p.dst_coff + co] = v;
+            }
+        }
+    }
+}
+
+template <int KK_, int TH, int BN, int CB, int WGM, int WGN>
+int launch_halo(ConvParams& p, int groups, hipStream_t st) {
+    p.tilesN = cdiv(p.Cout_g, BN);
+    const long long nb = (long long)p.N * cdiv(p.Ho, TH) * cdiv(p.Wo, 16) * p.tilesN;
+    dim3 grid((unsigned)nb, groups, 1), block(64 * WGM * WGN, 1, 1);
+    hipLaunchKernelGGL((conv_halo_kernel<KK_, TH, BN, CB, WGM, WGN>), grid, block, 0, st, p);
+    E2_LAUNCH_CHECK("conv_halo");
+    return 0;
+}
+
+// halo tile codes = 10000 + id:   id, K, TH, BN, CB, WGM, WGN
+#define E2_HALO_CONFIGS(X)                                                                                          \
+    X(1, 3, 8, 128, 32, 2, 2) X(2, 3, 8, 128, 16, 2, 2) X(3, 3, 4, 128, 32, 1, 4) X(4, 3, 4, 128, 16, 1, 4)          \
+    X(5, 3, 8, 64, 32, 2, 2) X(11, 3, 8, 64, 16, 2, 2) X(6, 3, 8, 32, 32, 4, 1) X(12, 3, 8, 32, 16, 4, 1)            \
+    X(7, 7, 8, 32, 16, 4, 1) X(8, 7, 8, 32, 32, 4, 1) X(9, 7, 8, 64, 32, 2, 2) X(10, 7, 8, 64, 16, 2, 2)
+
+int halo_cb_of(int id) {
+    switch (id) {
+#define X(id_, k, th, bn, cb, wm, wn) case id_: return cb;
+        E2_HALO_CONFIGS(X)
+#undef X
+        default: return 0;
+    }
+}
+int halo_k_of(int id) {
+    switch (id) {
+#define X(id_, k, th, bn, cb, wm, wn) case id_: return k;
+        E2_HALO_CONFIGS(X)
+#undef X
+        default: return 0;
+    }
+}
+int dispatch_halo(ConvParams& p, int groups, int id, hipStream_t st) {
+    switch (id) {
+#define X(id_, k, th, bn, cb, wm, wn) case id_: return launch_halo<k, th, bn, cb, wm, wn>(p, groups, st);
+        E2_HALO_CONFIGS(X)
+#undef X
+        default: break;
+    }
+    e2fgvi_set_error("conv2d: halo tile id %d is not instantiated", id);
+    return E2FGVI_EINVAL;
+}
+
 // ---- weight packing ---------------------------------------------------------------------------
 struct PackParams {
     int Cout, groups, KH, KW, nsrc, bk;
@@ -459,6 +696,33 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
     if (!d->dst_nchw)
         E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d: dst slice exceeds dst_ld");
     int code = d->tile;
+    if (code == 0 && d->stride == 1 && d->KH == d->KW && (d->KH == 3 || d->KH == 7) && q.Cout_g <= 64) {
+        // narrow stride-1 layers on large images (decoder tail, SPyNet top levels): the halo-staged kernel wins
+        // 5...12 % (measured, tools/conv_bench.py) and cuts the im2col re-read traffic; wide layers stay on the
+        // implicit-GEMM path, which is MFMA-bound and faster there
+        const long long tiles = (long long)d->N * cdiv(d->Ho, 8) * cdiv(d->Wo, 16);
+        bool c16 = true;     // a 16-channel block must be the pack granule or divide every source without padding
+        for (int s = 0; s < d->nsrc; ++s) c16 = c16 && (d->bk == 16 || d->src_cpg[s] % 32 == 0);
+        if (tiles >= 512 && d->Wo >= 32 && c16) {
+            const bool narrow = q.Cout_g <= 32;
+            code = 10000 + (d->KH == 3 ? (narrow ? 12 : 11) : (narrow ? 7 : 10));
+        }
+    }
+    if (code >= 10000) {   // halo-staged kernel
+        const int id = code - 10000;
+        const int cb = halo_cb_of(id), k = halo_k_of(id);
+        E2_REQUIRE(cb != 0, E2FGVI_EINVAL, "conv2d: bad halo tile id %d", id);
+        E2_REQUIRE(d->stride == 1 && d->KH == k && d->KW == k, E2FGVI_EINVAL,
+                   "conv2d: halo tile %d needs a stride-1 %dx%d convolution", id, k, k);
+        if (cb != d->bk)
+            for (int s = 0; s < d->nsrc; ++s)
+                E2_REQUIRE(d->src_cpg[s] % cb == 0 && d->src_cpg[s] % d->bk == 0, E2FGVI_EINVAL,
+                           "conv2d: halo tile %d (channel block %d) incompatible with source %d of %d channels", id, cb, s,
+                           d->src_cpg[s]);
+        p.chunks_per_tap = 0;
+        for (int s = 0; s < d->nsrc; ++s) p.chunks_per_tap += cdiv(d->src_cpg[s], cb);
+        return dispatch_halo(p, d->groups, id, (hipStream_t)stream);
+    }
     if (code < 10) {     // shape only (or auto): pick K-chunk, register stages and K-groups from the measurements
         const int shape = code ? code : auto_shape(p, d->groups);
         bool all16 = true;

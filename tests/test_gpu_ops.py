@@ -52,6 +52,23 @@ CONV_CASES = [
     (2, 30, 54, [128], 1, 512, 7, 3, 3, 0, False, 0, None),                  # soft split
     (2, 9, 13, [256], 1, 128, 1, 1, 0, 0, True, 0, None),                    # fusion 1x1
     (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 0, None),                     # decoder last conv (tanh)
+    # halo-staged kernel (tile codes 10000 + id), every instantiated configuration
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 0, True, 10001, None),
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 2, True, 10002, None),
+    (1, 30, 54, [128], 1, 128, 3, 1, 1, 2, False, 10003, None),
+    (2, 30, 54, [128], 1, 200, 3, 1, 1, 2, False, 10004, None),
+    (2, 24, 40, [64], 1, 64, 3, 1, 1, 2, False, 10005, None),
+    (2, 24, 40, [64], 1, 64, 3, 1, 1, 2, True, 10011, None),
+    (2, 17, 40, [32], 1, 32, 3, 1, 1, 1, False, 10006, None),
+    (2, 17, 40, [32], 1, 16, 3, 1, 1, 1, False, 10012, None),
+    (3, 16, 32, [64], 1, 32, 7, 1, 3, 1, False, 10007, None),
+    (3, 16, 32, [32], 1, 16, 7, 1, 3, 1, False, 10008, None),
+    (3, 16, 32, [32], 1, 64, 7, 1, 3, 1, False, 10009, None),
+    (3, 20, 25, [64], 1, 64, 7, 1, 3, 1, True, 10010, None),
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10007, None),                 # spynet conv 1 (8 channels, padded block)
+    (2, 16, 24, [128, 192], 2, 512, 3, 1, 1, 2, False, 10001, None),         # grouped, two sources
+    (1, 30, 54, [128, 128, 128, 4], 1, 128, 3, 1, 1, 2, False, 10001, None),  # four sources incl. a 4-channel one
+    (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 10006, None),                 # tanh + 3 output channels
 ]
 
 

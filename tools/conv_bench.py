@@ -27,15 +27,23 @@ SHAPES = {
     "ss": (10, 60, 108, [128], 1, 512, 7, 3, 3, 32),
     "sc": (7200, 1, 1, [512], 1, 6272, 1, 1, 0, 32),
     "dec2": (10, 120, 216, [128], 1, 64, 3, 1, 1, 32),
+    "dec6": (10, 240, 432, [64], 1, 3, 3, 1, 1, 32),
+    "spy1": (18, 64, 128, [8], 1, 32, 7, 1, 3, 16),
+    "spy4": (18, 64, 128, [32], 1, 16, 7, 1, 3, 32),
+    "spy5": (18, 64, 128, [16], 1, 2, 7, 1, 3, 16),
 }
 CODES = {
-    "fc2_bk32": [0, 223, 222, 226, 1122, 1222, 211, 221],
-    "proj": [0, 223, 222, 226, 211],
-    "qkv": [0, 211, 226, 222, 216],
-    "ss": [0, 223, 226, 211, 221, 222],
-    "sc": [0, 218, 211, 219],
-    "dec2": [0, 222, 212, 223],
-    "dec4": [0, 222, 212, 223],
+    "enc8": [0, 10001, 10002, 10003, 10004],
+    "enc2": [0, 10005, 10011],
+    "dec0": [0, 10001, 10002],
+    "dec2": [0, 10005, 10011],
+    "dec4": [0, 10005, 10011],
+    "dec6": [0, 10006, 10012],
+    "spy1": [0, 10007],
+    "spy2": [0, 10009, 10010],
+    "spy3": [0, 10007, 10008],
+    "spy4": [0, 10007, 10008],
+    "spy5": [0, 10007],
 }
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
