@@ -278,8 +278,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void conv_igemm_kernel(const C
 // of each tap streams through the 2-deep LDS ring.  Global A traffic drops ~6x (3x3) / ~20x (7x7), the per-chunk
 // address arithmetic disappears, the MFMA work and the packed weights are unchanged (chunk (tap, block) of the
 // [tap][channel] packing is simply visited in (block, tap) order).
-template <int KK_, int TH, int BN, int CB, int WGM, int WGN>
+// TG = taps per weight stage: 1 (one barrier per tap) or KK_ (a whole kernel row per barrier -- narrow layers do only
+// CB/2 MFMAs per wave and tap, too little to amortise a barrier).
+template <int KK_, int TH, int BN, int CB, int WGM, int WGN, int TG>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvParams p) {
+    static_assert(TG == 1 || TG == KK_, "TG");
     constexpr int TW = 16;
     constexpr int PH = TH + KK_ - 1, PW = TW + KK_ - 1, NPIX = PH * PW;
     constexpr int NT = 64 * WGM * WGN;
@@ -288,12 +291,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
     constexpr int CH = CB / 4;
     constexpr int P_F4 = NPIX * CH;
     constexpr int P_IT = (P_F4 + NT - 1) / NT;
-    constexpr int B_F4 = CB * BN / 4;
+    constexpr int B1_F4 = CB * BN / 4;          // float4s of one tap's weight slab
+    constexpr int B_F4 = TG * B1_F4;
     constexpr int B_IT = (B_F4 + NT - 1) / NT;
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(TM >= 1 && TN >= 1 && (TH / 2) % WGM == 0, "tile");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * NPIX * LDP + 2 * CB * BN];
+    __shared__ __attribute__((aligned(16))) float smem[2 * NPIX * LDP + 2 * TG * CB * BN];
     float* sP0 = smem;
     float* sB0 = smem + 2 * NPIX * LDP;
 
@@ -327,13 +331,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
         pp_lds[it] = pp * LDP + c4 * 4;
         pp_c4[it] = c4;
     }
-    unsigned b_off[B_IT];
+    unsigned b_off[B_IT];     // byte offset inside one tap's slab; b_tap = which tap of the stage
+    int b_tap[B_IT];
 #pragma unroll
     for (int ib = 0; ib < B_IT; ++ib) {
         const int f = tid + ib * NT;
-        const int kq = f / BN, n = f - kq * BN;
+        const int tg = f / B1_F4, f1 = f - tg * B1_F4;
+        const int kq = f1 / BN, n = f1 - kq * BN;
         const bool ok = (B_F4 % NT == 0 || f < B_F4) && (n0 + n) < p.Npad;
         b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
+        b_tap[ib] = tg;
     }
     const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_stride, p.wgroup_bytes);
     const unsigned b_step = (unsigned)(CB / 4) * (unsigned)p.Npad * 16u;
@@ -368,10 +375,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
         c0 += CB;
         if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
     };
-    auto load_b = [&](int kt, bool valid) {
-        const unsigned wk = (unsigned)kt * b_step;
+    // weight stage = taps [tap0, tap0+TG) of channel block `blk`; chunk index in the packing is tap*nblk + blk
+    auto load_b = [&](int tap0, int blk, bool valid) {
 #pragma unroll
-        for (int ib = 0; ib < B_IT; ++ib) rb[ib] = buf_load4(wrsrc, (b_off[ib] == OOB || !valid) ? OOB : b_off[ib] + wk);
+        for (int ib = 0; ib < B_IT; ++ib) {
+            const unsigned wk = (unsigned)((tap0 + b_tap[ib]) * nblk + blk) * b_step;
+            rb[ib] = buf_load4(wrsrc, (b_off[ib] == OOB || !valid) ? OOB : b_off[ib] + wk);
+        }
     };
     auto store_b = [&](float* dst) {
 #pragma unroll
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
     // prologue: patch of block 0 and the weight slab of (block 0, tap 0)
     load_patch(true);
     advance_blk();
-    load_b(0, true);
+    load_b(0, 0, true);
     store_patch(sP0);
     store_b(sB0);
     __syncthreads();
@@ -403,14 +413,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
         load_patch(blk + 1 < nblk);            // next block's patch is in flight during this block's taps
         advance_blk();
         const float* sP = sP0 + pcur * (NPIX * LDP);
-        int tap = 0;
-        for (int ky = 0; ky < KK_; ++ky)
-            for (int kx = 0; kx < KK_; ++kx, ++tap) {
-                // next weight slab: (blk, tap+1) or (blk+1, 0); chunk index in the packing is tap*nblk + blk
-                const bool last_tap = tap == NTAP - 1;
-                const int ntap = last_tap ? 0 : tap + 1, nb = last_tap ? blk + 1 : blk;
-                load_b(ntap * nblk + nb, nb < nblk);
-                const float* sB = sB0 + bcur * (CB * BN);
+        for (int tap0 = 0; tap0 < NTAP; tap0 += TG) {
+            // next weight stage: (blk, tap0+TG) or (blk+1, 0)
+            const bool last = tap0 + TG >= NTAP;
+            const int ntap0 = last ? 0 : tap0 + TG, nb = last ? blk + 1 : blk;
+            load_b(ntap0, nb, nb < nblk);
+            const float* sBst = sB0 + bcur * (TG * CB * BN);
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg) {
+                const int tap = tap0 + tg;
+                const int ky = (TG == 1) ? tap / KK_ : tap0 / KK_, kx = (TG == 1) ? tap - ky * KK_ : tg;
+                const float* sB = sBst + tg * (CB * BN);
                 const int tapoff = (ky * PW + kx) * LDP;
 #pragma unroll
                 for (int m8 = 0; m8 < CB / 8; ++m8) {
@@ -428,11 +441,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
                             for (int tn = 0; tn < TN; ++tn)
                                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
                 }
-                store_b(sB0 + (bcur ^ 1) * (CB * BN));
-                if (last_tap) store_patch(sP0 + (pcur ^ 1) * (NPIX * LDP));
-                __syncthreads();
-                bcur ^= 1;
             }
+            store_b(sB0 + (bcur ^ 1) * (TG * CB * BN));
+            if (last) store_patch(sP0 + (pcur ^ 1) * (NPIX * LDP));
+            __syncthreads();
+            bcur ^= 1;
+        }
         pcur ^= 1;
     }
 
@@ -464,25 +478,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
     }
 }
 
-template <int KK_, int TH, int BN, int CB, int WGM, int WGN>
+template <int KK_, int TH, int BN, int CB, int WGM, int WGN, int TG>
 int launch_halo(ConvParams& p, int groups, hipStream_t st) {
     p.tilesN = cdiv(p.Cout_g, BN);
     const long long nb = (long long)p.N * cdiv(p.Ho, TH) * cdiv(p.Wo, 16) * p.tilesN;
     dim3 grid((unsigned)nb, groups, 1), block(64 * WGM * WGN, 1, 1);
-    hipLaunchKernelGGL((conv_halo_kernel<KK_, TH, BN, CB, WGM, WGN>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<KK_, TH, BN, CB, WGM, WGN, TG>), grid, block, 0, st, p);
     E2_LAUNCH_CHECK("conv_halo");
     return 0;
 }
 
-// halo tile codes = 10000 + id:   id, K, TH, BN, CB, WGM, WGN
+// halo tile codes = 10000 + id:   id, K, TH, BN, CB, WGM, WGN, taps per weight stage
 #define E2_HALO_CONFIGS(X)                                                                                          \
-    X(1, 3, 8, 128, 32, 2, 2) X(2, 3, 8, 128, 16, 2, 2) X(3, 3, 4, 128, 32, 1, 4) X(4, 3, 4, 128, 16, 1, 4)          \
-    X(5, 3, 8, 64, 32, 2, 2) X(11, 3, 8, 64, 16, 2, 2) X(6, 3, 8, 32, 32, 4, 1) X(12, 3, 8, 32, 16, 4, 1)            \
-    X(7, 7, 8, 32, 16, 4, 1) X(8, 7, 8, 32, 32, 4, 1) X(9, 7, 8, 64, 32, 2, 2) X(10, 7, 8, 64, 16, 2, 2)
+    X(1, 3, 8, 128, 32, 2, 2, 1) X(2, 3, 8, 128, 16, 2, 2, 1) X(3, 3, 4, 128, 32, 1, 4, 1) X(4, 3, 4, 128, 16, 1, 4, 1)  \
+    X(5, 3, 8, 64, 32, 2, 2, 1) X(11, 3, 8, 64, 16, 2, 2, 1) X(6, 3, 8, 32, 32, 4, 1, 1) X(12, 3, 8, 32, 16, 4, 1, 1)    \
+    X(7, 7, 8, 32, 16, 4, 1, 1) X(8, 7, 8, 32, 32, 4, 1, 1) X(9, 7, 8, 64, 32, 2, 2, 1) X(10, 7, 8, 64, 16, 2, 2, 1)     \
+    X(22, 3, 8, 128, 16, 2, 2, 3) X(24, 3, 4, 128, 16, 1, 4, 3) X(31, 3, 8, 64, 16, 2, 2, 3) X(25, 3, 8, 64, 32, 2, 2, 3) \
+    X(32, 3, 8, 32, 16, 4, 1, 3) X(26, 3, 8, 32, 32, 4, 1, 3)                                                        \
+    X(27, 7, 8, 32, 16, 4, 1, 7) X(30, 7, 8, 64, 16, 2, 2, 7) X(28, 7, 8, 32, 32, 4, 1, 7)
 
 int halo_cb_of(int id) {
     switch (id) {
-#define X(id_, k, th, bn, cb, wm, wn) case id_: return cb;
+#define X(id_, k, th, bn, cb, wm, wn, tg) case id_: return cb;
         E2_HALO_CONFIGS(X)
 #undef X
         default: return 0;
@@ -490,7 +507,7 @@ int halo_cb_of(int id) {
 }
 int halo_k_of(int id) {
     switch (id) {
-#define X(id_, k, th, bn, cb, wm, wn) case id_: return k;
+#define X(id_, k, th, bn, cb, wm, wn, tg) case id_: return k;
         E2_HALO_CONFIGS(X)
 #undef X
         default: return 0;
@@ -498,7 +515,7 @@ int halo_k_of(int id) {
 }
 int dispatch_halo(ConvParams& p, int groups, int id, hipStream_t st) {
     switch (id) {
-#define X(id_, k, th, bn, cb, wm, wn) case id_: return launch_halo<k, th, bn, cb, wm, wn>(p, groups, st);
+#define X(id_, k, th, bn, cb, wm, wn, tg) case id_: return launch_halo<k, th, bn, cb, wm, wn, tg>(p, groups, st);
         E2_HALO_CONFIGS(X)
 #undef X
         default: break;
@@ -705,7 +722,7 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
         for (int s = 0; s < d->nsrc; ++s) c16 = c16 && (d->bk == 16 || d->src_cpg[s] % 32 == 0);
         if (tiles >= 512 && d->Wo >= 32 && c16) {
             const bool narrow = q.Cout_g <= 32;
-            code = 10000 + (d->KH == 3 ? (narrow ? 12 : 11) : (narrow ? 7 : 10));
+            code = 10000 + (d->KH == 3 ? (narrow ? 12 : 11) : (narrow ? 27 : 10));   // 27: 7 taps per barrier
         }
     }
     if (code >= 10000) {   // halo-staged kernel

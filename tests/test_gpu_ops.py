@@ -69,6 +69,17 @@ CONV_CASES = [
     (2, 16, 24, [128, 192], 2, 512, 3, 1, 1, 2, False, 10001, None),         # grouped, two sources
     (1, 30, 54, [128, 128, 128, 4], 1, 128, 3, 1, 1, 2, False, 10001, None),  # four sources incl. a 4-channel one
     (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 10006, None),                 # tanh + 3 output channels
+    # row-staged weight slabs (one barrier per kernel row)
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 2, True, 10022, None),
+    (2, 30, 54, [128], 1, 200, 3, 1, 1, 2, False, 10024, None),
+    (2, 24, 40, [64], 1, 64, 3, 1, 1, 2, True, 10031, None),
+    (2, 24, 40, [64, 32], 1, 64, 3, 1, 1, 2, False, 10025, None),
+    (2, 17, 40, [32], 1, 16, 3, 1, 1, 1, False, 10032, None),
+    (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 10026, None),
+    (3, 16, 32, [64], 1, 32, 7, 1, 3, 1, False, 10027, None),
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10027, None),
+    (3, 20, 25, [64], 1, 64, 7, 1, 3, 1, True, 10030, None),
+    (3, 16, 32, [32], 1, 16, 7, 1, 3, 1, False, 10028, None),
 ]
 
 

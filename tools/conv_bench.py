@@ -33,17 +33,17 @@ SHAPES = {
     "spy5": (18, 64, 128, [16], 1, 2, 7, 1, 3, 16),
 }
 CODES = {
-    "enc8": [0, 10001, 10002, 10003, 10004],
-    "enc2": [0, 10005, 10011],
-    "dec0": [0, 10001, 10002],
-    "dec2": [0, 10005, 10011],
-    "dec4": [0, 10005, 10011],
-    "dec6": [0, 10006, 10012],
-    "spy1": [0, 10007],
-    "spy2": [0, 10009, 10010],
-    "spy3": [0, 10007, 10008],
-    "spy4": [0, 10007, 10008],
-    "spy5": [0, 10007],
+    "enc8": [0, 10004, 10024, 10022],
+    "enc2": [0, 10011, 10031],
+    "dec0": [0, 10002, 10022],
+    "dec2": [0, 10011, 10031],
+    "dec4": [0, 10011, 10031, 10025],
+    "dec6": [0, 10012, 10032, 10026],
+    "spy1": [0, 10007, 10027],
+    "spy2": [0, 10010, 10030],
+    "spy3": [0, 10007, 10027, 10028],
+    "spy4": [0, 10007, 10027, 10028],
+    "spy5": [0, 10007, 10027],
 }
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
