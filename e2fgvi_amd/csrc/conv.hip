@@ -478,6 +478,200 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
     }
 }
 
+// 16-output-channel variant of the halo kernel on v_mfma_f32_16x16x4_f32 (lane l: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D[row=(l>>4)*4+reg][col=l&15]): layers with <= 16 output channels (SPyNet 32->16 and 16->2, the 64->3 decoder tail,
+// the flow heads) would spend >= half of a 32-wide MFMA on padding.  A wave still owns a 2x16-pixel sub-tile, now as
+// two 16-pixel row tiles; each quarter-wave takes 4 consecutive k with one ds_read_b128 (4 MFMAs per read).
+template <int KK_, int TH, int CB, int WGM, int TG>
+__global__ __launch_bounds__(64 * WGM) void conv_halo16_kernel(const ConvParams p) {
+    static_assert(TG == 1 || TG == KK_, "TG");
+    static_assert(CB % 16 == 0, "16 k per MFMA step group");
+    constexpr int TW = 16, BN = 16;
+    constexpr int PH = TH + KK_ - 1, PW = TW + KK_ - 1, NPIX = PH * PW;
+    constexpr int NT = 64 * WGM;
+    constexpr int TM = (TH / 2) / WGM;
+    constexpr int LDP = CB + 4;
+    constexpr int CH = CB / 4;
+    constexpr int P_F4 = NPIX * CH;
+    constexpr int P_IT = (P_F4 + NT - 1) / NT;
+    constexpr int B1_F4 = CB * BN / 4;
+    constexpr int B_F4 = TG * B1_F4;
+    constexpr int B_IT = (B_F4 + NT - 1) / NT;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    static_assert(TM >= 1 && (TH / 2) % WGM == 0, "tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * NPIX * LDP + 2 * TG * CB * BN];
+    float* sP0 = smem;
+    float* sB0 = smem + 2 * NPIX * LDP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wm = tid >> 6;
+    const int g = blockIdx.y;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nsp = p.N * tiles_y * tiles_x;
+    int sp = xcd_remap(blockIdx.x, nsp);
+    const int txi = sp % tiles_x;
+    sp /= tiles_x;
+    const int tyi = sp % tiles_y;
+    const int img = sp / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+
+    int pp_pix[P_IT], pp_lds[P_IT], pp_c4[P_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        const int f = tid + it * NT;
+        const int pp = f / CH, c4 = f - pp * CH;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = y0 - p.pad + py, ix = x0 - p.pad + px;
+        const bool ok = (P_F4 % NT == 0 || f < P_F4) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pp_pix[it] = ok ? (img * p.H + iy) * p.W + ix : -1;
+        pp_lds[it] = pp * LDP + c4 * 4;
+        pp_c4[it] = c4;
+    }
+    unsigned b_off[B_IT];
+    int b_tap[B_IT];
+#pragma unroll
+    for (int ib = 0; ib < B_IT; ++ib) {
+        const int f = tid + ib * NT;
+        const int tg = f / B1_F4, f1 = f - tg * B1_F4;
+        const int kq = f1 / BN, n = f1 - kq * BN;
+        const bool ok = (B_F4 % NT == 0 || f < B_F4) && n < p.Npad;
+        b_off[ib] = ok ? (unsigned)((kq * p.Npad + n) * 16) : OOB;
+        b_tap[ib] = tg;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_stride, p.wgroup_bytes);
+    const unsigned b_step = (unsigned)(CB / 4) * (unsigned)p.Npad * 16u;
+
+    const int i = lane & 15, kgrp = lane >> 4;
+    int a_base[TM][2];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) a_base[tm][r] = ((2 * (wm * TM + tm) + r) * PW + i) * LDP + kgrp * 4;
+
+    f32x4 rp[P_IT], rb[B_IT];
+    const int nblk = p.chunks_per_tap;
+    int s = 0, c0 = 0;
+    auto load_patch = [&](bool valid) {
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
+        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
+        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u;
+        const int cpg = p.cpg[s];
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const bool ok = valid && pp_pix[it] >= 0 && (c0 + pp_c4[it] * 4) < cpg;
+            rp[it] = buf_load4(arsrc, ok ? (unsigned)pp_pix[it] * ld4 + chan + (unsigned)pp_c4[it] * 16u : OOB);
+        }
+    };
+    auto store_patch = [&](float* dst) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it)
+            if (P_F4 % NT == 0 || (tid + it * NT) < P_F4) *reinterpret_cast<f32x4*>(dst + pp_lds[it]) = rp[it];
+    };
+    auto advance_blk = [&]() {
+        c0 += CB;
+        if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
+    };
+    auto load_b = [&](int tap0, int blk, bool valid) {
+#pragma unroll
+        for (int ib = 0; ib < B_IT; ++ib) {
+            const unsigned wk = (unsigned)((tap0 + b_tap[ib]) * nblk + blk) * b_step;
+            rb[ib] = buf_load4(wrsrc, (b_off[ib] == OOB || !valid) ? OOB : b_off[ib] + wk);
+        }
+    };
+    auto store_b = [&](float* dst) {
+#pragma unroll
+        for (int ib = 0; ib < B_IT; ++ib) {
+            const int f = tid + ib * NT;
+            if (B_F4 % NT == 0 || f < B_F4) *reinterpret_cast<f32x4*>(dst + f * 4) = rb[ib];
+        }
+    };
+
+    f32x4 acc[TM][2];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[tm][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NTAP = KK_ * KK_;
+    load_patch(true);
+    advance_blk();
+    load_b(0, 0, true);
+    store_patch(sP0);
+    store_b(sB0);
+    __syncthreads();
+
+    int pcur = 0, bcur = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        load_patch(blk + 1 < nblk);
+        advance_blk();
+        const float* sP = sP0 + pcur * (NPIX * LDP);
+        for (int tap0 = 0; tap0 < NTAP; tap0 += TG) {
+            const bool last = tap0 + TG >= NTAP;
+            const int ntap0 = last ? 0 : tap0 + TG, nb = last ? blk + 1 : blk;
+            load_b(ntap0, nb, nb < nblk);
+            const float* sBst = sB0 + bcur * (TG * CB * BN);
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg) {
+                const int tap = tap0 + tg;
+                const int ky = (TG == 1) ? tap / KK_ : tap0 / KK_, kx = (TG == 1) ? tap - ky * KK_ : tg;
+                const float* sB = sBst + tg * (CB * BN);
+                const int tapoff = (ky * PW + kx) * LDP;
+#pragma unroll
+                for (int m16 = 0; m16 < CB / 16; ++m16) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sB + ((4 * m16 + kgrp) * BN + i) * 4);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(sP + a_base[tm][r] + tapoff + m16 * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[tm][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[tm][r], 0, 0, 0);
+                        }
+                }
+            }
+            store_b(sB0 + (bcur ^ 1) * (TG * CB * BN));
+            if (last) store_patch(sP0 + (pcur ^ 1) * (NPIX * LDP));
+            __syncthreads();
+            bcur ^= 1;
+        }
+        pcur ^= 1;
+    }
+
+    const int n = lane & 15;
+    if (n < p.Cout_g) {
+        const int co = g * p.Cout_g + n;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int oy = y0 + 2 * (wm * TM + tm) + r, ox = x0 + (lane >> 4) * 4 + e;
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    const long long m = ((long long)img * p.Ho + oy) * p.Wo + ox;
+                    float v = acc[tm][r][e] + bv;
+                    if (p.res) v += p.res[m * p.res_ld + p.res_coff + co];
+                    v = apply_act(v, p.act, p.slope);
+                    if (p.dst_nchw)
+                        p.dst[((long long)img * p.Cout + co) * ((long long)p.Ho * p.Wo) + (long long)oy * p.Wo + ox] = v;
+                    else
+                        p.dst[m * p.dst_ld + p.dst_coff + co] = v;
+                }
+    }
+}
+
+template <int KK_, int TH, int CB, int WGM, int TG>
+int launch_halo16(ConvParams& p, int groups, hipStream_t st) {
+    p.tilesN = 1;
+    const long long nb = (long long)p.N * cdiv(p.Ho, TH) * cdiv(p.Wo, 16);
+    hipLaunchKernelGGL((conv_halo16_kernel<KK_, TH, CB, WGM, TG>), dim3((unsigned)nb, groups, 1), dim3(64 * WGM), 0, st, p);
+    E2_LAUNCH_CHECK("conv_halo16");
+    return 0;
+}
+
 template <int KK_, int TH, int BN, int CB, int WGM, int WGN, int TG>
 int launch_halo(ConvParams& p, int groups, hipStream_t st) {
     p.tilesN = cdiv(p.Cout_g, BN);
@@ -495,10 +689,18 @@ int launch_halo(ConvParams& p, int groups, hipStream_t st) {
     X(7, 7, 8, 32, 16, 4, 1, 1) X(8, 7, 8, 32, 32, 4, 1, 1) X(9, 7, 8, 64, 32, 2, 2, 1) X(10, 7, 8, 64, 16, 2, 2, 1)     \
     X(22, 3, 8, 128, 16, 2, 2, 3) X(24, 3, 4, 128, 16, 1, 4, 3) X(31, 3, 8, 64, 16, 2, 2, 3) X(25, 3, 8, 64, 32, 2, 2, 3) \
     X(32, 3, 8, 32, 16, 4, 1, 3) X(26, 3, 8, 32, 32, 4, 1, 3)                                                        \
-    X(27, 7, 8, 32, 16, 4, 1, 7) X(30, 7, 8, 64, 16, 2, 2, 7) X(28, 7, 8, 32, 32, 4, 1, 7)
+    X(27, 7, 8, 32, 16, 4, 1, 7) X(30, 7, 8, 64, 16, 2, 2, 7) X(28, 7, 8, 32, 32, 4, 1, 7)                          \
+    X(51, 7, 8, 32, 8, 4, 1, 7) X(52, 3, 8, 32, 8, 4, 1, 3) X(53, 3, 8, 64, 8, 2, 2, 3) X(54, 7, 8, 64, 8, 2, 2, 7)
+
+// 16-wide halo tiles: id, K, TH, CB, WGM, taps per weight stage
+#define E2_HALO16_CONFIGS(X) \
+    X(41, 7, 8, 16, 4, 7) X(42, 3, 8, 16, 4, 3) X(43, 7, 8, 32, 4, 7) X(44, 3, 8, 32, 4, 3) X(45, 3, 8, 16, 4, 1) X(46, 7, 8, 16, 4, 1)
 
 int halo_cb_of(int id) {
     switch (id) {
+#define X(id_, k, th, cb, wm, tg) case id_: return cb;
+        E2_HALO16_CONFIGS(X)
+#undef X
 #define X(id_, k, th, bn, cb, wm, wn, tg) case id_: return cb;
         E2_HALO_CONFIGS(X)
 #undef X
@@ -507,6 +709,9 @@ int halo_cb_of(int id) {
 }
 int halo_k_of(int id) {
     switch (id) {
+#define X(id_, k, th, cb, wm, tg) case id_: return k;
+        E2_HALO16_CONFIGS(X)
+#undef X
 #define X(id_, k, th, bn, cb, wm, wn, tg) case id_: return k;
         E2_HALO_CONFIGS(X)
 #undef X
@@ -515,6 +720,9 @@ int halo_k_of(int id) {
 }
 int dispatch_halo(ConvParams& p, int groups, int id, hipStream_t st) {
     switch (id) {
+#define X(id_, k, th, cb, wm, tg) case id_: return launch_halo16<k, th, cb, wm, tg>(p, groups, st);
+        E2_HALO16_CONFIGS(X)
+#undef X
 #define X(id_, k, th, bn, cb, wm, wn, tg) case id_: return launch_halo<k, th, bn, cb, wm, wn, tg>(p, groups, st);
         E2_HALO_CONFIGS(X)
 #undef X
@@ -565,7 +773,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 
 bool geometry(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* cpg, int bk, PackParams* q) {
     if (Cout <= 0 || groups <= 0 || Cout % groups || KH <= 0 || KW <= 0 || nsrc < 1 || nsrc > E2FGVI_MAX_SRC) return false;
-    if (bk != 16 && bk != 32) return false;
+    if (bk != 8 && bk != 16 && bk != 32) return false;
     q->Cout = Cout; q->groups = groups; q->KH = KH; q->KW = KW; q->nsrc = nsrc; q->bk = bk;
     q->Cout_g = Cout / groups;
     q->Npad = round_up(q->Cout_g, 32);
@@ -593,7 +801,7 @@ int launch_conv(ConvParams& p, int groups, hipStream_t st) {
     return 0;
 }
 
-// tile code = shape + 10 * (kernel K-chunk: 1=16, 2=32, 3=64) + 100 * register stages + 1000 * (K-groups - 1)
+// tile code = shape + 10 * (kernel K-chunk: 1=16, 2=32, 3=64, 4=8) + 100 * register stages + 1000 * (K-groups - 1)
 // shapes: 1 128x128  2 128x64  3 64x64  4 128x32  5 64x32  6 64x128  7 32x128  8 256x128  9 128x256 (8 waves)
 #define E2_CONV_CONFIGS(X)                                                                                \
     X(121, 128, 128, 32, 2, 2, 1, 1) X(221, 128, 128, 32, 2, 2, 2, 1) X(211, 128, 128, 16, 2, 2, 2, 1)     \
@@ -613,7 +821,10 @@ int launch_conv(ConvParams& p, int groups, hipStream_t st) {
     X(227, 32, 128, 32, 1, 4, 2, 1) X(217, 32, 128, 16, 1, 4, 2, 1) X(1227, 32, 128, 32, 1, 4, 2, 2)       \
     X(2227, 32, 128, 32, 1, 4, 2, 3)                                                                       \
     X(218, 256, 128, 16, 4, 2, 2, 1) X(228, 256, 128, 32, 4, 2, 2, 1) X(118, 256, 128, 16, 4, 2, 1, 1)     \
-    X(219, 128, 256, 16, 2, 4, 2, 1) X(119, 128, 256, 16, 2, 4, 1, 1)
+    X(219, 128, 256, 16, 2, 4, 2, 1) X(119, 128, 256, 16, 2, 4, 1, 1)                                      \
+    X(241, 128, 128, 8, 2, 2, 2, 1) X(242, 128, 64, 8, 2, 2, 2, 1) X(243, 64, 64, 8, 2, 2, 2, 1)           \
+    X(244, 128, 32, 8, 4, 1, 2, 1) X(245, 64, 32, 8, 2, 1, 2, 1) X(246, 64, 128, 8, 2, 2, 2, 1)            \
+    X(3245, 64, 32, 8, 2, 1, 2, 4)
 
 int dispatch_tile(ConvParams& p, int groups, int code, hipStream_t st) {
     switch (code) {
@@ -627,7 +838,7 @@ int dispatch_tile(ConvParams& p, int groups, int code, hipStream_t st) {
     return E2FGVI_EINVAL;
 }
 
-int kernel_bk_of(int code) { const int k = (code / 10) % 10; return k == 1 ? 16 : k == 2 ? 32 : k == 3 ? 64 : 0; }
+int kernel_bk_of(int code) { const int k = (code / 10) % 10; return k == 1 ? 16 : k == 2 ? 32 : k == 3 ? 64 : k == 4 ? 8 : 0; }
 
 int auto_shape(const ConvParams& p, int groups) {
     auto blocks = [&](int bm, int bn) { return (long long)cdiv(p.M, bm) * cdiv(p.Cout_g, bn) * groups; };
@@ -723,6 +934,10 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
         if (tiles >= 512 && d->Wo >= 32 && c16) {
             const bool narrow = q.Cout_g <= 32;
             code = 10000 + (d->KH == 3 ? (narrow ? 12 : 11) : (narrow ? 27 : 10));   // 27: 7 taps per barrier
+            if (q.Cout_g <= 16) code = 10000 + (d->KH == 3 ? 42 : 41);              // 16-wide MFMA tiles
+        } else if (tiles >= 512 && d->Wo >= 32 && d->bk == 8) {                     // 4/8-channel inputs (SPyNet conv 1)
+            const bool narrow = q.Cout_g <= 32;
+            code = 10000 + (d->KH == 3 ? (narrow ? 52 : 53) : (narrow ? 51 : 54));
         }
     }
     if (code >= 10000) {   // halo-staged kernel
@@ -731,6 +946,7 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
         E2_REQUIRE(cb != 0, E2FGVI_EINVAL, "conv2d: bad halo tile id %d", id);
         E2_REQUIRE(d->stride == 1 && d->KH == k && d->KW == k, E2FGVI_EINVAL,
                    "conv2d: halo tile %d needs a stride-1 %dx%d convolution", id, k, k);
+        E2_REQUIRE(id < 40 || id > 50 || q.Cout_g <= 16, E2FGVI_EINVAL, "conv2d: halo tile %d is for <= 16 output channels per group", id);
         if (cb != d->bk)
             for (int s = 0; s < d->nsrc; ++s)
                 E2_REQUIRE(d->src_cpg[s] % cb == 0 && d->src_cpg[s] % d->bk == 0, E2FGVI_EINVAL,
@@ -766,7 +982,10 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
             kt *= d->KH * d->KW;
             if (blocks < 384 && kt >= 24) ks = 4;
         }
-        code = (ks - 1) * 1000 + 200 + (kb == 16 ? 10 : 20) + shape;
+        int shp = shape;
+        if (kb == 8 && shp == 8) shp = 1;                 // no 8-wave tile for 8-channel chunks
+        if (kb == 8 && shp == 3) ks = 1;                  // (the 64x64 K-group merge scratch needs a deeper chunk)
+        code = (ks - 1) * 1000 + 200 + (kb == 8 ? 40 : kb == 16 ? 10 : 20) + shp;
     }
     const int kbk = kernel_bk_of(code);
     E2_REQUIRE(kbk != 0, E2FGVI_EINVAL, "conv2d: bad tile code %d", code);

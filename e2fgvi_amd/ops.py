@@ -57,7 +57,8 @@ class PackedConv:
         if bk is None:
             # K-chunk granule: 32 unless padding every source up to a multiple of 32 wastes more than ~8 % of K
             pad32 = sum((c + 31) // 32 * 32 for c in self.cpg)
-            bk = 32 if pad32 <= 1.08 * sum(self.cpg) else 16
+            pad16 = sum((c + 15) // 16 * 16 for c in self.cpg)
+            bk = 32 if pad32 <= 1.08 * sum(self.cpg) else (16 if pad16 <= 1.08 * sum(self.cpg) else 8)
         self.bk = bk
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         n = lib.e2fgvi_packed_conv_weight_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, bk)

@@ -60,7 +60,7 @@ typedef struct {
     int32_t KH, KW, stride, pad;
     int32_t groups;
     int32_t Cout;                      /* total output channels                                    */
-    int32_t bk;                        /* K-chunk the weights were packed for: 16 or 32            */
+    int32_t bk;                        /* K-chunk the weights were packed for: 8, 16 or 32         */
     const float* wpacked;
     const float* bias;                 /* [Cout] or NULL                                           */
     const float* residual;             /* NHWC [N,Ho,Wo,*] added before the activation, or NULL    */

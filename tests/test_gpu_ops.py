@@ -65,7 +65,7 @@ CONV_CASES = [
     (3, 16, 32, [32], 1, 16, 7, 1, 3, 1, False, 10008, None),
     (3, 16, 32, [32], 1, 64, 7, 1, 3, 1, False, 10009, None),
     (3, 20, 25, [64], 1, 64, 7, 1, 3, 1, True, 10010, None),
-    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10007, None),                 # spynet conv 1 (8 channels, padded block)
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10007, 16),                   # spynet conv 1 (8 channels, padded block)
     (2, 16, 24, [128, 192], 2, 512, 3, 1, 1, 2, False, 10001, None),         # grouped, two sources
     (1, 30, 54, [128, 128, 128, 4], 1, 128, 3, 1, 1, 2, False, 10001, None),  # four sources incl. a 4-channel one
     (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 10006, None),                 # tanh + 3 output channels
@@ -77,9 +77,26 @@ CONV_CASES = [
     (2, 17, 40, [32], 1, 16, 3, 1, 1, 1, False, 10032, None),
     (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 10026, None),
     (3, 16, 32, [64], 1, 32, 7, 1, 3, 1, False, 10027, None),
-    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10027, None),
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10027, 16),
     (3, 20, 25, [64], 1, 64, 7, 1, 3, 1, True, 10030, None),
     (3, 16, 32, [32], 1, 16, 7, 1, 3, 1, False, 10028, None),
+    # 16-output-channel tiles on v_mfma_f32_16x16x4_f32
+    (3, 16, 32, [32], 1, 16, 7, 1, 3, 1, False, 10041, None),
+    (3, 20, 33, [16], 1, 2, 7, 1, 3, 0, True, 10041, None),
+    (2, 17, 40, [64], 1, 3, 3, 1, 1, 3, False, 10042, None),
+    (2, 17, 40, [32], 1, 16, 3, 1, 1, 2, True, 10042, None),
+    (3, 16, 32, [64], 1, 12, 7, 1, 3, 1, False, 10043, None),
+    (2, 17, 40, [64], 1, 16, 3, 1, 1, 1, False, 10044, None),
+    (2, 17, 40, [32], 1, 5, 3, 1, 1, 1, False, 10045, None),
+    (3, 16, 32, [16], 1, 16, 7, 1, 3, 1, False, 10046, None),
+    # 8-channel K-chunks (pack granule 8): implicit GEMM and halo
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 0, 8),
+    (2, 24, 32, [4], 1, 64, 3, 2, 1, 2, False, 0, 8),
+    (3, 4, 8, [8], 1, 32, 7, 1, 3, 1, False, 0, 8),
+    (3, 16, 32, [8], 1, 32, 7, 1, 3, 1, False, 10051, 8),
+    (2, 24, 32, [8], 1, 24, 3, 1, 1, 2, True, 10052, 8),
+    (2, 24, 32, [4], 1, 64, 3, 1, 1, 2, False, 10053, 8),
+    (2, 24, 32, [8], 1, 64, 7, 1, 3, 2, False, 10054, 8),
 ]
 
 

@@ -30,20 +30,15 @@ SHAPES = {
     "dec6": (10, 240, 432, [64], 1, 3, 3, 1, 1, 32),
     "spy1": (18, 64, 128, [8], 1, 32, 7, 1, 3, 16),
     "spy4": (18, 64, 128, [32], 1, 16, 7, 1, 3, 32),
+    "spy1b8": (18, 64, 128, [8], 1, 32, 7, 1, 3, 8),
     "spy5": (18, 64, 128, [16], 1, 2, 7, 1, 3, 16),
 }
 CODES = {
-    "enc8": [0, 10004, 10024, 10022],
-    "enc2": [0, 10011, 10031],
-    "dec0": [0, 10002, 10022],
-    "dec2": [0, 10011, 10031],
-    "dec4": [0, 10011, 10031, 10025],
-    "dec6": [0, 10012, 10032, 10026],
-    "spy1": [0, 10007, 10027],
-    "spy2": [0, 10010, 10030],
-    "spy3": [0, 10007, 10027, 10028],
-    "spy4": [0, 10007, 10027, 10028],
-    "spy5": [0, 10007, 10027],
+    "dec6": [10012, 10042, 10045, 10044],
+    "spy1": [10027, 0],
+    "spy1b8": [0, 10051, 244],
+    "spy4": [10027, 10041, 10046, 10043],
+    "spy5": [10027, 10041, 10046],
 }
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
