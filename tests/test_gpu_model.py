@@ -182,6 +182,26 @@ def test_full_size_properties(dev):
     assert o2.abs().max().item() <= 1.0            # tanh range
 
 
+def test_full_size_against_oracle(dev):
+    """the BASELINE configuration itself (432x240, T = l_t = 10, default random-init weights and stress weights)
+    against the CPU oracle: max |d| <= 1e-3 on the output frames (north star)"""
+    import importlib
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    from oracle import e2fgvi_oracle as O
+    x, _ = synth_clip(1, 10, 240, 432, seed=100)
+    for kind in ("default", "stress"):
+        sd = synth_state_dict("e2fgvi", kind, 0)
+        net = importlib.import_module("model.e2fgvi").InpaintGenerator()
+        net.load_state_dict(sd)
+        net = net.to(dev).eval()
+        got, (ff, fb) = net(x.to(dev), 10)
+        ref, (rf, rb) = O.forward(sd, x, 10, "e2fgvi")
+        d, r = err(got, ref)
+        print("full size %s: max abs %.3e (%.2e x rms)" % (kind, d, r))
+        assert d <= 1e-3 and r <= 2e-2
+        assert err(ff, rf)[0] <= 1e-3 * max(1.0, rf.abs().max().item())
+
+
 def test_argument_errors(dev):
     """the drop-in raises where the reference would fail or silently mis-compute"""
     import importlib

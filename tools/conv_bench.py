@@ -31,14 +31,13 @@ SHAPES = {
     "spy1": (18, 64, 128, [8], 1, 32, 7, 1, 3, 16),
     "spy4": (18, 64, 128, [32], 1, 16, 7, 1, 3, 32),
     "spy1b8": (18, 64, 128, [8], 1, 32, 7, 1, 3, 8),
+    "enc0_b8": (10, 240, 432, [4], 1, 64, 3, 2, 1, 8),
+    "enc0_b16": (10, 240, 432, [4], 1, 64, 3, 2, 1, 16),
     "spy5": (18, 64, 128, [16], 1, 2, 7, 1, 3, 16),
 }
 CODES = {
-    "dec6": [10012, 10042, 10045, 10044],
-    "spy1": [10027, 0],
-    "spy1b8": [0, 10051, 244],
-    "spy4": [10027, 10041, 10046, 10043],
-    "spy5": [10027, 10041, 10046],
+    "enc0_b8": [0, 242, 243, 245],
+    "enc0_b16": [0, 212, 213],
 }
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
