@@ -44,6 +44,18 @@ struct ConvParams {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// E2FGVI_ACT_DCNPOST: SecondOrderDeformableAlignment's post-processing of the conv_offset output (reference
+// model/modules/feat_prop.py:38-53) fused into the producing conv: channels [0, 2C/3) are (dy,dx)-interleaved offsets
+// -> max_residue * tanh(v) + flow (dy takes the flow's y component; first half of the offsets uses flow_1, second half
+// flow_2); channels [2C/3, C) are masks -> sigmoid(v).  fl = this pixel's (u1, v1, u2, v2).
+__device__ __forceinline__ float dcn_post(float v, int co, int C, const float* fl, float max_residue) {
+    const int noff = (C / 3) * 2;
+    if (co >= noff) return 1.f / (1.f + expf(-v));
+    const int which = (co * 2 >= noff) ? 2 : 0;
+    const float f = fl[which + ((co & 1) ? 0 : 1)];       // even channel = dy <- v (index 1), odd = dx <- u (index 0)
+    return max_residue * tanhf(v) + f;
+}
+
 // raw buffer resource: out-of-range offsets (>= bytes) return 0 -- the hardware does the zero padding of the
 // convolution halo, of the padded channels and of the K tail, with no branch and no select on the loaded data
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -257,8 +269,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void conv_igemm_kernel(const C
                 const int m = m0 + (wm * TM + tm) * 32 + row;
                 if (m >= p.M) continue;
                 float v = acc[tm][tn][r] + bv;
-                if (p.res) v += p.res[(long long)m * p.res_ld + p.res_coff + co];
-                v = apply_act(v, p.act, p.slope);
+                if (p.act == E2FGVI_ACT_DCNPOST) v = dcn_post(v, co, p.Cout, p.res + (long long)m * 4, p.slope);
+                else {
+                    if (p.res) v += p.res[(long long)m * p.res_ld + p.res_coff + co];
+                    v = apply_act(v, p.act, p.slope);
+                }
                 if (p.dst_nchw) {
                     const int img = m / HoWo, rem = m - img * HoWo;
                     p.dst[((long long)img * p.Cout + co) * HoWo + rem] = v;
@@ -467,8 +482,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
                 if (oy >= p.Ho || ox >= p.Wo) continue;
                 const long long m = ((long long)img * p.Ho + oy) * p.Wo + ox;
                 float v = acc[tm][tn][r] + bv;
-                if (p.res) v += p.res[m * p.res_ld + p.res_coff + co];
-                v = apply_act(v, p.act, p.slope);
+                if (p.act == E2FGVI_ACT_DCNPOST) v = dcn_post(v, co, p.Cout, p.res + m * 4, p.slope);
+                else {
+                    if (p.res) v += p.res[m * p.res_ld + p.res_coff + co];
+                    v = apply_act(v, p.act, p.slope);
+                }
                 if (p.dst_nchw)
                     p.dst[((long long)img * p.Cout + co) * ((long long)p.Ho * p.Wo) + (long long)oy * p.Wo + ox] = v;
                 else
@@ -653,8 +671,11 @@ __global__ __launch_bounds__(64 * WGM) void conv_halo16_kernel(const ConvParams 
                     if (oy >= p.Ho || ox >= p.Wo) continue;
                     const long long m = ((long long)img * p.Ho + oy) * p.Wo + ox;
                     float v = acc[tm][r][e] + bv;
-                    if (p.res) v += p.res[m * p.res_ld + p.res_coff + co];
-                    v = apply_act(v, p.act, p.slope);
+                    if (p.act == E2FGVI_ACT_DCNPOST) v = dcn_post(v, co, p.Cout, p.res + m * 4, p.slope);
+                    else {
+                        if (p.res) v += p.res[m * p.res_ld + p.res_coff + co];
+                        v = apply_act(v, p.act, p.slope);
+                    }
                     if (p.dst_nchw)
                         p.dst[((long long)img * p.Cout + co) * ((long long)p.Ho * p.Wo) + (long long)oy * p.Wo + ox] = v;
                     else
@@ -921,6 +942,9 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
     p.w = d->wpacked; p.bias = d->bias; p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_nchw = d->dst_nchw;
     p.act = d->act; p.slope = d->slope;
+    if (d->act == E2FGVI_ACT_DCNPOST)
+        E2_REQUIRE(d->residual && d->res_ld == 4 && d->Cout % 3 == 0 && d->groups == 1 && !d->dst_nchw, E2FGVI_EINVAL,
+                   "conv2d: ACT_DCNPOST needs residual = flows [P,4], Cout multiple of 3, groups 1, NHWC output");
     if (!d->dst_nchw)
         E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d: dst slice exceeds dst_ld");
     int code = d->tile;

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedDcn, PackedLinear
+from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedDcn, PackedLinear
 
 WIN = (5, 9)
 
@@ -262,9 +262,10 @@ class Engine:
                     x = off_convs[0]([(cond, 0), cur, (cond, ch), fl], **lk)
                     x = off_convs[1]([x], **lk)
                     x = off_convs[2]([x], **lk)
-                    raw = off_convs[3]([x])
-                    feat_prop = dcn([feat_prop, feat_n2 if feat_n2 is not None else zero], raw, flows=fl,
-                                    max_residue=10.0)
+                    # 10*tanh + flow.flip / sigmoid (feat_prop.py:38-53) applied in the epilogue of the last conv_offset
+                    # layer: the deformable conv then reads finished offsets and masks
+                    offs = off_convs[3]([x], residual=fl, act=ACT_DCNPOST, slope=10.0)
+                    feat_prop = dcn([feat_prop, feat_n2 if feat_n2 is not None else zero], offs)
                 srcs = [cur, feats["backward_"][idx], feat_prop] if name == "forward_" else [cur, feat_prop]
                 y = bb[0](srcs, **lk)
                 feat_prop = bb[1]([y], residual=feat_prop, out=store[idx])

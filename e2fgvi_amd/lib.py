@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libe2fgvi_hip.so")
 
 MAX_SRC = 4
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_DCNPOST = 0, 1, 2, 3, 4
 
 _fp = C.c_void_p   # device pointers travel as plain addresses
 

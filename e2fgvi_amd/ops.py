@@ -11,7 +11,7 @@ import torch
 
 from . import lib as _L
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = _L.ACT_NONE, _L.ACT_RELU, _L.ACT_LRELU, _L.ACT_TANH
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_DCNPOST = _L.ACT_NONE, _L.ACT_RELU, _L.ACT_LRELU, _L.ACT_TANH, _L.ACT_DCNPOST
 
 
 def _stream():

@@ -31,6 +31,10 @@ extern "C" {
 #define E2FGVI_ACT_RELU 1
 #define E2FGVI_ACT_LRELU 2   /* slope in desc */
 #define E2FGVI_ACT_TANH 3
+/* conv_offset post-processing of SecondOrderDeformableAlignment (feat_prop.py:38-53) fused into the conv that produces
+ * it: `residual` must point to the per-pixel flows [P,4] = (u1,v1,u2,v2) with res_ld = 4, `slope` = max_residue:
+ * offset channels -> slope*tanh(v) + flow.flip, mask channels (last third) -> sigmoid(v) */
+#define E2FGVI_ACT_DCNPOST 4
 
 #define E2FGVI_MAX_SRC 4
 

@@ -123,6 +123,26 @@ def test_conv(dev, case):
     assert_close(nchw(out.cpu()), ref, REL, "conv")
 
 
+def test_conv_dcn_postprocess_epilogue(dev):
+    """ACT_DCNPOST: conv_offset's last layer emits finished offsets / masks (feat_prop.py:38-53)"""
+    from e2fgvi_amd import ops
+    g = _gen(30)
+    N, H, W = 2, 14, 22
+    x = torch.randn(N, 128, H, W, generator=g)
+    w = torch.randn(432, 128, 3, 3, generator=g) / 40
+    b = torch.randn(432, generator=g) * 0.1
+    f1 = torch.randn(N, 2, H, W, generator=g) * 2
+    f2 = torch.randn(N, 2, H, W, generator=g) * 2
+    raw = F.conv2d(x, w, b, padding=1)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    off = 10 * torch.tanh(torch.cat((o1, o2), 1))
+    q1, q2 = torch.chunk(off, 2, 1)
+    ref = torch.cat([q1 + f1.flip(1).repeat(1, 72, 1, 1), q2 + f2.flip(1).repeat(1, 72, 1, 1), torch.sigmoid(m)], 1)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), [128], pad=1)
+    out = layer([nhwc(x).to(dev)], residual=nhwc(torch.cat([f1, f2], 1)).to(dev), act=ops.ACT_DCNPOST, slope=10.0)
+    assert_close(nchw(out.cpu()), ref, 2e-5, "dcn post-process epilogue")
+
+
 def test_conv_slices_and_nchw_out(dev):
     """channel-offset sources, output into a slice of a wider buffer, NCHW store."""
     from e2fgvi_amd import ops
