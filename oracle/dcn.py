@@ -13,6 +13,9 @@ published algorithm of ``modulated_deformable_im2col`` + GEMM:
       col = val * m
   out = W[Co, C*K] @ col + bias
 
+PARITY UNPINNED for this one op: mmcv-full 1.4.8 is neither under /root/reference nor installable here, and the
+reference has no tests or golden vectors at this boundary, so the restatement cannot be checked against mmcv's own
+output.  Everything else in the oracle is pinned against the reference's own Python run in the build container.
 Parity anchors (no golden vectors exist upstream -- SURVEY.md 8c): the reference call site
 model/modules/feat_prop.py:55-58, and the cross-checks in tests/test_oracle_dcn.py
 (zero offset + unit mask == F.conv2d; integer offsets == shifted conv; constant sub-pixel
