@@ -69,12 +69,20 @@ def build_key_table(fh, fw, valid_ind_rolled):
 
 
 class Engine:
-    def __init__(self, state_dict, model="e2fgvi", device="cuda"):
+    def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32"):
+        """precision="fp32": every contraction on fp32 MFMA (the default and the parity configuration).
+        precision="bf16": the wide conv / linear layers run on bf16 MFMA with fp32 accumulation (BASELINE.json HQ
+        configurations); SPyNet, the first / last conv, conv_offset's last layer, the deformable conv and the attention
+        stay fp32, all tensors in HBM stay fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         self.hq = model == "e2fgvi_hq"
         self.device = torch.device(device)
         sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
         self.sd = sd
         f = lambda k: sd[k].float().contiguous()
+        pw = dict(precision=precision)          # layers that follow the precision mode
 
         # ---- encoder (e2fgvi.py:75-94)
         w0 = torch.zeros(64, 4, 3, 3, device=self.device)
@@ -84,13 +92,13 @@ class Engine:
                                   (([64], 1, 1), ([64], 1, 2), ([128], 1, 1), ([256], 1, 1), ([128, 192], 2, 1),
                                    ([64, 128], 4, 1), ([32, 48], 8, 1), ([256, 256], 1, 1))):
             enc.append(PackedConv(f("encoder.layers.%d.weight" % i), f("encoder.layers.%d.bias" % i), cpg, groups=g,
-                                  stride=s, pad=1))
+                                  stride=s, pad=1, **pw))
         self.enc = enc
 
         # ---- decoder (e2fgvi.py:143-150)
-        self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1),
-                    PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1),
-                    PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1),
+        self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1, **pw),
+                    PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1, **pw),
+                    PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1, **pw),
                     PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)
@@ -98,25 +106,26 @@ class Engine:
         for d, nparts in (("backward_", 2), ("forward_", 3)):
             p = "feat_prop_module.deform_align.%s." % d
             # conv_offset.0 input = cat(cond_n1, cur, cond_n2, flow_1, flow_2): sources (cond|0), cur, (cond|128), flows4
-            off = [PackedConv(f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias"), [128, 128, 128, 4], pad=1),
-                   PackedConv(f(p + "conv_offset.2.weight"), f(p + "conv_offset.2.bias"), [128], pad=1),
-                   PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1),
+            off = [PackedConv(f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias"), [128, 128, 128, 4], pad=1, **pw),
+                   PackedConv(f(p + "conv_offset.2.weight"), f(p + "conv_offset.2.bias"), [128], pad=1, **pw),
+                   PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1, **pw),
                    PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1)]
             dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1)
             b = "feat_prop_module.backbone.%s." % d
-            bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1),
-                  PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1)]
+            bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **pw),
+                  PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **pw)]
             self.prop[d] = (off, dcn, bb)
-        self.fusion = PackedConv(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128])
+        self.fusion = PackedConv(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128], **pw)
 
         # ---- soft split / composite (tfocal_transformer.py:19-72)
-        self.ss = PackedConv(f("ss.embedding.weight").view(512, 128, 7, 7), f("ss.embedding.bias"), [128], stride=3, pad=3)
+        self.ss = PackedConv(f("ss.embedding.weight").view(512, 128, 7, 7), f("ss.embedding.bias"), [128], stride=3, pad=3,
+                             **pw)
         # patch channel order c*49+tap -> tap*128+c (private layout of the fold kernels)
         wsc = f("sc.embedding.weight").view(128, 49, 512).permute(1, 0, 2).reshape(6272, 512).contiguous()
         bsc = f("sc.embedding.bias").view(128, 49).t().reshape(6272).contiguous()
-        self.sc = PackedLinear(wsc, bsc)
+        self.sc = PackedLinear(wsc, bsc, **pw)
         if self.hq:
-            self.sc_bias_conv = PackedConv(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1)
+            self.sc_bias_conv = PackedConv(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1, **pw)
             self.sc_bias_hwc = None
         else:
             self.sc_bias_hwc = f("sc.bias").permute(1, 2, 0).contiguous()
@@ -131,9 +140,9 @@ class Engine:
             self.blocks.append(dict(
                 pool_w=f(p + "pool_layers.0.weight").view(45), pool_b=f(p + "pool_layers.0.bias"),
                 n1w=f(p + "norm1.weight"), n1b=f(p + "norm1.bias"), n2w=f(p + "norm2.weight"), n2b=f(p + "norm2.bias"),
-                qkv=PackedLinear(f(p + "attn.qkv.weight"), f(p + "attn.qkv.bias")),
-                proj=PackedLinear(f(p + "attn.proj.weight"), f(p + "attn.proj.bias")),
-                fc1=PackedLinear(w1, b1), fc2=PackedLinear(w2, f(p + "mlp.conv2.1.bias")),
+                qkv=PackedLinear(f(p + "attn.qkv.weight"), f(p + "attn.qkv.bias"), **pw),
+                proj=PackedLinear(f(p + "attn.proj.weight"), f(p + "attn.proj.bias"), **pw),
+                fc1=PackedLinear(w1, b1, **pw), fc2=PackedLinear(w2, f(p + "mlp.conv2.1.bias"), **pw),
                 valid=sd[p + "attn.valid_ind_rolled"].cpu().tolist()))
 
         # ---- SPyNet (flow_comp.py:49-82,172-215)
@@ -152,7 +161,11 @@ class Engine:
         self.half = torch.full((4,), 0.5, device=self.device)
         self._tables = {}
         self._zeros = {}
-        self.overlap_flows = True
+        # SPyNet runs on a side stream next to the encoder -- fp32 mode only.  Measured on MI355X (tools/overlap_probe.py,
+        # DESIGN.md "Stream overlap"): with the 2x2-accumulator bf16 conv tiles on the other stream, spynet_level_input
+        # intermittently produced wrong values in lanes 48-63 of a wave; no fp32 kernel ever triggered it, and the bf16
+        # kernels themselves are bit-reproducible on one stream.  bf16 mode therefore stays on a single stream.
+        self.overlap_flows = precision == "fp32"
         self._side = None
         torch.cuda.synchronize(self.device)
 

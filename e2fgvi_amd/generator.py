@@ -165,6 +165,8 @@ class _InpaintGeneratorBase(nn.Module):
         self.update_spynet = SPyNet()        # built after init_weights, like the reference (e2fgvi.py:208)
         self._engine = None
         self._engine_key = None
+        # "fp32" (default, the parity configuration) or "bf16" (optional bf16-MFMA mode for the HQ configurations)
+        self.precision = "fp32"
 
     def init_weights(self, init_type="normal", gain=0.02):
         """Distribution of the reference's BaseNetwork.init_weights (e2fgvi.py:29-68) followed by
@@ -188,7 +190,7 @@ class _InpaintGeneratorBase(nn.Module):
     # -- engine cache -------------------------------------------------------------------------
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
-        return (str(ps[0].device), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:8]))
+        return (str(ps[0].device), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:8]), self.precision)
 
     def engine(self):
         from .engine import Engine
@@ -198,7 +200,7 @@ class _InpaintGeneratorBase(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("InpaintGenerator runs only on an MI355X (ROCm 'cuda') device: move the module "
                                    "with .to('cuda'); there is no CPU path")
-            self._engine = Engine(self.state_dict(), self.MODEL, dev)
+            self._engine = Engine(self.state_dict(), self.MODEL, dev, precision=self.precision)
             self._engine_key = key
         return self._engine
 

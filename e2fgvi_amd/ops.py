@@ -44,7 +44,9 @@ class PackedConv:
     cpg:    channels per group contributed by each source of the virtual input concat.
     """
 
-    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None):
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32"):
+        """precision: "fp32" (default: fp32 MFMA, bit-equivalent to an fp32 FMA chain) or "bf16" (optional mode for
+        the HQ configurations: bf16 MFMA, fp32 accumulate, fp32 tensors in HBM)."""
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -54,6 +56,20 @@ class PackedConv:
         if sum(self.cpg) != cin_g:
             raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
         self.groups, self.stride, self.pad = groups, stride, pad
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        if precision == "bf16":
+            self.bk = 32
+            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+            n = lib.e2fgvi_packed_conv_weight_bf16_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
+            if n < 0:
+                _L.check(int(n), "packed_conv_weight_bf16_size")
+            self.wpacked = torch.empty(int(n), dtype=torch.bfloat16, device=w.device)
+            _L.check(lib.e2fgvi_pack_conv_weight_bf16(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
+                                                      len(self.cpg), arr, _stream()), "pack_conv_weight_bf16")
+            self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+            return
         if bk is None:
             # K-chunk granule: 32 unless padding every source up to a multiple of 32 wastes more than ~8 % of K
             pad32 = sum((c + 31) // 32 * 32 for c in self.cpg)
@@ -131,15 +147,18 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
-        _L.check(lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+        if self.precision == "bf16":
+            _L.check(lib.e2fgvi_conv2d_nhwc_bf16(C.byref(d), _stream()), "conv2d_nhwc_bf16")
+        else:
+            _L.check(lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
         return out
 
 
 class PackedLinear(PackedConv):
     """y[rows, Cout] = x[rows, Cin] @ W^T + b (+ residual), rows treated as 1x1 images."""
 
-    def __init__(self, weight, bias, bk=None):
-        super().__init__(weight, bias, [weight.shape[1]], bk=bk)
+    def __init__(self, weight, bias, bk=None, precision="fp32"):
+        super().__init__(weight, bias, [weight.shape[1]], bk=bk, precision=precision)
 
     def __call__(self, x, out=None, residual=None, act=ACT_NONE, slope=0.0, tile=0):
         _chk(x, "x")

@@ -409,3 +409,45 @@ def test_mmcv_compatible_op(dev):
     out = m(x.to(dev), off.to(dev), msk.to(dev))
     ref = ref_op(x, off, msk, m.weight.detach().cpu(), m.bias.detach().cpu(), 1, 1, 1, 1, 2)
     assert_close(out.cpu(), ref, 5e-5, "mmcv-compatible op")
+
+
+BF16_CASES = [
+    # N, H, W, cpg, groups, Cout, k, stride, pad, act, residual, tile
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 2, True, 0),
+    (1, 33, 47, [64], 1, 128, 3, 1, 1, 0, False, 5),
+    (2, 30, 54, [128, 128, 128, 4], 1, 128, 3, 1, 1, 2, False, 1),
+    (2, 16, 24, [128, 192], 2, 512, 3, 1, 1, 2, False, 0),
+    (2, 24, 40, [64], 1, 64, 3, 2, 1, 2, False, 2),
+    (3, 16, 32, [32], 1, 64, 7, 1, 3, 1, False, 3),
+    (3, 16, 32, [96], 1, 32, 3, 1, 1, 1, False, 4),
+    (900, 1, 1, [512], 1, 1536, 1, 1, 0, 0, False, 0),
+    (700, 1, 1, [1960], 1, 512, 1, 1, 0, 0, True, 0),
+    (2, 64, 64, [256], 1, 384, 3, 1, 1, 2, False, 6),
+    (1, 40, 72, [64], 1, 3, 3, 1, 1, 3, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
+def test_conv_bf16_mode(dev, case):
+    """optional bf16-MFMA precision mode: (a) close to the fp32 result, (b) equal -- up to fp32 accumulation order --
+    to an fp32 convolution of bf16-rounded inputs and weights (i.e. only the operand rounding differs)"""
+    from e2fgvi_amd import ops
+    N, H, W, cpg, groups, Cout, k, stride, pad, act, use_res, tile = case
+    g = _gen(40)
+    srcs = [torch.randn(N, groups * c, H, W, generator=g) for c in cpg]
+    cin_g = sum(cpg)
+    w = torch.randn(Cout, cin_g, k, k, generator=g) / math.sqrt(cin_g * k * k)
+    b = torch.randn(Cout, generator=g)
+    xcat = torch.cat([s.view(N, groups, c, H, W) for s, c in zip(srcs, cpg)], 2).view(N, groups * cin_g, H, W)
+    res = None
+    ref32 = F.conv2d(xcat, w, b, stride=stride, padding=pad, groups=groups)
+    refbf = F.conv2d(xcat.bfloat16().float(), w.bfloat16().float(), b, stride=stride, padding=pad, groups=groups)
+    if use_res:
+        res = torch.randn(ref32.shape, generator=g)
+        ref32, refbf = ref32 + res, refbf + res
+    ref32, refbf = _act_ref(ref32, act, 0.2), _act_ref(refbf, act, 0.2)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=stride, pad=pad, precision="bf16")
+    out = layer([nhwc(s).to(dev) for s in srcs], residual=None if res is None else nhwc(res).to(dev), act=act, slope=0.2,
+                tile=tile)
+    assert_close(nchw(out.cpu()), refbf, 3e-5, "bf16 conv vs bf16-rounded fp32 reference")
+    assert_close(nchw(out.cpu()), ref32, 3e-2, "bf16 conv vs fp32")
