@@ -1,0 +1,446 @@
+// Winograd F(2x2, 3x3) fp32 convolution on the fp32 MFMA pipe (gfx950): 3x3, stride 1, pad 1, NHWC, virtual concat
+// of up to 4 sources, groups.  16 multiplies per 2x2 outputs instead of 36 -> 2.25x less MFMA work than the implicit
+// GEMM of conv.hip for the wide stride-1 layers (encoder, decoder, SoftComp bias conv).  Arithmetic stays fp32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 4x4 input patch d, 3x3 filter g  (Lavin & Gray, F(2x2,3x3))
+//   as 16 independent GEMMs  M_a[tile, cout] = sum_cin V_a[tile, cin] * U_a[cin, cout],  a = (xi, nu) in 4x4
+//
+// Workgroup = 8 waves = one 16x16-pixel output block (8x8 Winograd tiles = 2 MFMA row-tiles) x BN output channels.
+// Wave w owns the two transform positions a = 2w, 2w+1 (same xi = w>>1, nu in {0,1} or {2,3}) and keeps
+// 2 x 2 x (BN/32) 32x32 accumulators.  Per 8-channel chunk of the input:
+//   * the raw 18x18-pixel halo patch is staged ONCE in LDS (global -> registers -> LDS one stage ahead; a stage = two
+//     chunks, so one barrier per 16 channels; even/odd pixel columns live in separate planes, which makes the stride-2
+//     patch reads of the 32 tiles of an MFMA row-tile bank-conflict free);
+//   * every lane builds its MFMA A operands straight from the patch: 6 ds_read_b128 (2 rows x 3 columns of the 4x4
+//     patch, 4 channels each) and ~36 VALU ops give V for both of the wave's positions -- the transformed input never
+//     exists in memory;
+//   * B operands (the pre-transformed weights of the wave's own two positions) never touch LDS: one 16-byte buffer load
+//     per (position, column tile), issued one chunk ahead, is exactly the lane's operand quad; 8 MFMAs per tile pair.
+// Epilogue: the 16 M_a tiles meet in LDS, every thread applies A^T M A to one (tile, 4 couts) item, adds the bias,
+// applies the activation and stores 2x2 pixels x 16 bytes (128-byte runs along cout).
+//
+// Packed weights: [group][chunk][a = 16][kq = 2][Npad][4]  (chunk = 8 input channels in concat order, sources padded
+// to 8; kq = channel quad; Npad = Cout_g rounded up to 32), produced by e2fgvi_pack_winograd_weight.
+#include "common.h"
+
+namespace {
+
+struct WinoParams {
+    const float* src[E2FGVI_MAX_SRC];
+    int ld[E2FGVI_MAX_SRC];
+    int coff[E2FGVI_MAX_SRC];
+    int cpg[E2FGVI_MAX_SRC];
+    unsigned src_bytes[E2FGVI_MAX_SRC];
+    int nsrc;
+    int N, H, W;
+    int Cout, Cout_g, Npad;
+    int blocksY, blocksX, tilesN, nblk;
+    int nchunks;
+    unsigned wgroup_bytes;
+    long long wgroup_elems;
+    const float* w;
+    const float* bias;
+    float* dst;
+    int dst_ld, dst_coff;
+    int act;
+    float slope;
+    int vec_store;          // destination rows are 16-byte addressable for every group / cout tile
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+constexpr int RAW_W = 18;                 // raw patch is 18 x 18 pixels
+constexpr int PLANE_ROW = 12;             // 16-byte units per patch row in one column-parity plane (9 used)
+constexpr int PLANE_BYTES = RAW_W * PLANE_ROW * 16;       // 3456
+constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;               // planes of one 8-channel chunk: [kq][column parity]
+constexpr int STAGE_BYTES = 2 * CHUNK_BYTES;               // an LDS stage holds two chunks (one barrier per 16 channels)
+constexpr unsigned OOB = 0xFFFFFFFFu;
+template <int V> struct IC { static constexpr int value = V; };
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
+    constexpr int NT = 512;
+    constexpr int TN = BN / 32;
+    constexpr int EPI_BYTES = 16 * 64 * 32 * 4;
+    constexpr int SMEM = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int RAW_ITEMS = RAW_W * RAW_W * 2;          // (pixel, kq) of one chunk
+    constexpr int RAW_IT = (RAW_ITEMS + NT - 1) / NT;     // 2
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y;
+    const int logical = xcd_remap(blockIdx.x, p.nblk);
+    // spatial block fastest: the CUs of one XCD share the weight slab of one cout tile in their L2
+    const int mblocks = p.N * p.blocksY * p.blocksX;
+    const int tile_n = logical / mblocks;
+    int rem = logical - tile_n * mblocks;
+    const int img = rem / (p.blocksY * p.blocksX);
+    rem -= img * (p.blocksY * p.blocksX);
+    const int by = rem / p.blocksX, bx = rem - by * p.blocksX;
+    const int n0 = tile_n * BN;
+    const int y0 = by * 16 - 1, x0 = bx * 16 - 1;          // top-left of the raw patch
+
+    // ---- raw-patch staging bookkeeping (chunk invariant)
+    unsigned raw_off[RAW_IT];      // pixel index in its source, OOB if outside the image / no item
+    int raw_dst[RAW_IT];           // LDS byte offset inside a chunk area, -1 if the thread has no item
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int item = tid + it * NT;
+        const int kq = item & 1, px = item >> 1;
+        const int py = px / RAW_W, pxx = px - py * RAW_W;
+        const int gy = y0 + py, gx = x0 + pxx;
+        const bool have = item < RAW_ITEMS;
+        const bool in = have && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        raw_off[it] = in ? (unsigned)((img * p.H + gy) * p.W + gx) : OOB;
+        raw_dst[it] = have ? (kq * 2 + (pxx & 1)) * PLANE_BYTES + (py * PLANE_ROW + (pxx >> 1)) * 16 : -1;
+    }
+    const unsigned raw_kq16 = (unsigned)(tid & 1) * 16u;            // NT is even: the kq of an item is the thread's parity
+
+    // Chunks past the end (odd chunk count, prefetch overrun) need no guards: their weight loads fall outside the
+    // group's buffer range and return zeros, so whatever patch data is re-read contributes nothing.
+    int s = 0, c0 = 0;              // next chunk to load: source, first channel inside the group's slice
+    f32x4 rraw[2][RAW_IT];
+    auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
+        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
+        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u + raw_kq16;
+#pragma unroll
+        for (int it = 0; it < RAW_IT; ++it)
+            q[it] = buf_load4(arsrc, raw_off[it] != OOB ? raw_off[it] * ld4 + chan : OOB);
+        c0 += 8;
+        if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
+    };
+    auto store_raw = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int it = 0; it < RAW_IT; ++it)
+                if (raw_dst[it] >= 0) *reinterpret_cast<f32x4*>(base + q * CHUNK_BYTES + raw_dst[it]) = rraw[q][it];
+    };
+
+    // ---- this wave's transform positions: xi = wave >> 1, nu in {0,1} (pair A) or {2,3} (pair B)
+    //   B^T rows:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3          (same combinations over columns)
+    //   pair A reads patch columns 0,1,2:  nu0 = c0 - c2,  nu1 = c1 + c2
+    //   pair B reads patch columns 1,2,3:  nu2 = c2 - c1,  nu3 = c1 - c3
+    const int xi = wave >> 1;
+    const int ra0 = (xi == 0) ? 0 : 1, ra1 = (xi == 3) ? 3 : 2;
+    const int cb = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int ty = i >> 3, tx = i & 7;
+    // LDS byte offsets (inside a chunk area) of the 6 patch reads for row-tile 0; row-tile 1 is 8 patch rows lower
+    int a_off[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int prow = 2 * ty + (r ? ra1 : ra0);
+            const int col = cb + j;                                  // patch column 0..3 -> pixel column 2*tx + col
+            a_off[r][j] = (h * 2 + (col & 1)) * PLANE_BYTES + (prow * PLANE_ROW + tx + (col >> 1)) * 16;
+        }
+
+    // ---- B operands (pre-transformed weights) go global -> registers, no LDS: lane (i, h) of position a, column
+    // tile n needs U[chunk][2*wave + a][kq = h][n0 + 32 n + i][0..3] = one 16-byte load
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_elems, p.wgroup_bytes);
+    const unsigned u_step = 32u * (unsigned)p.Npad * 16u;          // bytes per chunk
+    unsigned u_off[2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + n * 32 + i;
+            // columns past Npad: an offset that stays out of range for every chunk (group size is < 0x70000000 bytes)
+            u_off[a][n] = col < p.Npad ? (unsigned)((((2 * wave + a) * 2 + h) * p.Npad + col) * 16) : 0x80000000u;
+        }
+    f32x4 bq[2][2][TN];
+    auto load_b = [&](int chunk, f32x4 (&q)[2][TN]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) q[a][n] = buf_load4(wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
+    };
+
+    f32x16 acc[2][2][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
+
+    const int nstages = (p.nchunks + 1) >> 1;
+    load_raw(rraw[0]);
+    load_raw(rraw[1]);
+    load_b(0, bq[0]);
+    store_raw(0);
+    load_raw(rraw[0]);
+    load_raw(rraw[1]);
+    __syncthreads();
+
+    // the K loop, specialised on the wave's role so that the input transform is plain adds / subtracts
+    auto k_loop = [&](auto XI_, auto PB_) {
+        constexpr int XI = decltype(XI_)::value;
+        constexpr bool PB = decltype(PB_)::value != 0;
+        for (int st = 0; st < nstages; ++st) {
+            const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                load_b(2 * st + q + 1, bq[q ^ 1]);                   // next chunk's weights land during this chunk
+                const unsigned char* raw = stage + q * CHUNK_BYTES;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const unsigned char* rm = raw + m * (8 * PLANE_ROW * 16);
+                    f32x4 e[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const f32x4 d0 = *reinterpret_cast<const f32x4*>(rm + a_off[0][j]);
+                        const f32x4 d1 = *reinterpret_cast<const f32x4*>(rm + a_off[1][j]);
+                        e[j] = XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
+                    }
+                    const f32x4 va = PB ? e[1] - e[0] : e[0] - e[2];
+                    const f32x4 vb = PB ? e[0] - e[2] : e[1] + e[2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n) {
+                            acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[k], bq[q][0][n][k], acc[0][m][n], 0, 0, 0);
+                            acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q][1][n][k], acc[1][m][n], 0, 0, 0);
+                        }
+                }
+            }
+            // the registers hold stage st+1: park it in the other buffer (its readers passed the previous barrier)
+            store_raw((st & 1) ^ 1);
+            load_raw(rraw[0]);
+            load_raw(rraw[1]);
+            __syncthreads();
+        }
+    };
+    switch (wave) {          // wave-uniform
+        case 0: k_loop(IC<0>{}, IC<0>{}); break;
+        case 1: k_loop(IC<0>{}, IC<1>{}); break;
+        case 2: k_loop(IC<1>{}, IC<0>{}); break;
+        case 3: k_loop(IC<1>{}, IC<1>{}); break;
+        case 4: k_loop(IC<2>{}, IC<0>{}); break;
+        case 5: k_loop(IC<2>{}, IC<1>{}); break;
+        case 6: k_loop(IC<3>{}, IC<0>{}); break;
+        default: k_loop(IC<3>{}, IC<1>{}); break;
+    }
+
+    // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, activation, store
+    float* E = reinterpret_cast<float*>(smem);
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int nh = 0; nh < TN; ++nh) {
+        if (nh) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    E[((2 * wave + a) * 64 + tile) * 32 + i] = acc[a][m][nh][r];
+                }
+        __syncthreads();
+        // one (tile, 4 consecutive couts) item per thread: 16 ds_read_b128, A^T M A, 4 stores of 16 bytes
+        const int cq = tid & 7, tile = tid >> 3;
+        const int n = n0 + nh * 32 + cq * 4;
+        f32x4 mm[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) mm[a] = *reinterpret_cast<const f32x4*>(E + (a * 64 + tile) * 32 + cq * 4);
+        // A^T = [1 1 1 0; 0 1 -1 -1]
+        f32x4 t0[4], t1[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            t0[nu] = mm[0 * 4 + nu] + mm[1 * 4 + nu] + mm[2 * 4 + nu];
+            t1[nu] = mm[1 * 4 + nu] - mm[2 * 4 + nu] - mm[3 * 4 + nu];
+        }
+        f32x4 y[4];
+        y[0] = t0[0] + t0[1] + t0[2];
+        y[1] = t0[1] - t0[2] - t0[3];
+        y[2] = t1[0] + t1[1] + t1[2];
+        y[3] = t1[1] - t1[2] - t1[3];
+        const int oy = by * 16 + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7);
+        if (n < p.Cout_g && oy < p.H && ox < p.W) {       // H and W are even: a tile is inside or outside as a whole
+            const int co = g * p.Cout_g + n;
+            float* o = p.dst + ((long long)img * HW + (long long)oy * p.W + ox) * p.dst_ld + p.dst_coff + co;
+            const long long poff[4] = {0, p.dst_ld, (long long)p.W * p.dst_ld, (long long)(p.W + 1) * p.dst_ld};
+            if (p.vec_store && n + 3 < p.Cout_g) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) { bv[0] = p.bias[co]; bv[1] = p.bias[co + 1]; bv[2] = p.bias[co + 2]; bv[3] = p.bias[co + 3]; }
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    f32x4 v = y[px] + bv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+                    *reinterpret_cast<f32x4*>(o + poff[px]) = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (n + c >= p.Cout_g) break;
+                    const float bv = p.bias ? p.bias[co + c] : 0.f;
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) o[poff[px] + c] = apply_act(y[px][c] + bv, p.act, p.slope);
+                }
+            }
+        }
+    }
+}
+
+struct WinoPack {
+    int Cout, groups, nsrc;
+    int cpg[E2FGVI_MAX_SRC];
+    int Cout_g, Npad, Cin_g, nchunks;
+    long long wgroup_elems, total;
+};
+
+bool wino_geometry(int Cout, int groups, int nsrc, const int32_t* cpg, WinoPack* q) {
+    if (Cout <= 0 || groups <= 0 || Cout % groups || nsrc < 1 || nsrc > E2FGVI_MAX_SRC) return false;
+    q->Cout = Cout; q->groups = groups; q->nsrc = nsrc;
+    q->Cout_g = Cout / groups;
+    q->Npad = round_up(q->Cout_g, 32);
+    q->Cin_g = 0; q->nchunks = 0;
+    for (int s = 0; s < E2FGVI_MAX_SRC; ++s) q->cpg[s] = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (cpg[s] <= 0 || cpg[s] % 8) return false;
+        q->cpg[s] = cpg[s];
+        q->Cin_g += cpg[s];
+        q->nchunks += cpg[s] / 8;
+    }
+    q->wgroup_elems = (long long)q->nchunks * 16 * 2 * q->Npad * 4;
+    q->total = q->wgroup_elems * groups;
+    return true;
+}
+
+__global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, const WinoPack p) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.total) return;
+    const int g = (int)(idx / p.wgroup_elems);
+    long long rem = idx - (long long)g * p.wgroup_elems;
+    const int kk = (int)(rem & 3);
+    rem >>= 2;
+    const int n = (int)(rem % p.Npad);
+    rem /= p.Npad;
+    const int kq = (int)(rem & 1);
+    rem >>= 1;
+    const int a = (int)(rem & 15);
+    const int chunk = (int)(rem >> 4);
+    // chunk -> (source, channel inside the group's slice of that source)
+    int s = 0, prefix = 0, ch = chunk * 8 + kq * 4 + kk;
+    while (ch >= p.cpg[s]) { ch -= p.cpg[s]; prefix += p.cpg[s]; ++s; }
+    float v = 0.f;
+    if (n < p.Cout_g) {
+        const float* f = w + ((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + ch) * 9;
+        // G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  U = G f G^T
+        const int xi = a >> 2, nu = a & 3;
+        float col[3];          // (G f)[xi][j]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float f0 = f[0 * 3 + j], f1 = f[1 * 3 + j], f2 = f[2 * 3 + j];
+            col[j] = xi == 0 ? f0 : xi == 1 ? 0.5f * (f0 + f1 + f2) : xi == 2 ? 0.5f * (f0 - f1 + f2) : f2;
+        }
+        v = nu == 0 ? col[0] : nu == 1 ? 0.5f * (col[0] + col[1] + col[2]) : nu == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2];
+    }
+    wp[idx] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t e2fgvi_packed_winograd_weight_size(int32_t Cout, int32_t groups, int32_t nsrc, const int32_t* src_cpg) {
+    WinoPack q;
+    if (!src_cpg || !wino_geometry(Cout, groups, nsrc, src_cpg, &q)) {
+        e2fgvi_set_error("packed_winograd_weight_size: bad geometry (channels per source must be multiples of 8)");
+        return E2FGVI_EINVAL;
+    }
+    return q.total;
+}
+
+extern "C" int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32_t Cout, int32_t groups, int32_t nsrc,
+                                           const int32_t* src_cpg, void* stream) {
+    WinoPack q;
+    E2_REQUIRE(w && wpacked && src_cpg, E2FGVI_EINVAL, "pack_winograd_weight: null pointer");
+    E2_REQUIRE(wino_geometry(Cout, groups, nsrc, src_cpg, &q), E2FGVI_EINVAL, "pack_winograd_weight: bad geometry");
+    hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       wpacked, q);
+    E2_LAUNCH_CHECK("pack_winograd_weight");
+    return 0;
+}
+
+extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) {
+    E2_REQUIRE(d, E2FGVI_EINVAL, "conv3x3_winograd: null descriptor");
+    WinoPack q;
+    E2_REQUIRE(wino_geometry(d->Cout, d->groups, d->nsrc, d->src_cpg, &q), E2FGVI_EINVAL,
+               "conv3x3_winograd: bad geometry (channels per source must be multiples of 8)");
+    E2_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, E2FGVI_EUNSUP,
+               "conv3x3_winograd: only 3x3, stride 1, pad 1");
+    E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, E2FGVI_EUNSUP,
+               "conv3x3_winograd: H and W must be even");
+    E2_REQUIRE(d->Ho == d->H && d->Wo == d->W, E2FGVI_EINVAL, "conv3x3_winograd: Ho/Wo must equal H/W");
+    E2_REQUIRE(d->wpacked && d->dst, E2FGVI_EINVAL, "conv3x3_winograd: null weight/dst");
+    E2_REQUIRE(!d->residual && !d->dst_nchw, E2FGVI_EUNSUP, "conv3x3_winograd: residual / NCHW output not supported");
+    E2_REQUIRE(d->act != E2FGVI_ACT_DCNPOST, E2FGVI_EUNSUP, "conv3x3_winograd: ACT_DCNPOST not supported");
+    E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv3x3_winograd: dst slice exceeds dst_ld");
+    WinoParams p;
+    for (int s = 0; s < E2FGVI_MAX_SRC; ++s) { p.src[s] = nullptr; p.ld[s] = 0; p.coff[s] = 0; p.cpg[s] = 0; p.src_bytes[s] = 0; }
+    for (int s = 0; s < d->nsrc; ++s) {
+        E2_REQUIRE(d->src[s], E2FGVI_EINVAL, "conv3x3_winograd: null source %d", s);
+        E2_REQUIRE(d->src_ld[s] % 4 == 0 && d->src_coff[s] % 4 == 0 && ((uintptr_t)d->src[s] & 15) == 0, E2FGVI_EINVAL,
+                   "conv3x3_winograd: source %d not 16-byte addressable", s);
+        E2_REQUIRE(d->src_coff[s] + d->groups * d->src_cpg[s] <= d->src_ld[s], E2FGVI_EINVAL,
+                   "conv3x3_winograd: source %d channel range exceeds its pixel stride", s);
+        const long long bytes = (long long)d->N * d->H * d->W * d->src_ld[s] * 4;
+        E2_REQUIRE(bytes < 4294967295LL, E2FGVI_EUNSUP, "conv3x3_winograd: source %d spans >= 4 GiB (split the batch)", s);
+        p.src[s] = d->src[s]; p.ld[s] = d->src_ld[s]; p.coff[s] = d->src_coff[s]; p.cpg[s] = d->src_cpg[s];
+        p.src_bytes[s] = (unsigned)bytes;
+    }
+    E2_REQUIRE(q.wgroup_elems * 4 < 0x70000000LL, E2FGVI_EUNSUP, "conv3x3_winograd: packed weight group >= 1.75 GiB");
+    E2_REQUIRE(((uintptr_t)d->wpacked & 15) == 0, E2FGVI_EINVAL, "conv3x3_winograd: packed weight not 16-byte aligned");
+    p.nsrc = d->nsrc;
+    p.N = d->N; p.H = d->H; p.W = d->W;
+    p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
+    p.blocksY = cdiv(d->H, 16); p.blocksX = cdiv(d->W, 16);
+    p.nchunks = q.nchunks;
+    p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * 4);
+    p.w = (const float*)d->wpacked; p.bias = d->bias;
+    p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff;
+    p.act = d->act; p.slope = d->slope;
+    p.vec_store = (((uintptr_t)d->dst & 15) == 0 && d->dst_ld % 4 == 0 && d->dst_coff % 4 == 0 && q.Cout_g % 4 == 0) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long long mblocks = (long long)p.N * p.blocksY * p.blocksX;
+    int tile = d->tile;
+    if (!tile) {
+        // 256 CUs hold one workgroup each: pick the cout tile whose last round of workgroups is best filled.  A 32-wide
+        // workgroup costs ~0.56 of a 64-wide one (the input transform is amortised over half the columns).
+        auto cost = [&](int bn, double unit) {
+            const long long wgs = mblocks * cdiv(q.Cout_g, bn) * d->groups;
+            return (double)((wgs + 255) / 256) * unit;
+        };
+        tile = cost(64, 1.0) <= cost(32, 0.56) ? 64 : 32;
+    }
+    if (tile == 64) {
+        p.tilesN = cdiv(q.Cout_g, 64);
+        E2_REQUIRE(mblocks * p.tilesN < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
+        p.nblk = (int)(mblocks * p.tilesN);
+        hipLaunchKernelGGL((conv_wino_kernel<64>), dim3(p.nblk, d->groups, 1), dim3(512), 0, st, p);
+    } else if (tile == 32) {
+        p.tilesN = cdiv(q.Cout_g, 32);
+        E2_REQUIRE(mblocks * p.tilesN < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
+        p.nblk = (int)(mblocks * p.tilesN);
+        hipLaunchKernelGGL((conv_wino_kernel<32>), dim3(p.nblk, d->groups, 1), dim3(512), 0, st, p);
+    } else {
+        e2fgvi_set_error("conv3x3_winograd: tile must be 0, 32 or 64");
+        return E2FGVI_EINVAL;
+    }
+    E2_LAUNCH_CHECK("conv3x3_winograd");
+    return 0;
+}

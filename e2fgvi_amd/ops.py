@@ -44,9 +44,11 @@ class PackedConv:
     cpg:    channels per group contributed by each source of the virtual input concat.
     """
 
-    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32"):
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32", algo="igemm"):
         """precision: "fp32" (default: fp32 MFMA, bit-equivalent to an fp32 FMA chain) or "bf16" (optional mode for
-        the HQ configurations: bf16 MFMA, fp32 accumulate, fp32 tensors in HBM)."""
+        the HQ configurations: bf16 MFMA, fp32 accumulate, fp32 tensors in HBM).
+        algo: "igemm" (implicit GEMM) or "winograd" (fp32 F(2x2,3x3); 3x3 / stride 1 / pad 1, every cpg % 8 == 0,
+        even H and W at call time, no residual)."""
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -59,6 +61,22 @@ class PackedConv:
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
+        if algo not in ("igemm", "winograd"):
+            raise ValueError("algo must be 'igemm' or 'winograd'")
+        self.algo = algo
+        if algo == "winograd":
+            if precision != "fp32" or (self.KH, self.KW, stride, pad) != (3, 3, 1, 1) or any(c % 8 for c in self.cpg):
+                raise ValueError("winograd needs fp32, 3x3 / stride 1 / pad 1 and channels per source in multiples of 8")
+            self.bk = 8
+            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+            n = lib.e2fgvi_packed_winograd_weight_size(self.Cout, groups, len(self.cpg), arr)
+            if n < 0:
+                _L.check(int(n), "packed_winograd_weight_size")
+            self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
+            _L.check(lib.e2fgvi_pack_winograd_weight(_ptr(w), _ptr(self.wpacked), self.Cout, groups, len(self.cpg), arr,
+                                                     _stream()), "pack_winograd_weight")
+            self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+            return
         if precision == "bf16":
             self.bk = 32
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
@@ -147,7 +165,9 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
-        if self.precision == "bf16":
+        if self.algo == "winograd":
+            _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
+        elif self.precision == "bf16":
             _L.check(lib.e2fgvi_conv2d_nhwc_bf16(C.byref(d), _stream()), "conv2d_nhwc_bf16")
         else:
             _L.check(lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")

@@ -451,3 +451,62 @@ def test_conv_bf16_mode(dev, case):
                 tile=tile)
     assert_close(nchw(out.cpu()), refbf, 3e-5, "bf16 conv vs bf16-rounded fp32 reference")
     assert_close(nchw(out.cpu()), ref32, 3e-2, "bf16 conv vs fp32")
+
+
+WINO_CASES = [
+    # N, H, W, cpg, groups, Cout, act, tile, dst_ld, dst_coff
+    (1, 16, 16, [8], 1, 32, 0, 0, None, 0),              # one block, one chunk
+    (2, 30, 54, [64], 1, 64, 2, 0, None, 0),             # partial blocks in both directions
+    (2, 60, 108, [256], 1, 384, 2, 0, None, 0),          # encoder.layers.8 shape (2 frames)
+    (2, 30, 54, [128, 192], 2, 512, 2, 0, None, 0),      # encoder.layers.10: grouped virtual concat
+    (2, 30, 54, [64, 128], 4, 384, 2, 0, None, 0),       # layers.12: Cout_g = 96 -> 32-wide tiles
+    (2, 30, 54, [32, 48], 8, 256, 2, 0, None, 0),        # layers.14: Cout_g = 32, cpg 48 (6 chunks)
+    (3, 22, 38, [256, 256], 1, 128, 2, 32, None, 0),     # layers.16 with forced 32-wide tiles
+    (1, 34, 50, [128], 1, 128, 1, 64, 160, 16),          # write into a channel slice of a wider tensor
+    (1, 18, 66, [40], 1, 24, 3, 0, None, 0),             # Cout not a multiple of 32, tanh
+    (5, 2, 2, [16], 1, 8, 0, 0, None, 0),                # image smaller than a block
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c[:8]))
+def test_conv3x3_winograd(dev, case):
+    """Winograd F(2x2,3x3) fp32 conv vs torch fp32 conv2d: same operator contract as conv2d_nhwc (virtual concat,
+    groups, bias, activation, strided destination); tolerance 2e-5 x rms (fp32 Winograd rounding, ~4x plain fp32)"""
+    from e2fgvi_amd import ops
+    N, H, W, cpg, groups, Cout, act, tile, dst_ld, dst_coff = case
+    g = _gen(41)
+    srcs = [torch.randn(N, groups * c, H, W, generator=g) for c in cpg]
+    cin_g = sum(cpg)
+    w = torch.randn(Cout, cin_g, 3, 3, generator=g) / math.sqrt(cin_g * 9)
+    b = torch.randn(Cout, generator=g)
+    xcat = torch.cat([s.view(N, groups, c, H, W) for s, c in zip(srcs, cpg)], 2).view(N, groups * cin_g, H, W)
+    ref = _act_ref(F.conv2d(xcat, w, b, stride=1, padding=1, groups=groups), act, 0.2)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=1, pad=1, algo="winograd")
+    if dst_ld is None:
+        out = layer([nhwc(s).to(dev) for s in srcs], act=act, slope=0.2, tile=tile)
+    else:
+        full = torch.full((N, H, W, dst_ld), 7.0, device=dev)
+        layer([nhwc(s).to(dev) for s in srcs], out=full, out_coff=dst_coff, act=act, slope=0.2, tile=tile)
+        out = full[..., dst_coff:dst_coff + Cout]
+        rest = torch.cat([full[..., :dst_coff], full[..., dst_coff + Cout:]], 3)
+        assert (rest == 7.0).all(), "winograd conv wrote outside its channel slice"
+    assert_close(nchw(out.cpu()), ref, 2e-5, "winograd conv")
+    # and against the implicit-GEMM path of the library (both are fp32)
+    direct = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=1, pad=1)([nhwc(s).to(dev) for s in srcs],
+                                                                                       act=act, slope=0.2)
+    assert_close(out.cpu(), direct.cpu(), 2e-5, "winograd vs implicit GEMM")
+
+
+def test_conv3x3_winograd_argument_errors(dev):
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.lib import HipError
+    w = torch.randn(32, 16, 3, 3, device=dev)
+    with pytest.raises(ValueError):
+        ops.PackedConv(torch.randn(32, 12, 3, 3, device=dev), None, [12], pad=1, algo="winograd")     # cpg % 8
+    with pytest.raises(ValueError):
+        ops.PackedConv(w, None, [16], stride=2, pad=1, algo="winograd")
+    layer = ops.PackedConv(w, None, [16], pad=1, algo="winograd")
+    with pytest.raises(HipError):
+        layer([torch.randn(1, 15, 16, 16, device=dev)])                                               # odd H
+    with pytest.raises(HipError):
+        layer([torch.randn(1, 16, 16, 16, device=dev)], residual=torch.randn(1, 16, 16, 32, device=dev))
