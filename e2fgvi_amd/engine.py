@@ -69,7 +69,7 @@ def build_key_table(fh, fw, valid_ind_rolled):
 
 
 class Engine:
-    def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32"):
+    def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32", winograd=True):
         """precision="fp32": every contraction on fp32 MFMA (the default and the parity configuration).
         precision="bf16": the wide conv / linear layers run on bf16 MFMA with fp32 accumulation (BASELINE.json HQ
         configurations); SPyNet, the first / last conv, conv_offset's last layer, the deformable conv and the attention
@@ -83,6 +83,8 @@ class Engine:
         self.sd = sd
         f = lambda k: sd[k].float().contiguous()
         pw = dict(precision=precision)          # layers that follow the precision mode
+        # wide 3x3 / stride-1 layers: fp32 Winograd F(2x2,3x3) whenever the call qualifies (even H, W), else implicit GEMM
+        ww = dict(precision=precision, algo="auto" if (winograd and precision == "fp32") else "igemm")
 
         # ---- encoder (e2fgvi.py:75-94)
         w0 = torch.zeros(64, 4, 3, 3, device=self.device)
@@ -92,13 +94,13 @@ class Engine:
                                   (([64], 1, 1), ([64], 1, 2), ([128], 1, 1), ([256], 1, 1), ([128, 192], 2, 1),
                                    ([64, 128], 4, 1), ([32, 48], 8, 1), ([256, 256], 1, 1))):
             enc.append(PackedConv(f("encoder.layers.%d.weight" % i), f("encoder.layers.%d.bias" % i), cpg, groups=g,
-                                  stride=s, pad=1, **pw))
+                                  stride=s, pad=1, **(ww if s == 1 else pw)))
         self.enc = enc
 
         # ---- decoder (e2fgvi.py:143-150)
-        self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1, **pw),
-                    PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1, **pw),
-                    PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1, **pw),
+        self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1, **ww),
+                    PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1, **ww),
+                    PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1, **ww),
                     PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)
@@ -125,7 +127,7 @@ class Engine:
         bsc = f("sc.embedding.bias").view(128, 49).t().reshape(6272).contiguous()
         self.sc = PackedLinear(wsc, bsc, **pw)
         if self.hq:
-            self.sc_bias_conv = PackedConv(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1, **pw)
+            self.sc_bias_conv = PackedConv(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1, **ww)
             self.sc_bias_hwc = None
         else:
             self.sc_bias_hwc = f("sc.bias").permute(1, 2, 0).contiguous()

@@ -47,8 +47,8 @@ class PackedConv:
     def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32", algo="igemm"):
         """precision: "fp32" (default: fp32 MFMA, bit-equivalent to an fp32 FMA chain) or "bf16" (optional mode for
         the HQ configurations: bf16 MFMA, fp32 accumulate, fp32 tensors in HBM).
-        algo: "igemm" (implicit GEMM) or "winograd" (fp32 F(2x2,3x3); 3x3 / stride 1 / pad 1, every cpg % 8 == 0,
-        even H and W at call time, no residual)."""
+        algo: "igemm" (implicit GEMM), "winograd" (fp32 F(2x2,3x3) only; 3x3 / stride 1 / pad 1, every cpg % 8 == 0,
+        even H and W at call time, no residual) or "auto" (both packings; Winograd whenever a call qualifies)."""
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -61,22 +61,28 @@ class PackedConv:
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
-        if algo not in ("igemm", "winograd"):
-            raise ValueError("algo must be 'igemm' or 'winograd'")
+        if algo not in ("igemm", "winograd", "auto"):
+            raise ValueError("algo must be 'igemm', 'winograd' or 'auto'")
+        wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 8 for c in self.cpg)
+        if algo == "winograd" and not wino_ok:
+            raise ValueError("winograd needs fp32, 3x3 / stride 1 / pad 1 and channels per source in multiples of 8")
+        if algo == "auto":
+            algo = "auto" if wino_ok else "igemm"
         self.algo = algo
-        if algo == "winograd":
-            if precision != "fp32" or (self.KH, self.KW, stride, pad) != (3, 3, 1, 1) or any(c % 8 for c in self.cpg):
-                raise ValueError("winograd needs fp32, 3x3 / stride 1 / pad 1 and channels per source in multiples of 8")
-            self.bk = 8
+        self.wino_packed = None
+        if algo in ("winograd", "auto"):
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
             n = lib.e2fgvi_packed_winograd_weight_size(self.Cout, groups, len(self.cpg), arr)
             if n < 0:
                 _L.check(int(n), "packed_winograd_weight_size")
-            self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
-            _L.check(lib.e2fgvi_pack_winograd_weight(_ptr(w), _ptr(self.wpacked), self.Cout, groups, len(self.cpg), arr,
+            self.wino_packed = torch.empty(int(n), dtype=torch.float32, device=w.device)
+            _L.check(lib.e2fgvi_pack_winograd_weight(_ptr(w), _ptr(self.wino_packed), self.Cout, groups, len(self.cpg), arr,
                                                      _stream()), "pack_winograd_weight")
-            self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
-            return
+            if algo == "winograd":
+                self.bk = 8
+                self.wpacked = None
+                self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+                return
         if precision == "bf16":
             self.bk = 32
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
@@ -143,7 +149,9 @@ class PackedConv:
         d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
-        d.wpacked = self.wpacked.data_ptr()
+        use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and residual is None
+                                               and not out_nchw and act != ACT_DCNPOST and tile in (0, 32, 64))
+        d.wpacked = (self.wino_packed if use_wino else self.wpacked).data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         dev = srcs[0][0].device
         if out is None:
@@ -165,7 +173,7 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
-        if self.algo == "winograd":
+        if use_wino:
             _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
         elif self.precision == "bf16":
             _L.check(lib.e2fgvi_conv2d_nhwc_bf16(C.byref(d), _stream()), "conv2d_nhwc_bf16")
