@@ -5,7 +5,8 @@
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 4x4 input patch d, 3x3 filter g  (Lavin & Gray, F(2x2,3x3))
 //   as 16 independent GEMMs  M_a[tile, cout] = sum_cin V_a[tile, cin] * U_a[cin, cout],  a = (xi, nu) in 4x4
 //
-// Workgroup = 8 waves = one 16x16-pixel output block (8x8 Winograd tiles = 2 MFMA row-tiles) x BN output channels.
+// Workgroup = 8 waves = one 16x16-pixel output block (8x8 Winograd tiles = 2 MFMA row-tiles; 8x16 pixels / 1 row-tile
+// in the small-image variant that the 60x108 propagation convs use) x BN output channels.
 // Wave w owns the two transform positions a = 2w, 2w+1 (same xi = w>>1, nu in {0,1} or {2,3}) and keeps
 // 2 x 2 x (BN/32) 32x32 accumulators.  Per 8-channel chunk of the input:
 //   * the raw 18x18-pixel halo patch is staged ONCE in LDS (global -> registers -> LDS one stage ahead; a stage = two
@@ -16,11 +17,12 @@
 //     exists in memory;
 //   * B operands (the pre-transformed weights of the wave's own two positions) never touch LDS: one 16-byte buffer load
 //     per (position, column tile), issued one chunk ahead, is exactly the lane's operand quad; 8 MFMAs per tile pair.
-// Epilogue: the 16 M_a tiles meet in LDS, every thread applies A^T M A to one (tile, 4 couts) item, adds the bias,
-// applies the activation and stores 2x2 pixels x 16 bytes (128-byte runs along cout).
+// Epilogue: the 16 M_a tiles meet in LDS, every thread applies A^T M A to one (tile, 4 couts) item, adds the bias and
+// the residual, applies the activation (or the DCN offset/mask post-processing) and stores 2x2 pixels x 16 bytes.
 //
 // Packed weights: [group][chunk][a = 16][kq = 2][Npad][4]  (chunk = 8 input channels in concat order, sources padded
-// to 8; kq = channel quad; Npad = Cout_g rounded up to 32), produced by e2fgvi_pack_winograd_weight.
+// to 8 -- a source may be 4 (mod 8) wide, its last half chunk is zero; kq = channel quad; Npad = Cout_g rounded up to
+// 32), produced by e2fgvi_pack_winograd_weight.
 #include "common.h"
 
 namespace {
@@ -40,12 +42,23 @@ struct WinoParams {
     long long wgroup_elems;
     const float* w;
     const float* bias;
+    const float* res;       // residual [pixel][res_ld] (+ res_coff), or the per-pixel flows [pixel][4] of ACT_DCNPOST
+    int res_ld, res_coff;
     float* dst;
     int dst_ld, dst_coff;
     int act;
     float slope;
-    int vec_store;          // destination rows are 16-byte addressable for every group / cout tile
+    int vec_store;          // destination (and residual) rows are 16-byte addressable for every group / cout tile
 };
+
+// offset / mask post-processing of SecondOrderDeformableAlignment fused into conv_offset's last layer -- same rule as
+// conv.hip::dcn_post (feat_prop.py:38-53)
+__device__ __forceinline__ float wino_dcn_post(float v, int co, int C, const float* fl, float max_residue) {
+    const int noff = (C / 3) * 2;
+    if (co >= noff) return 1.f / (1.f + expf(-v));
+    const int which = (co * 2 >= noff) ? 2 : 0;
+    return max_residue * tanhf(v) + fl[which + ((co & 1) ? 0 : 1)];
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -54,22 +67,25 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned by
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
 
-constexpr int RAW_W = 18;                 // raw patch is 18 x 18 pixels
+constexpr int RAW_W = 18;                 // raw patch is (8 MT + 2) x 18 pixels
 constexpr int PLANE_ROW = 12;             // 16-byte units per patch row in one column-parity plane (9 used)
-constexpr int PLANE_BYTES = RAW_W * PLANE_ROW * 16;       // 3456
-constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;               // planes of one 8-channel chunk: [kq][column parity]
-constexpr int STAGE_BYTES = 2 * CHUNK_BYTES;               // an LDS stage holds two chunks (one barrier per 16 channels)
 constexpr unsigned OOB = 0xFFFFFFFFu;
 template <int V> struct IC { static constexpr int value = V; };
 
-template <int BN>
+// MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
+template <int MT, int BN>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
     constexpr int NT = 512;
     constexpr int TN = BN / 32;
-    constexpr int EPI_BYTES = 16 * 64 * 32 * 4;
+    constexpr int RAW_H = 8 * MT + 2;
+    constexpr int PLANE_BYTES = RAW_H * PLANE_ROW * 16;
+    constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;              // planes of one 8-channel chunk: [kq][column parity]
+    constexpr int STAGE_BYTES = 2 * CHUNK_BYTES;              // an LDS stage holds two chunks (one barrier per 16 channels)
+    constexpr int TILES = 32 * MT;
+    constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
     constexpr int SMEM = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
-    constexpr int RAW_ITEMS = RAW_W * RAW_W * 2;          // (pixel, kq) of one chunk
-    constexpr int RAW_IT = (RAW_ITEMS + NT - 1) / NT;     // 2
+    constexpr int RAW_ITEMS = RAW_H * RAW_W * 2;          // (pixel, kq) of one chunk
+    constexpr int RAW_IT = (RAW_ITEMS + NT - 1) / NT;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
     rem -= img * (p.blocksY * p.blocksX);
     const int by = rem / p.blocksX, bx = rem - by * p.blocksX;
     const int n0 = tile_n * BN;
-    const int y0 = by * 16 - 1, x0 = bx * 16 - 1;          // top-left of the raw patch
+    const int y0 = by * (8 * MT) - 1, x0 = bx * 16 - 1;    // top-left of the raw patch
 
     // ---- raw-patch staging bookkeeping (chunk invariant)
     unsigned raw_off[RAW_IT];      // pixel index in its source, OOB if outside the image / no item
@@ -111,9 +127,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
         const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
         const unsigned ld4 = (unsigned)p.ld[s] * 4u;
         const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u + raw_kq16;
+        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < p.cpg[s];   // a source may end in the middle of a chunk (cpg % 8 == 4)
 #pragma unroll
         for (int it = 0; it < RAW_IT; ++it)
-            q[it] = buf_load4(arsrc, raw_off[it] != OOB ? raw_off[it] * ld4 + chan : OOB);
+            q[it] = buf_load4(arsrc, (cvalid && raw_off[it] != OOB) ? raw_off[it] * ld4 + chan : OOB);
         c0 += 8;
         if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
     };
@@ -167,11 +184,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
             for (int n = 0; n < TN; ++n) q[a][n] = buf_load4(wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
     };
 
-    f32x16 acc[2][2][TN];
+    f32x16 acc[2][MT][TN];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < TN; ++n)
 #pragma unroll
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
                 load_b(2 * st + q + 1, bq[q ^ 1]);                   // next chunk's weights land during this chunk
                 const unsigned char* raw = stage + q * CHUNK_BYTES;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     const unsigned char* rm = raw + m * (8 * PLANE_ROW * 16);
                     f32x4 e[3];
 #pragma unroll
@@ -235,7 +252,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
         default: k_loop(IC<3>{}, IC<1>{}); break;
     }
 
-    // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, activation, store
+    // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
     float* E = reinterpret_cast<float*>(smem);
     const int HW = p.H * p.W;
 #pragma unroll
@@ -244,53 +261,69 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    E[((2 * wave + a) * 64 + tile) * 32 + i] = acc[a][m][nh][r];
+                    E[((2 * wave + a) * TILES + tile) * 32 + i] = acc[a][m][nh][r];
                 }
         __syncthreads();
         // one (tile, 4 consecutive couts) item per thread: 16 ds_read_b128, A^T M A, 4 stores of 16 bytes
         const int cq = tid & 7, tile = tid >> 3;
         const int n = n0 + nh * 32 + cq * 4;
-        f32x4 mm[16];
+        const int oy = by * (8 * MT) + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7);
+        // H and W are even: a tile is inside or outside the image as a whole
+        if (tile < TILES && n < p.Cout_g && oy < p.H && ox < p.W) {
+            f32x4 mm[16];
 #pragma unroll
-        for (int a = 0; a < 16; ++a) mm[a] = *reinterpret_cast<const f32x4*>(E + (a * 64 + tile) * 32 + cq * 4);
-        // A^T = [1 1 1 0; 0 1 -1 -1]
-        f32x4 t0[4], t1[4];
+            for (int a = 0; a < 16; ++a) mm[a] = *reinterpret_cast<const f32x4*>(E + (a * TILES + tile) * 32 + cq * 4);
+            // A^T = [1 1 1 0; 0 1 -1 -1]
+            f32x4 t0[4], t1[4];
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            t0[nu] = mm[0 * 4 + nu] + mm[1 * 4 + nu] + mm[2 * 4 + nu];
-            t1[nu] = mm[1 * 4 + nu] - mm[2 * 4 + nu] - mm[3 * 4 + nu];
-        }
-        f32x4 y[4];
-        y[0] = t0[0] + t0[1] + t0[2];
-        y[1] = t0[1] - t0[2] - t0[3];
-        y[2] = t1[0] + t1[1] + t1[2];
-        y[3] = t1[1] - t1[2] - t1[3];
-        const int oy = by * 16 + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7);
-        if (n < p.Cout_g && oy < p.H && ox < p.W) {       // H and W are even: a tile is inside or outside as a whole
+            for (int nu = 0; nu < 4; ++nu) {
+                t0[nu] = mm[0 * 4 + nu] + mm[1 * 4 + nu] + mm[2 * 4 + nu];
+                t1[nu] = mm[1 * 4 + nu] - mm[2 * 4 + nu] - mm[3 * 4 + nu];
+            }
+            f32x4 y[4];
+            y[0] = t0[0] + t0[1] + t0[2];
+            y[1] = t0[1] - t0[2] - t0[3];
+            y[2] = t1[0] + t1[1] + t1[2];
+            y[3] = t1[1] - t1[2] - t1[3];
             const int co = g * p.Cout_g + n;
-            float* o = p.dst + ((long long)img * HW + (long long)oy * p.W + ox) * p.dst_ld + p.dst_coff + co;
-            const long long poff[4] = {0, p.dst_ld, (long long)p.W * p.dst_ld, (long long)(p.W + 1) * p.dst_ld};
-            if (p.vec_store && n + 3 < p.Cout_g) {
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) { bv[0] = p.bias[co]; bv[1] = p.bias[co + 1]; bv[2] = p.bias[co + 2]; bv[3] = p.bias[co + 3]; }
+            const long long pix0 = (long long)img * HW + (long long)oy * p.W + ox;
+            const int pstep[4] = {0, 1, p.W, p.W + 1};
+            const bool full = n + 3 < p.Cout_g;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
 #pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    f32x4 v = y[px] + bv;
+                for (int c = 0; c < 4; ++c) bv[c] = (full || n + c < p.Cout_g) ? p.bias[co + c] : 0.f;
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const long long pix = pix0 + pstep[px];
+                f32x4 v = y[px] + bv;
+                if (p.act == E2FGVI_ACT_DCNPOST) {
+                    const f32x4 fl = *reinterpret_cast<const f32x4*>(p.res + pix * 4);
+                    const float flv[4] = {fl[0], fl[1], fl[2], fl[3]};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = wino_dcn_post(v[c], co + c, p.Cout, flv, p.slope);
+                } else {
+                    if (p.res) {
+                        const float* r = p.res + pix * p.res_ld + p.res_coff + co;
+                        if (p.vec_store && full) v = v + *reinterpret_cast<const f32x4*>(r);
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (full || n + c < p.Cout_g) v[c] += r[c];
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
-                    *reinterpret_cast<f32x4*>(o + poff[px]) = v;
                 }
-            } else {
+                float* o = p.dst + pix * p.dst_ld + p.dst_coff + co;
+                if (p.vec_store && full) *reinterpret_cast<f32x4*>(o) = v;
+                else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (n + c >= p.Cout_g) break;
-                    const float bv = p.bias ? p.bias[co + c] : 0.f;
-#pragma unroll
-                    for (int px = 0; px < 4; ++px) o[poff[px] + c] = apply_act(y[px][c] + bv, p.act, p.slope);
+                    for (int c = 0; c < 4; ++c) if (full || n + c < p.Cout_g) o[c] = v[c];
                 }
             }
         }
@@ -312,10 +345,10 @@ bool wino_geometry(int Cout, int groups, int nsrc, const int32_t* cpg, WinoPack*
     q->Cin_g = 0; q->nchunks = 0;
     for (int s = 0; s < E2FGVI_MAX_SRC; ++s) q->cpg[s] = 0;
     for (int s = 0; s < nsrc; ++s) {
-        if (cpg[s] <= 0 || cpg[s] % 8) return false;
+        if (cpg[s] <= 0 || cpg[s] % 4) return false;
         q->cpg[s] = cpg[s];
         q->Cin_g += cpg[s];
-        q->nchunks += cpg[s] / 8;
+        q->nchunks += (cpg[s] + 7) / 8;          // a source ends its last chunk half empty when cpg % 8 == 4
     }
     q->wgroup_elems = (long long)q->nchunks * 16 * 2 * q->Npad * 4;
     q->total = q->wgroup_elems * groups;
@@ -336,10 +369,11 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
     const int a = (int)(rem & 15);
     const int chunk = (int)(rem >> 4);
     // chunk -> (source, channel inside the group's slice of that source)
-    int s = 0, prefix = 0, ch = chunk * 8 + kq * 4 + kk;
-    while (ch >= p.cpg[s]) { ch -= p.cpg[s]; prefix += p.cpg[s]; ++s; }
+    int s = 0, prefix = 0, lc = chunk;                     // chunk -> (source, chunk inside the source)
+    while (lc >= (p.cpg[s] + 7) / 8) { lc -= (p.cpg[s] + 7) / 8; prefix += p.cpg[s]; ++s; }
+    const int ch = lc * 8 + kq * 4 + kk;
     float v = 0.f;
-    if (n < p.Cout_g) {
+    if (n < p.Cout_g && ch < p.cpg[s]) {
         const float* f = w + ((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + ch) * 9;
         // G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  U = G f G^T
         const int xi = a >> 2, nu = a & 3;
@@ -376,20 +410,35 @@ extern "C" int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32
     return 0;
 }
 
+template <int MT, int BN>
+static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
+    p.blocksY = cdiv(p.H, 8 * MT);
+    p.blocksX = cdiv(p.W, 16);
+    p.tilesN = cdiv(p.Cout_g, BN);
+    const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
+    E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
+    p.nblk = (int)nblk;
+    hipLaunchKernelGGL((conv_wino_kernel<MT, BN>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    E2_LAUNCH_CHECK("conv3x3_winograd");
+    return 0;
+}
+
 extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv3x3_winograd: null descriptor");
     WinoPack q;
     E2_REQUIRE(wino_geometry(d->Cout, d->groups, d->nsrc, d->src_cpg, &q), E2FGVI_EINVAL,
-               "conv3x3_winograd: bad geometry (channels per source must be multiples of 8)");
+               "conv3x3_winograd: bad geometry (channels per source must be multiples of 4)");
     E2_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, E2FGVI_EUNSUP,
                "conv3x3_winograd: only 3x3, stride 1, pad 1");
     E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0, E2FGVI_EUNSUP,
                "conv3x3_winograd: H and W must be even");
     E2_REQUIRE(d->Ho == d->H && d->Wo == d->W, E2FGVI_EINVAL, "conv3x3_winograd: Ho/Wo must equal H/W");
     E2_REQUIRE(d->wpacked && d->dst, E2FGVI_EINVAL, "conv3x3_winograd: null weight/dst");
-    E2_REQUIRE(!d->residual && !d->dst_nchw, E2FGVI_EUNSUP, "conv3x3_winograd: residual / NCHW output not supported");
-    E2_REQUIRE(d->act != E2FGVI_ACT_DCNPOST, E2FGVI_EUNSUP, "conv3x3_winograd: ACT_DCNPOST not supported");
+    E2_REQUIRE(!d->dst_nchw, E2FGVI_EUNSUP, "conv3x3_winograd: NCHW output not supported");
     E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv3x3_winograd: dst slice exceeds dst_ld");
+    if (d->act == E2FGVI_ACT_DCNPOST)
+        E2_REQUIRE(d->residual && d->Cout % 3 == 0 && d->groups == 1 && ((uintptr_t)d->residual & 15) == 0, E2FGVI_EINVAL,
+                   "conv3x3_winograd: ACT_DCNPOST needs the [pixel][4] flows as residual, Cout %% 3 == 0, groups == 1");
     WinoParams p;
     for (int s = 0; s < E2FGVI_MAX_SRC; ++s) { p.src[s] = nullptr; p.ld[s] = 0; p.coff[s] = 0; p.cpg[s] = 0; p.src_bytes[s] = 0; }
     for (int s = 0; s < d->nsrc; ++s) {
@@ -408,39 +457,38 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
     p.nsrc = d->nsrc;
     p.N = d->N; p.H = d->H; p.W = d->W;
     p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
-    p.blocksY = cdiv(d->H, 16); p.blocksX = cdiv(d->W, 16);
     p.nchunks = q.nchunks;
     p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * 4);
     p.w = (const float*)d->wpacked; p.bias = d->bias;
+    p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff;
     p.act = d->act; p.slope = d->slope;
-    p.vec_store = (((uintptr_t)d->dst & 15) == 0 && d->dst_ld % 4 == 0 && d->dst_coff % 4 == 0 && q.Cout_g % 4 == 0) ? 1 : 0;
+    bool vec = ((uintptr_t)d->dst & 15) == 0 && d->dst_ld % 4 == 0 && d->dst_coff % 4 == 0 && q.Cout_g % 4 == 0;
+    if (d->residual && d->act != E2FGVI_ACT_DCNPOST)
+        vec = vec && ((uintptr_t)d->residual & 15) == 0 && d->res_ld % 4 == 0 && d->res_coff % 4 == 0;
+    p.vec_store = vec ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    const long long mblocks = (long long)p.N * p.blocksY * p.blocksX;
     int tile = d->tile;
     if (!tile) {
-        // 256 CUs hold one workgroup each: pick the cout tile whose last round of workgroups is best filled.  A 32-wide
-        // workgroup costs ~0.56 of a 64-wide one (the input transform is amortised over half the columns).
-        auto cost = [&](int bn, double unit) {
-            const long long wgs = mblocks * cdiv(q.Cout_g, bn) * d->groups;
-            return (double)((wgs + 255) / 256) * unit;
-        };
-        tile = cost(64, 1.0) <= cost(32, 0.56) ? 64 : 32;
+        // 256 CUs hold one workgroup each (two of the smallest shape): pick the shape whose rounds of workgroups cost
+        // least.  Relative cost of a workgroup: 16x16 px x 64 couts = 1; halving the couts or the rows saves less than
+        // half (the patch transform, prologue and epilogue do not shrink with the tile).
+        const int MTs[4] = {2, 2, 1, 1}, BNs[4] = {64, 32, 64, 32};
+        const double unit[4] = {1.0, 0.56, 0.56, 0.33};
+        double best = 1e30;
+        for (int c = 0; c < 4; ++c) {
+            const long long wgs = (long long)d->N * cdiv(d->H, 8 * MTs[c]) * cdiv(d->W, 16) * cdiv(q.Cout_g, BNs[c]) * d->groups;
+            const double t = (double)((wgs + 255) / 256) * unit[c];
+            if (t < best - 1e-9) { best = t; tile = BNs[c] + (MTs[c] == 1 ? 100 : 0); }
+        }
     }
-    if (tile == 64) {
-        p.tilesN = cdiv(q.Cout_g, 64);
-        E2_REQUIRE(mblocks * p.tilesN < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
-        p.nblk = (int)(mblocks * p.tilesN);
-        hipLaunchKernelGGL((conv_wino_kernel<64>), dim3(p.nblk, d->groups, 1), dim3(512), 0, st, p);
-    } else if (tile == 32) {
-        p.tilesN = cdiv(q.Cout_g, 32);
-        E2_REQUIRE(mblocks * p.tilesN < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
-        p.nblk = (int)(mblocks * p.tilesN);
-        hipLaunchKernelGGL((conv_wino_kernel<32>), dim3(p.nblk, d->groups, 1), dim3(512), 0, st, p);
-    } else {
-        e2fgvi_set_error("conv3x3_winograd: tile must be 0, 32 or 64");
-        return E2FGVI_EINVAL;
+    switch (tile) {
+        case 64: return launch_wino<2, 64>(p, d->groups, st);
+        case 32: return launch_wino<2, 32>(p, d->groups, st);
+        case 164: return launch_wino<1, 64>(p, d->groups, st);
+        case 132: return launch_wino<1, 32>(p, d->groups, st);
+        default: break;
     }
-    E2_LAUNCH_CHECK("conv3x3_winograd");
-    return 0;
+    e2fgvi_set_error("conv3x3_winograd: tile must be 0 (auto), 32, 64 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");
+    return E2FGVI_EINVAL;
 }

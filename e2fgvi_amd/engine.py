@@ -108,14 +108,15 @@ class Engine:
         for d, nparts in (("backward_", 2), ("forward_", 3)):
             p = "feat_prop_module.deform_align.%s." % d
             # conv_offset.0 input = cat(cond_n1, cur, cond_n2, flow_1, flow_2): sources (cond|0), cur, (cond|128), flows4
-            off = [PackedConv(f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias"), [128, 128, 128, 4], pad=1, **pw),
-                   PackedConv(f(p + "conv_offset.2.weight"), f(p + "conv_offset.2.bias"), [128], pad=1, **pw),
-                   PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1, **pw),
-                   PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1)]
+            off = [PackedConv(f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias"), [128, 128, 128, 4], pad=1, **ww),
+                   PackedConv(f(p + "conv_offset.2.weight"), f(p + "conv_offset.2.bias"), [128], pad=1, **ww),
+                   PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1, **ww),
+                   PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1,
+                              algo=ww["algo"])]
             dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1)
             b = "feat_prop_module.backbone.%s." % d
-            bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **pw),
-                  PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **pw)]
+            bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **ww),
+                  PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **ww)]
             self.prop[d] = (off, dcn, bb)
         self.fusion = PackedConv(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128], **pw)
 

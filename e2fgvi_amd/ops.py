@@ -47,8 +47,8 @@ class PackedConv:
     def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32", algo="igemm"):
         """precision: "fp32" (default: fp32 MFMA, bit-equivalent to an fp32 FMA chain) or "bf16" (optional mode for
         the HQ configurations: bf16 MFMA, fp32 accumulate, fp32 tensors in HBM).
-        algo: "igemm" (implicit GEMM), "winograd" (fp32 F(2x2,3x3) only; 3x3 / stride 1 / pad 1, every cpg % 8 == 0,
-        even H and W at call time, no residual) or "auto" (both packings; Winograd whenever a call qualifies)."""
+        algo: "igemm" (implicit GEMM), "winograd" (fp32 F(2x2,3x3) only; 3x3 / stride 1 / pad 1, every cpg % 4 == 0,
+        even H and W at call time, NHWC output) or "auto" (both packings; Winograd whenever a call qualifies)."""
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -63,9 +63,9 @@ class PackedConv:
         self.precision = precision
         if algo not in ("igemm", "winograd", "auto"):
             raise ValueError("algo must be 'igemm', 'winograd' or 'auto'")
-        wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 8 for c in self.cpg)
+        wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 4 for c in self.cpg)
         if algo == "winograd" and not wino_ok:
-            raise ValueError("winograd needs fp32, 3x3 / stride 1 / pad 1 and channels per source in multiples of 8")
+            raise ValueError("winograd needs fp32, 3x3 / stride 1 / pad 1 and channels per source in multiples of 4")
         if algo == "auto":
             algo = "auto" if wino_ok else "igemm"
         self.algo = algo
@@ -149,8 +149,8 @@ class PackedConv:
         d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
-        use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and residual is None
-                                               and not out_nchw and act != ACT_DCNPOST and tile in (0, 32, 64))
+        use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and not out_nchw
+                                               and tile in (0, 32, 64, 132, 164))
         d.wpacked = (self.wino_packed if use_wino else self.wpacked).data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         dev = srcs[0][0].device

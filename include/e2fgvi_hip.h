@@ -98,9 +98,10 @@ int e2fgvi_conv2d_nhwc_bf16(const e2fgvi_conv_desc* d, void* stream);
 
 /* Winograd F(2x2,3x3) form of the same operator for 3x3 / stride 1 / pad 1 layers with even H, W (the encoder's
  * stride-1 layers e2fgvi.py:77-93, the decoder convs :112-150, SoftComp's HQ bias conv e2fgvi_hq tfocal :67-79): fp32
- * arithmetic on the fp32 MFMA pipe, 16 instead of 36 multiplies per 2x2 outputs.  Same descriptor; restrictions: every
- * src_cpg a multiple of 8, no residual, NHWC output, bk ignored, tile = 0 (auto) / 32 / 64 output channels per
- * workgroup.  Weights: [group][8-channel chunk][16 positions][2][Npad][4] holding G g G^T. */
+ * arithmetic on the fp32 MFMA pipe, 16 instead of 36 multiplies per 2x2 outputs.  Also the propagation convs
+ * (feat_prop.py:20-28,73-79) incl. the ACT_DCNPOST epilogue.  Same descriptor; restrictions: every src_cpg a multiple
+ * of 4, NHWC output, bk ignored; tile = 0 (auto), 32 / 64 (couts per workgroup, 16x16-pixel blocks) or 132 / 164
+ * (8x16-pixel blocks).  Weights: [group][8-channel chunk][16 positions][2][Npad][4] holding G g G^T. */
 int64_t e2fgvi_packed_winograd_weight_size(int32_t Cout, int32_t groups, int32_t nsrc, const int32_t* src_cpg); /* floats */
 int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32_t Cout, int32_t groups, int32_t nsrc,
                                 const int32_t* src_cpg, void* stream);

@@ -465,6 +465,10 @@ WINO_CASES = [
     (1, 34, 50, [128], 1, 128, 1, 64, 160, 16),          # write into a channel slice of a wider tensor
     (1, 18, 66, [40], 1, 24, 3, 0, None, 0),             # Cout not a multiple of 32, tanh
     (5, 2, 2, [16], 1, 8, 0, 0, None, 0),                # image smaller than a block
+    (1, 60, 108, [128], 1, 128, 2, 132, None, 0),        # propagation conv, 8x16-pixel blocks
+    (1, 60, 108, [128, 128, 128], 1, 128, 2, 164, None, 0),   # backbone.0 (forward), 8x16 blocks x 64 couts
+    (2, 30, 54, [128, 128, 128, 4], 1, 128, 2, 0, None, 0),   # conv_offset.0: a 4-channel source (flows) ends a chunk
+    (1, 20, 36, [12, 4, 8], 1, 40, 0, 132, None, 0),          # sources of 12 / 4 / 8 channels
 ]
 
 
@@ -497,16 +501,59 @@ def test_conv3x3_winograd(dev, case):
     assert_close(out.cpu(), direct.cpu(), 2e-5, "winograd vs implicit GEMM")
 
 
+@pytest.mark.parametrize("tile", [0, 64, 132])
+def test_conv3x3_winograd_residual(dev, tile):
+    """residual add in the Winograd epilogue (backbone.2 of the propagation: feat_prop + conv(...)), aligned and not"""
+    from e2fgvi_amd import ops
+    g = _gen(42)
+    x = torch.randn(2, 128, 30, 54, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
+    b = torch.randn(128, generator=g)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), [128], pad=1, algo="winograd")
+    for res_ld, res_coff in ((128, 0), (136, 8), (131, 3)):
+        resfull = torch.randn(2, 30, 54, res_ld, generator=g)
+        res = resfull[..., res_coff:res_coff + 128]
+        ref = F.leaky_relu(F.conv2d(x, w, b, padding=1) + nchw(res), 0.1)
+        out = layer([nhwc(x).to(dev)], residual=resfull.to(dev), res_coff=res_coff, act=2, slope=0.1, tile=tile)
+        assert_close(nchw(out.cpu()), ref, 2e-5, "winograd conv + residual (ld %d coff %d)" % (res_ld, res_coff))
+
+
+@pytest.mark.parametrize("tile", [0, 32, 164])
+def test_conv3x3_winograd_dcnpost(dev, tile):
+    """ACT_DCNPOST epilogue (10*tanh + flow.flip on the offsets, sigmoid on the masks; feat_prop.py:38-53) on the
+    Winograd path == the implicit-GEMM path's, and == the torch formula"""
+    from e2fgvi_amd import ops
+    g = _gen(43)
+    N, H, W = 2, 30, 54
+    x = torch.randn(N, 128, H, W, generator=g)
+    w = torch.randn(432, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
+    b = torch.randn(432, generator=g) * 0.1
+    fl = torch.randn(N, H, W, 4, generator=g) * 3
+    raw = F.conv2d(x, w, b, padding=1)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    off = 10 * torch.tanh(torch.cat([o1, o2], 1))
+    f1 = fl[..., 0:2].permute(0, 3, 1, 2)
+    f2 = fl[..., 2:4].permute(0, 3, 1, 2)
+    off1, off2 = torch.chunk(off, 2, 1)
+    ref = torch.cat([off1 + f1.flip(1).repeat(1, 72, 1, 1), off2 + f2.flip(1).repeat(1, 72, 1, 1), torch.sigmoid(m)], 1)
+    wl = ops.PackedConv(w.to(dev), b.to(dev), [128], pad=1, algo="winograd")
+    out = wl([nhwc(x).to(dev)], residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0, tile=tile)
+    assert_close(nchw(out.cpu()), ref, 3e-5, "winograd DCNPOST vs torch")
+    dl = ops.PackedConv(w.to(dev), b.to(dev), [128], pad=1)
+    direct = dl([nhwc(x).to(dev)], residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0)
+    assert_close(out.cpu(), direct.cpu(), 3e-5, "winograd DCNPOST vs implicit GEMM")
+
+
 def test_conv3x3_winograd_argument_errors(dev):
     from e2fgvi_amd import ops
     from e2fgvi_amd.lib import HipError
     w = torch.randn(32, 16, 3, 3, device=dev)
     with pytest.raises(ValueError):
-        ops.PackedConv(torch.randn(32, 12, 3, 3, device=dev), None, [12], pad=1, algo="winograd")     # cpg % 8
+        ops.PackedConv(torch.randn(32, 10, 3, 3, device=dev), None, [10], pad=1, algo="winograd")     # cpg % 4
     with pytest.raises(ValueError):
         ops.PackedConv(w, None, [16], stride=2, pad=1, algo="winograd")
     layer = ops.PackedConv(w, None, [16], pad=1, algo="winograd")
     with pytest.raises(HipError):
         layer([torch.randn(1, 15, 16, 16, device=dev)])                                               # odd H
     with pytest.raises(HipError):
-        layer([torch.randn(1, 16, 16, 16, device=dev)], residual=torch.randn(1, 16, 16, 32, device=dev))
+        layer([torch.randn(1, 16, 16, 16, device=dev)], tile=48)                                      # unknown tile code

@@ -18,7 +18,13 @@ LAYERS = [  # name, N, H, W, cpg, groups, Cout
     ("dec.2  128->64  @120x216", 10, 120, 216, [128], 1, 64),
     ("dec.4   64->64  @240x432", 10, 240, 432, [64], 1, 64),
     ("prop   128->128 @60x108 x1", 1, 60, 108, [128], 1, 128),
+    ("prop off.0 388->128 x1", 1, 60, 108, [128, 128, 128, 4], 1, 128),
+    ("prop off.6 128->432 x1", 1, 60, 108, [128], 1, 432),
+    ("prop bb.0 256->128 x1", 1, 60, 108, [128, 128], 1, 128),
+    ("prop bb.0 384->128 x1", 1, 60, 108, [128, 128, 128], 1, 128),
 ]
+if os.environ.get("WINO_ONLY_PROP"):
+    LAYERS = [l for l in LAYERS if l[0].startswith("prop")]
 
 def timeit(fn, iters=10):
     for _ in range(2): fn()
