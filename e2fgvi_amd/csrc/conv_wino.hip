@@ -72,15 +72,38 @@ constexpr int PLANE_ROW = 12;             // 16-byte units per patch row in one 
 constexpr unsigned OOB = 0xFFFFFFFFu;
 template <int V> struct IC { static constexpr int value = V; };
 
+// The weight (B operand) loads must be ISSUED a whole chunk before their use; the compiler sinks ordinary loads down to
+// just before the first MFMA that needs them and the L2 latency lands on the critical path (measured: ~1300 cycles per
+// chunk).  They are therefore issued through inline asm, pinned in place, and waited for with an explicit s_waitcnt
+// whose count is the number of vector loads issued after them.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 rsrc_words(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void buf_load4_pinned(f32x4& v, i32x4 rsrc, unsigned byte_off) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc));
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+
 // MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
-template <int MT, int BN>
-__global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
+template <int MT, int BN, int SC>
+__global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
+    static_assert(SC == 2 || SC == 4, "chunks per LDS stage");
     constexpr int NT = 512;
     constexpr int TN = BN / 32;
     constexpr int RAW_H = 8 * MT + 2;
     constexpr int PLANE_BYTES = RAW_H * PLANE_ROW * 16;
     constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;              // planes of one 8-channel chunk: [kq][column parity]
-    constexpr int STAGE_BYTES = 2 * CHUNK_BYTES;              // an LDS stage holds two chunks (one barrier per 16 channels)
+    constexpr int STAGE_BYTES = SC * CHUNK_BYTES;             // an LDS stage holds SC chunks (one barrier per 8 SC channels)
     constexpr int TILES = 32 * MT;
     constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
     constexpr int SMEM = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
@@ -122,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
     // Chunks past the end (odd chunk count, prefetch overrun) need no guards: their weight loads fall outside the
     // group's buffer range and return zeros, so whatever patch data is re-read contributes nothing.
     int s = 0, c0 = 0;              // next chunk to load: source, first channel inside the group's slice
-    f32x4 rraw[2][RAW_IT];
+    f32x4 rraw[SC][RAW_IT];
     auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
         const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
         const unsigned ld4 = (unsigned)p.ld[s] * 4u;
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
     auto store_raw = [&](int buf) {
         unsigned char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < SC; ++q)
 #pragma unroll
             for (int it = 0; it < RAW_IT; ++it)
                 if (raw_dst[it] >= 0) *reinterpret_cast<f32x4*>(base + q * CHUNK_BYTES + raw_dst[it]) = rraw[q][it];
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
 
     // ---- B operands (pre-transformed weights) go global -> registers, no LDS: lane (i, h) of position a, column
     // tile n needs U[chunk][2*wave + a][kq = h][n0 + 32 n + i][0..3] = one 16-byte load
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_elems, p.wgroup_bytes);
+    const i32x4 wrsrc = rsrc_words(p.w + (long long)g * p.wgroup_elems, p.wgroup_bytes);
     const unsigned u_step = 32u * (unsigned)p.Npad * 16u;          // bytes per chunk
     unsigned u_off[2][TN];
 #pragma unroll
@@ -181,7 +204,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int n = 0; n < TN; ++n) q[a][n] = buf_load4(wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
+            for (int n = 0; n < TN; ++n) buf_load4_pinned(q[a][n], wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
+    };
+    // the chunk's weights were issued one chunk ago; LATER is the number of vector loads issued since then
+    auto claim_b = [&](auto LATER_, f32x4 (&q)[2][TN]) {
+        wait_vmcnt<decltype(LATER_)::value>();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) asm volatile("" : "+v"(q[a][n]));
     };
 
     f32x16 acc[2][MT][TN];
@@ -194,13 +225,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
 
-    const int nstages = (p.nchunks + 1) >> 1;
-    load_raw(rraw[0]);
-    load_raw(rraw[1]);
+    const int nstages = (p.nchunks + SC - 1) / SC;
+#pragma unroll
+    for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
     load_b(0, bq[0]);
     store_raw(0);
-    load_raw(rraw[0]);
-    load_raw(rraw[1]);
+#pragma unroll
+    for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
     __syncthreads();
 
     // the K loop, specialised on the wave's role so that the input transform is plain adds / subtracts
@@ -210,8 +241,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
         for (int st = 0; st < nstages; ++st) {
             const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                load_b(2 * st + q + 1, bq[q ^ 1]);                   // next chunk's weights land during this chunk
+            for (int q = 0; q < SC; ++q) {
+                load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);            // next chunk's weights land during this chunk
+                // loads issued after this chunk's weights: the next chunk's (2 TN) and, across a stage boundary, the
+                // patch prefetch (SC * RAW_IT)
+                if (q == 0) claim_b(IC<2 * TN + SC * RAW_IT>{}, bq[q & 1]);
+                else claim_b(IC<2 * TN>{}, bq[q & 1]);
+                __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* raw = stage + q * CHUNK_BYTES;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -229,15 +265,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoParams p) {
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
                         for (int n = 0; n < TN; ++n) {
-                            acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[k], bq[q][0][n][k], acc[0][m][n], 0, 0, 0);
-                            acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q][1][n][k], acc[1][m][n], 0, 0, 0);
+                            acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[k], bq[q & 1][0][n][k], acc[0][m][n], 0, 0, 0);
+                            acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q & 1][1][n][k], acc[1][m][n], 0, 0, 0);
                         }
                 }
             }
             // the registers hold stage st+1: park it in the other buffer (its readers passed the previous barrier)
             store_raw((st & 1) ^ 1);
-            load_raw(rraw[0]);
-            load_raw(rraw[1]);
+#pragma unroll
+            for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
             __syncthreads();
         }
     };
@@ -410,7 +446,7 @@ extern "C" int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32
     return 0;
 }
 
-template <int MT, int BN>
+template <int MT, int BN, int SC>
 static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     p.blocksY = cdiv(p.H, 8 * MT);
     p.blocksX = cdiv(p.W, 16);
@@ -418,7 +454,7 @@ static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL((conv_wino_kernel<MT, BN>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd");
     return 0;
 }
@@ -470,23 +506,18 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     int tile = d->tile;
     if (!tile) {
-        // 256 CUs hold one workgroup each (two of the smallest shape): pick the shape whose rounds of workgroups cost
-        // least.  Relative cost of a workgroup: 16x16 px x 64 couts = 1; halving the couts or the rows saves less than
-        // half (the patch transform, prologue and epilogue do not shrink with the tile).
-        const int MTs[4] = {2, 2, 1, 1}, BNs[4] = {64, 32, 64, 32};
-        const double unit[4] = {1.0, 0.56, 0.56, 0.33};
-        double best = 1e30;
-        for (int c = 0; c < 4; ++c) {
-            const long long wgs = (long long)d->N * cdiv(d->H, 8 * MTs[c]) * cdiv(d->W, 16) * cdiv(q.Cout_g, BNs[c]) * d->groups;
-            const double t = (double)((wgs + 255) / 256) * unit[c];
-            if (t < best - 1e-9) { best = t; tile = BNs[c] + (MTs[c] == 1 ? 100 : 0); }
-        }
+        // Measured on MI355X (tools/wino_bench.py, profiles/r01_wino_bench.txt): the 8x16-pixel x 32-cout shape (two
+        // workgroups per CU: one's prologue / epilogue hides under the other's MFMAs) wins or ties everywhere except on
+        // the layers with >= 256 output channels per group, where the 16x16 x 64 shape amortises the patch transform
+        // over twice the columns and is 3-6 % faster.
+        const long long big = (long long)d->N * cdiv(d->H, 16) * cdiv(d->W, 16) * cdiv(q.Cout_g, 64) * d->groups;
+        tile = (q.Cout_g >= 256 && big >= 128) ? 64 : 132;
     }
     switch (tile) {
-        case 64: return launch_wino<2, 64>(p, d->groups, st);
-        case 32: return launch_wino<2, 32>(p, d->groups, st);
-        case 164: return launch_wino<1, 64>(p, d->groups, st);
-        case 132: return launch_wino<1, 32>(p, d->groups, st);
+        case 64: return launch_wino<2, 64, 2>(p, d->groups, st);
+        case 32: return launch_wino<2, 32, 2>(p, d->groups, st);
+        case 164: return launch_wino<1, 64, 2>(p, d->groups, st);
+        case 132: return launch_wino<1, 32, 2>(p, d->groups, st);
         default: break;
     }
     e2fgvi_set_error("conv3x3_winograd: tile must be 0 (auto), 32, 64 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");
