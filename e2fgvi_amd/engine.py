@@ -69,7 +69,7 @@ def build_key_table(fh, fw, valid_ind_rolled):
 
 
 class Engine:
-    def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32", winograd=True):
+    def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32", winograd=True, autotune=True):
         """precision="fp32": every contraction on fp32 MFMA (the default and the parity configuration).
         precision="bf16": the wide conv / linear layers run on bf16 MFMA with fp32 accumulation (BASELINE.json HQ
         configurations); SPyNet, the first / last conv, conv_offset's last layer, the deformable conv and the attention
@@ -164,6 +164,13 @@ class Engine:
         self.half = torch.full((4,), 0.5, device=self.device)
         self._tables = {}
         self._zeros = {}
+        if autotune and precision == "fp32":
+            # GEMM-shaped layers (token Linears, soft split / composite): the best implicit-GEMM tile depends on the
+            # token count; time the candidates on the first call of each size (eager warm-up, never under graph capture)
+            for blk in self.blocks:
+                for k in ("qkv", "proj", "fc1", "fc2"):
+                    blk[k].tune = True
+            self.ss.tune = self.sc.tune = self.fusion.tune = True
         # SPyNet runs on a side stream next to the encoder -- fp32 mode only.  Measured on MI355X (tools/overlap_probe.py,
         # DESIGN.md "Stream overlap"): with the 2x2-accumulator bf16 conv tiles on the other stream, spynet_level_input
         # intermittently produced wrong values in lanes 48-63 of a wave; no fp32 kernel ever triggered it, and the bf16
