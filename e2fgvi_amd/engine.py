@@ -16,6 +16,8 @@ All activations are NHWC fp32; nothing here computes on the CPU or through torch
 owns the buffers (and does index-only copies when clips are batched).
 """
 import numpy as np
+import os
+
 import torch
 
 from . import ops
@@ -164,7 +166,7 @@ class Engine:
         self.half = torch.full((4,), 0.5, device=self.device)
         self._tables = {}
         self._zeros = {}
-        if autotune and precision == "fp32":
+        if autotune and precision == "fp32" and os.environ.get("E2FGVI_AUTOTUNE", "1") != "0":
             # GEMM-shaped layers (token Linears, soft split / composite): the best implicit-GEMM tile depends on the
             # token count; time the candidates on the first call of each size (eager warm-up, never under graph capture)
             for blk in self.blocks:

@@ -39,7 +39,8 @@ def empty_nhwc(n, h, w, c, device):
 # ------------------------------------------------------------------------------------------ conv / linear
 # implicit-GEMM tile codes worth timing on GEMM-shaped layers (64x64 / 128x128 / 64x128 / 128x256 / 256x128 shapes with
 # 16- and 32-deep K steps); 0 = the library's static choice
-TUNE_CANDIDATES = (0, 213, 223, 211, 216, 226, 219, 218, 126, 123)
+TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
+_TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 
 
 class PackedConv:
@@ -67,7 +68,6 @@ class PackedConv:
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
         self.tune = False          # time TUNE_CANDIDATES on the first call of every new input size and keep the fastest
-        self._tuned = {}
         if algo not in ("igemm", "winograd", "auto"):
             raise ValueError("algo must be 'igemm', 'winograd' or 'auto'")
         wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 4 for c in self.cpg)
@@ -117,17 +117,20 @@ class PackedConv:
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
 
     def _autotune(self, lib, d):
-        """Device time of every candidate tile code on this exact call (3 launches each, hip events); the launches
+        """Device time of every candidate tile code on this exact call (2 launches each, hip events); the launches
         rewrite the same output, so the result of the call is unaffected."""
         best, best_ms = 0, float("inf")
         st = _stream()
+        d.tile = 0
+        for _ in range(3):                                       # bring clocks / caches to steady state first
+            lib.e2fgvi_conv2d_nhwc(C.byref(d), st)
         for code in TUNE_CANDIDATES:
             d.tile = code
             if lib.e2fgvi_conv2d_nhwc(C.byref(d), st) != 0:      # not instantiated / not applicable to this packing
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(3):
+            for _ in range(2):
                 lib.e2fgvi_conv2d_nhwc(C.byref(d), st)
             e1.record()
             e1.synchronize()
@@ -201,12 +204,13 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
-        if tile == 0 and self.tune and not use_wino and self.precision == "fp32":
-            key = (N, H, W, residual is not None)
-            best = self._tuned.get(key)
+        if tile == 0 and self.tune and not use_wino and self.precision == "fp32" and N * Ho * Wo >= 2048:
+            key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk, N, H, W,
+                   residual is not None, act)
+            best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
-                best = self._tuned[key] = self._autotune(lib, d)
+                best = _TUNED[key] = self._autotune(lib, d)
             d.tile = best or 0
         if use_wino:
             _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")

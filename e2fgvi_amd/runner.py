@@ -85,23 +85,33 @@ class ShardedStep:
 
 
 def dominant_kernel_probe(net, dev, iters=20):
-    """Device time of the dominant kernel family (conv_igemm, fp32 MFMA) on its heaviest single launch of the
-    north-star clip: encoder layer 8 (256 -> 384, 3x3, 10 frames of 60x108), hip events on the launch stream."""
+    """Device time of the dominant kernel (conv_wino_kernel, fp32 Winograd F(2x2,3x3) on the fp32 MFMA pipe) on its
+    heaviest single launch of the north-star clip: encoder layer 10 (640 -> 512 in 2 groups, 3x3, 10 frames of 60x108),
+    hip events on the launch stream.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s, so it can exceed the MFMA
+    peak: the kernel executes 16/36 of those multiplies (x the block padding)."""
     from . import ops
     eng = net.engine()
-    layer = eng.enc[4]
-    x = torch.randn(10, 60, 108, 256, device=dev)
-    out = layer([x], act=ops.ACT_LRELU, slope=0.2)
+    layer = eng.enc[5]
+    x0 = torch.randn(10, 60, 108, 256, device=dev)
+    x1 = torch.randn(10, 60, 108, 384, device=dev)
+    out = layer([x0, x1], act=ops.ACT_LRELU, slope=0.2)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        layer([x], out=out, act=ops.ACT_LRELU, slope=0.2)
+        layer([x0, x1], out=out, act=ops.ACT_LRELU, slope=0.2)
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
-    gflop = 2 * 10 * 60 * 108 * 9 * 256 * 384 * 1e-9
+    gflop = 2 * 10 * 60 * 108 * 9 * 320 * 512 * 1e-9
     tf = gflop / (us * 1e-6) / 1e3
-    return {"kernel": "conv_igemm_kernel<128,128,16,2,2,2,1> (encoder.layers.8: 3x3 256->384 on 10x60x108)",
-            "avg_us": round(us, 2), "gflop_per_launch": round(gflop, 3), "achieved": round(tf, 2),
-            "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4)}
+    wino = layer.algo == "auto"
+    # multiplies actually issued: 16 per 2x2 outputs and input channel instead of 36, on 64x112 padded pixels per frame
+    executed = tf * (16.0 / 36.0) * (64 * 112) / (60 * 108) if wino else tf
+    name = ("conv_wino_kernel<2,64,2> (Winograd F(2x2,3x3), encoder.layers.10: 3x3 640->512 g2 on 10x60x108)" if wino else
+            "conv_igemm_kernel (encoder.layers.10: 3x3 640->512 g2 on 10x60x108)")
+    return {"kernel": name, "avg_us": round(us, 2), "gflop_per_launch": round(gflop, 3), "achieved": round(tf, 2),
+            "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+            "mfma_executed": round(executed, 2), "mfma_frac": round(executed / 157.3, 4),
+            "note": "achieved = algorithmic (direct conv) FLOPs / time; Winograd issues 16/36 of them, mfma_executed is what "
+                    "the matrix pipe actually did"}

@@ -8,6 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export E2FGVI_AUTOTUNE=0     # no tuning launches inside the counted forwards
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > $OUT/$C.log 2>&1 || true
 done
