@@ -309,13 +309,15 @@ class Engine:
         blk = self.blocks[i]
         H, W = hw
         tab, nk = self._table(fh, fw, blk)
-        n1 = ops.layernorm(x, blk["n1w"], blk["n1b"])
-        pooled = ops.window_pool(n1, blk["pool_w"], blk["pool_b"], b * t, fh, fw)
-        # qkv of the tokens and of the pooled windows share one allocation (one buffer resource in the attention kernel)
-        rows, prow = n1.shape[0], pooled.shape[0]
-        both = torch.empty((rows + prow, 1536), dtype=torch.float32, device=n1.device)
-        qkv = blk["qkv"](n1, out=both[:rows])
-        kvp = blk["qkv"](pooled, out=both[rows:])
+        # LayerNorm output and the pooled windows share one buffer, and so do their qkv rows: ONE qkv GEMM for both
+        # (and one buffer resource in the attention kernel)
+        rows = x.shape[0]
+        prow = b * t * (fh // 5) * (fw // 9)
+        nbuf = torch.empty((rows + prow, 512), dtype=torch.float32, device=x.device)
+        n1 = ops.layernorm(x, blk["n1w"], blk["n1b"], out=nbuf[:rows])
+        ops.window_pool(n1, blk["pool_w"], blk["pool_b"], b * t, fh, fw, out=nbuf[rows:])
+        both = blk["qkv"](nbuf)
+        qkv, kvp = both[:rows], both[rows:]
         att = ops.focal_attention(qkv, kvp, tab, nk, b, t, fh, fw)
         x1 = blk["proj"](att, residual=x)
         n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"])

@@ -434,11 +434,15 @@ def layernorm(x, gamma, beta, out=None):
     return out
 
 
-def window_pool(x, w45, bias1, BT, fh, fw):
+def window_pool(x, w45, bias1, BT, fh, fw, out=None):
     lib = _L.load()
     _chk(x, "x"); _chk(w45, "w45"); _chk(bias1, "bias1")
     Cc = x.shape[-1]
-    out = torch.empty((BT * (fh // 5) * (fw // 9), Cc), dtype=torch.float32, device=x.device)
+    rows = BT * (fh // 5) * (fw // 9)
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=torch.float32, device=x.device)
+    elif tuple(_chk(out, "out").shape) != (rows, Cc):
+        raise ValueError("window_pool out must be [%d,%d]" % (rows, Cc))
     _L.check(lib.e2fgvi_window_pool(_ptr(x), _ptr(w45), _ptr(bias1), _ptr(out), BT, fh, fw, Cc, _stream()), "window_pool")
     return out
 
