@@ -69,6 +69,11 @@ SYMBOLS = {
     "e2fgvi_window_pool": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_ffn_fold": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_ffn_unfold_gelu": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_mask_prepare": (C.c_int, [_fp, _i32, _i32, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
+    "e2fgvi_masked_clip": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _fp, _i32, _i32, _fp]),
+    "e2fgvi_composite": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_float_to_u8": (C.c_int, [_fp, _fp, _i64, _fp]),
+    "e2fgvi_pred_to_u8": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_softcomp_fold": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
 }
 

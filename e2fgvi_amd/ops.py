@@ -476,3 +476,68 @@ def softcomp_fold(emb, F_, fh, fw, H, W, Cc, bias_hwc=None, residual=None):
     _L.check(lib.e2fgvi_softcomp_fold(_ptr(emb), _ptr(bias_hwc), _ptr(residual), _ptr(out), F_, fh, fw, H, W, Cc,
                                       _stream()), "softcomp_fold")
     return out
+
+
+# ------------------------------------------------------------------------------------------ video driver (byte side)
+def _u8(t, name):
+    return _chk(t, name, torch.uint8)
+
+
+def mask_prepare(masks_u8, ytab, xtab, H, W, iterations=4):
+    """masks_u8 [L,Hin,Win] uint8 -> [L,H,W] uint8 of 0/1 (NEAREST resize by the given tables, > 0, cross dilation)."""
+    lib = _L.load()
+    _u8(masks_u8, "masks")
+    _chk(ytab, "ytab", torch.int32); _chk(xtab, "xtab", torch.int32)
+    L, Hin, Win = masks_u8.shape
+    if ytab.numel() != H or xtab.numel() != W:
+        raise ValueError("ytab / xtab must have H / W entries")
+    out = torch.empty((L, H, W), dtype=torch.uint8, device=masks_u8.device)
+    _L.check(lib.e2fgvi_mask_prepare(_ptr(masks_u8), L, Hin, Win, _ptr(ytab), _ptr(xtab), _ptr(out), H, W, iterations, _stream()),
+             "mask_prepare")
+    return out
+
+
+def masked_clip(frames_u8, masks01, ids, Hp, Wp):
+    """frames_u8 [L,H,W,3], masks01 [L,H,W], ids int32 [t] -> fp32 [1,t,3,Hp,Wp] masked clip in [-1,1], mirror padded."""
+    lib = _L.load()
+    _u8(frames_u8, "frames"); _u8(masks01, "masks"); _chk(ids, "ids", torch.int32)
+    L, H, W, _ = frames_u8.shape
+    t = ids.numel()
+    out = torch.empty((1, t, 3, Hp, Wp), dtype=torch.float32, device=frames_u8.device)
+    _L.check(lib.e2fgvi_masked_clip(_ptr(frames_u8), _ptr(masks01), _ptr(ids), t, H, W, _ptr(out), Hp, Wp, _stream()), "masked_clip")
+    return out
+
+
+def composite(pred, ids, first, frames_u8, masks01, comp):
+    """pred fp32 [>=n,3,Hp,Wp]; ids int32 [n]; first uint8 [n]; comp fp32 [L,H,W,3] updated in place (test.py:168-179)."""
+    lib = _L.load()
+    _chk(pred, "pred"); _chk(ids, "ids", torch.int32); _u8(first, "first"); _u8(frames_u8, "frames"); _u8(masks01, "masks")
+    _chk(comp, "comp")
+    L, H, W, _ = frames_u8.shape
+    n = ids.numel()
+    if pred.shape[0] < n or pred.shape[1] != 3:
+        raise ValueError("pred must hold at least %d frames of 3 channels" % n)
+    _L.check(lib.e2fgvi_composite(_ptr(pred), _ptr(ids), _ptr(first), n, _ptr(frames_u8), _ptr(masks01), _ptr(comp), H, W,
+                                  pred.shape[2], pred.shape[3], _stream()), "composite")
+    return comp
+
+
+def float_to_u8(x):
+    lib = _L.load()
+    _chk(x, "x")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _L.check(lib.e2fgvi_float_to_u8(_ptr(x), _ptr(out), x.numel(), _stream()), "float_to_u8")
+    return out
+
+
+def pred_to_u8(pred, H=None, W=None):
+    """model output [N,3,Hp,Wp] in (-1,1) -> uint8 NHWC [N,H,W,3] = uint8((pred+1)/2*255), cropped to H x W."""
+    lib = _L.load()
+    _chk(pred, "pred")
+    N, c, Hp, Wp = pred.shape
+    if c != 3:
+        raise ValueError("pred must be [N,3,H,W]")
+    H, W = H or Hp, W or Wp
+    out = torch.empty((N, H, W, 3), dtype=torch.uint8, device=pred.device)
+    _L.check(lib.e2fgvi_pred_to_u8(_ptr(pred), _ptr(out), N, H, W, Hp, Wp, _stream()), "pred_to_u8")
+    return out

@@ -23,14 +23,20 @@ def gather_frames(local_out, world, group=None, out=None, force=False):
     return out
 
 
-def inpaint_sharded(net, clips, num_local_frames, rank, world, group=None):
+def inpaint_sharded(net, clips, num_local_frames, rank, world, group=None, pack_u8=False):
     """clips: [B,t,3,H,W] (same on every rank, or at least this rank's slice valid).  Every rank runs its
-    contiguous share and all ranks receive all output frames [B*t,3,H,W].  B must be divisible by world."""
+    contiguous share and all ranks receive all output frames [B*t,3,H,W].  B must be divisible by world.
+
+    pack_u8: convert this rank's frames to the uint8 NHWC form test.py saves (uint8((pred+1)/2*255), HIP kernel) BEFORE
+    the all-gather -- a quarter of the bytes over xGMI; returns uint8 [B*t,H,W,3]."""
     B = clips.shape[0]
     if B % world:
         raise ValueError("number of clips (%d) must be divisible by the number of ranks (%d)" % (B, world))
     lo, hi = shard_range(B, rank, world)
     out, _ = net(clips[lo:hi], num_local_frames)
+    if pack_u8:
+        from . import ops
+        out = ops.pred_to_u8(out.contiguous())
     return gather_frames(out, world, group)
 
 

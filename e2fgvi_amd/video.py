@@ -1,13 +1,16 @@
-"""Sliding-window video inpainting driver on device (SURVEY.md 8f rank 1).
+"""Sliding-window video inpainting driver on device (SURVEY.md 8f rank 1 and 4).
 
-Mirrors the reference's demo loop -- ``test.py:39-53`` (reference-frame selection), ``:57-70`` (mask
-binarise + 4x cross dilation), ``:146-179`` (neighbour window of +-stride frames every ``stride`` frames,
-mirror padding to multiples of (60,108), compositing with the mask, 0.5/0.5 blending of overlapping
-predictions) -- without cv2 / torchvision: frames and masks come in as uint8 arrays, everything after the
-upload happens on the GPU, and only the finished uint8 frames are copied back.
+Mirrors the reference's demo loop -- ``test.py:39-53`` (reference-frame selection), ``:56-69`` (mask NEAREST resize,
+binarise, 4x cross dilation), ``:146-179`` (neighbour window of +-stride frames every ``stride`` frames, mirror padding
+to multiples of (60,108), compositing with the mask, 0.5/0.5 blending of overlapping predictions) -- without cv2 /
+torchvision / PIL: frames and masks come in as uint8 arrays, everything after the upload runs in HIP kernels
+(csrc/video.hip) and only the finished uint8 frames are copied back.  The window planning below is host logic; the byte
+arithmetic has no CPU path.
 """
 import numpy as np
 import torch
+
+from . import ops
 
 
 def get_ref_index(f, neighbor_ids, length, ref_length=10, num_ref=-1):
@@ -28,70 +31,69 @@ def get_ref_index(f, neighbor_ids, length, ref_length=10, num_ref=-1):
     return ref_index
 
 
-def dilate_cross(mask, iterations=4):
-    """cv2.dilate(m, getStructuringElement(MORPH_CROSS, (3, 3)), iterations=4) for a binary [L,H,W] tensor
-    (test.py:64-68): each iteration ORs the 4-neighbourhood; pixels outside the image do not contribute."""
-    m = mask.bool()
-    for _ in range(iterations):
-        n = m.clone()
-        n[:, 1:] |= m[:, :-1]
-        n[:, :-1] |= m[:, 1:]
-        n[:, :, 1:] |= m[:, :, :-1]
-        n[:, :, :-1] |= m[:, :, 1:]
-        m = n
-    return m
+def plan_windows(length, neighbor_stride=5, ref_length=10, num_ref=-1):
+    """The (neighbour ids, reference ids) of every window of test.py:146-153, in the reference's order."""
+    windows = []
+    for f in range(0, length, neighbor_stride):
+        neighbor_ids = list(range(max(0, f - neighbor_stride), min(length, f + neighbor_stride + 1)))
+        windows.append((neighbor_ids, get_ref_index(f, neighbor_ids, length, ref_length, num_ref)))
+    return windows
 
 
-def mirror_pad(x, mod_h=60, mod_w=108):
-    """test.py:156-165: pad H, W up to multiples of (60,108) by appending the flipped clip and cropping."""
-    h, w = x.shape[-2:]
-    h_pad = (mod_h - h % mod_h) % mod_h
-    w_pad = (mod_w - w % mod_w) % mod_w
-    x = torch.cat([x, torch.flip(x, [3])], 3)[:, :, :, :h + h_pad, :]
-    x = torch.cat([x, torch.flip(x, [4])], 4)[:, :, :, :, :w + w_pad]
-    return x
+def padded_size(h, w, mod_h=60, mod_w=108):
+    """test.py:156-159: H, W rounded up to multiples of (60,108)."""
+    return h + (mod_h - h % mod_h) % mod_h, w + (mod_w - w % mod_w) % mod_w
+
+
+def nearest_table(n_in, n_out):
+    """Source index of every output index of PIL's ``Image.resize(size, Image.NEAREST)`` (test.py:62).  Pillow's
+    ImagingScaleAffine starts at 0.5 * scale and ADDS the scale once per output pixel in double precision, then
+    truncates; the running sum is reproduced literally (np.cumsum accumulates sequentially)."""
+    scale = float(n_in) / float(n_out)
+    steps = np.full(n_out, scale, dtype=np.float64)
+    steps[0] = 0.0 + scale * 0.5
+    pos = np.cumsum(steps)
+    return np.minimum(pos.astype(np.int64), n_in - 1).astype(np.int32)
+
+
+def prepare_masks(masks_u8, size_hw, device, dilate=True):
+    """uint8 masks [L,Hin,Win] (any size, any non-zero = hole) -> device uint8 [L,H,W] of 0/1 like test.py:56-69."""
+    m = torch.as_tensor(np.ascontiguousarray(masks_u8)).to(device)
+    H, W = size_hw
+    ytab = torch.from_numpy(nearest_table(m.shape[1], H)).to(device)
+    xtab = torch.from_numpy(nearest_table(m.shape[2], W)).to(device)
+    return ops.mask_prepare(m, ytab, xtab, H, W, 4 if dilate else 0)
 
 
 @torch.no_grad()
 def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, num_ref=-1, dilate=True,
                   device=None, pad=True, batch_windows=1):
-    """frames_u8: uint8 [L,H,W,3]; masks_u8: [L,H,W] (non-zero = hole).  Returns uint8 [L,H,W,3] composited
-    frames, computed like test.py:129-179.  ``model(masked[b,t,3,H',W'], n_local) -> (pred[b*t,3,H',W'], _)``.
+    """frames_u8: uint8 [L,H,W,3]; masks_u8: [L,Hm,Wm] (non-zero = hole; resized to the frames with NEAREST like
+    read_mask).  Returns uint8 [L,H,W,3] composited frames, computed like test.py:129-179.
+    ``model(masked[b,t,3,H',W'], n_local) -> (pred[b*t,3,H',W'], _)`` on the device.
 
     ``batch_windows`` > 1 runs windows of equal shape (same number of local and reference frames) as one forward of
-    b clips -- clips are independent, so the predictions are the same; the compositing / blending below is still
-    applied in the reference's window order (the 0.5/0.5 blend is order dependent)."""
-    frames_u8 = torch.as_tensor(np.asarray(frames_u8))
-    masks_u8 = torch.as_tensor(np.asarray(masks_u8))
+    b clips -- clips are independent, so the predictions are the same; the compositing / blending is still applied in
+    the reference's window order (the 0.5/0.5 blend is order dependent)."""
     if device is None:
-        device = next(model.parameters()).device if hasattr(model, "parameters") else torch.device("cpu")
-    L, h, w, _ = frames_u8.shape
-    frames_d = frames_u8.to(device)
-    binary = (masks_u8.to(device) > 0)
-    if dilate:
-        binary = dilate_cross(binary, 4)
-    imgs = (frames_d.permute(0, 3, 1, 2).float() / 255.0).unsqueeze(0) * 2 - 1            # to_tensors()*2-1
-    masks = binary.float().view(1, L, 1, h, w)
-    bmask = binary.view(L, h, w, 1)
-
-    windows = []
-    for f in range(0, L, neighbor_stride):
-        neighbor_ids = list(range(max(0, f - neighbor_stride), min(L, f + neighbor_stride + 1)))
-        windows.append((neighbor_ids, get_ref_index(f, neighbor_ids, L, ref_length, num_ref)))
+        device = next(model.parameters()).device
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("inpaint_video runs on the MI355X (cuda) device only; there is no CPU path")
+    frames_d = torch.as_tensor(np.ascontiguousarray(frames_u8)).to(device)
+    L, h, w, _ = frames_d.shape
+    masks01 = prepare_masks(masks_u8, (h, w), device, dilate)
+    Hp, Wp = padded_size(h, w) if pad else (h, w)
+    windows = plan_windows(L, neighbor_stride, ref_length, num_ref)
+    ids_dev = [torch.tensor(nb + rf, dtype=torch.int32, device=device) for nb, rf in windows]
 
     def predict(group):
-        clips = []
-        for neighbor_ids, ref_ids in group:
-            ids = neighbor_ids + ref_ids
-            masked = imgs[:, ids] * (1 - masks[:, ids])
-            clips.append(mirror_pad(masked) if pad else masked)
-        x = torch.cat(clips, 0).contiguous()
-        n_local = len(group[0][0])
+        x = torch.cat([ops.masked_clip(frames_d, masks01, ids_dev[i], Hp, Wp) for i in group], 0) if len(group) > 1 \
+            else ops.masked_clip(frames_d, masks01, ids_dev[group[0]], Hp, Wp)
+        n_local = len(windows[group[0]][0])
         pred, _ = model(x, n_local)
         t = x.shape[1]
-        pred = (pred[:, :, :h, :w] + 1) / 2
-        pred = (pred.permute(0, 2, 3, 1) * 255).view(len(group), t, h, w, 3)             # float, [b,t,h,w,3]
-        return [pred[i, :n_local] for i in range(len(group))]
+        return [pred[k * t:k * t + n_local] for k in range(len(group))]
 
     preds = [None] * len(windows)
     if batch_windows <= 1:
@@ -102,17 +104,14 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
             by_shape.setdefault((len(nb), len(rf)), []).append(i)
         order = [idx[k:k + batch_windows] for idx in by_shape.values() for k in range(0, len(idx), batch_windows)]
     for grp in order:
-        for i, p in zip(grp, predict([windows[i] for i in grp])):
+        for i, p in zip(grp, predict(grp)):
             preds[i] = p
 
-    comp = [None] * L
-    for (neighbor_ids, _), pred in zip(windows, preds):
-        for i, idx in enumerate(neighbor_ids):
-            # np.array(pred).astype(uint8) * mask + frame * (1 - mask)   (test.py:171-174)
-            img = torch.where(bmask[idx], pred[i].to(torch.uint8), frames_d[idx])
-            if comp[idx] is None:
-                comp[idx] = img
-            else:
-                comp[idx] = comp[idx].float() * 0.5 + img.float() * 0.5
-    out = torch.stack([c.to(torch.uint8) for c in comp], 0)
-    return out.cpu().numpy()
+    comp = torch.empty((L, h, w, 3), dtype=torch.float32, device=device)
+    seen = [False] * L
+    for i, (neighbor_ids, _) in enumerate(windows):
+        first = torch.tensor([0 if seen[j] else 1 for j in neighbor_ids], dtype=torch.uint8, device=device)
+        ops.composite(preds[i].contiguous(), ids_dev[i][:len(neighbor_ids)].contiguous(), first, frames_d, masks01, comp)
+        for j in neighbor_ids:
+            seen[j] = True
+    return ops.float_to_u8(comp).cpu().numpy()

@@ -31,6 +31,29 @@ extern "C" {
 #define E2FGVI_ACT_RELU 1
 #define E2FGVI_ACT_LRELU 2   /* slope in desc */
 #define E2FGVI_ACT_TANH 3
+/* ------------------------------------------------------------------------------------------------
+ * Byte side of the sliding-window video driver (reference: test.py).
+ * uint8 frames [L,H,W,3] and masks stay on the device; all results are bit-exact with the numpy / PIL reference.
+ * ------------------------------------------------------------------------------------------------ */
+/* test.py:56-69 read_mask: NEAREST resize of [L,Hin,Win] masks to H x W (ytab[H] / xtab[W] = source row / column of
+ * every output row / column, built like Pillow's ImagingScaleAffine), binarise (> 0), `iterations` dilations with the
+ * 3x3 cross (cv2.dilate, out-of-image pixels ignored).  out: [L,H,W] of 0 / 1. */
+int e2fgvi_mask_prepare(const uint8_t* masks, int32_t L, int32_t Hin, int32_t Win, const int32_t* ytab, const int32_t* xtab,
+                        uint8_t* out, int32_t H, int32_t W, int32_t iterations, void* stream);
+/* test.py:146-165: clip[ti][c][y][x] = (frames[ids[ti]]/255*2-1) * (1 - masks[ids[ti]]), fp32 NCHW [t,3,Hp,Wp], rows /
+ * columns beyond H / W mirror the frame (cat([x, flip(x)])[:Hp]). */
+int e2fgvi_masked_clip(const uint8_t* frames, const uint8_t* masks, const int32_t* ids, int32_t t, int32_t H, int32_t W,
+                       float* clip, int32_t Hp, int32_t Wp, void* stream);
+/* test.py:168-179: for the first n frames of pred [*,3,Hp,Wp] (model output in (-1,1)):
+ * img = uint8((pred+1)/2*255) * mask + frame * (1-mask); comp[ids[i]] = first[i] ? img : comp*0.5 + img*0.5 (float [L,H,W,3]). */
+int e2fgvi_composite(const float* pred, const int32_t* ids, const uint8_t* first, int32_t n, const uint8_t* frames,
+                     const uint8_t* masks, float* comp, int32_t H, int32_t W, int32_t Hp, int32_t Wp, void* stream);
+/* ndarray.astype(uint8) of the blended frames (truncation) */
+int e2fgvi_float_to_u8(const float* src, uint8_t* dst, int64_t n, void* stream);
+/* model output [N,3,Hp,Wp] in (-1,1) -> uint8 NHWC [N,H,W,3] = uint8((pred+1)/2*255): the form the clip-sharded runner
+ * gathers over xGMI (4x fewer bytes than fp32). */
+int e2fgvi_pred_to_u8(const float* pred, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t Hp, int32_t Wp, void* stream);
+
 /* conv_offset post-processing of SecondOrderDeformableAlignment (feat_prop.py:38-53) fused into the conv that produces
  * it: `residual` must point to the per-pixel flows [P,4] = (u1,v1,u2,v2) with res_ld = 4, `slope` = max_residue:
  * offset channels -> slope*tanh(v) + flow.flip, mask channels (last third) -> sigmoid(v) */
