@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libe2fgvi_hip.so")
-SOURCES = ["error.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "mdcn.hip", "attention.hip", "misc.hip", "video.hip"]
+SOURCES = ["error.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "mdcn.hip", "attention.hip", "misc.hip", "video.hip", "metrics.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 

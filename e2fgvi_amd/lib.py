@@ -74,6 +74,8 @@ SYMBOLS = {
     "e2fgvi_composite": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_float_to_u8": (C.c_int, [_fp, _fp, _i64, _fp]),
     "e2fgvi_pred_to_u8": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_psnr_ssim_workspace": (_i64, [_i32, _i32, _i32]),
+    "e2fgvi_psnr_ssim": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp, _fp, _fp]),
     "e2fgvi_softcomp_fold": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
 }
 

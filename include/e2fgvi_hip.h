@@ -54,6 +54,16 @@ int e2fgvi_float_to_u8(const float* src, uint8_t* dst, int64_t n, void* stream);
  * gathers over xGMI (4x fewer bytes than fp32). */
 int e2fgvi_pred_to_u8(const float* pred, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t Hp, int32_t Wp, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * evaluate.py metrics (core/metrics.py:20-56): per image pair of fp32 NHWC [N,H,W,3] frames in
+ * [0,255]: out[2n] = PSNR (inf when identical), out[2n+1] = SSIM as skimage compare_ssim(data_range=255,
+ * multichannel=True, win_size) computes it (uniform window, sample covariance, K1 .01, K2 .03, crop (win-1)/2).
+ * fp64 like the reference.  workspace: e2fgvi_psnr_ssim_workspace(N,H,W) bytes, caller-owned.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t e2fgvi_psnr_ssim_workspace(int32_t N, int32_t H, int32_t W);
+int e2fgvi_psnr_ssim(const float* img1, const float* img2, int32_t N, int32_t H, int32_t W, int32_t win_size,
+                     void* workspace, double* out, void* stream);
+
 /* conv_offset post-processing of SecondOrderDeformableAlignment (feat_prop.py:38-53) fused into the conv that produces
  * it: `residual` must point to the per-pixel flows [P,4] = (u1,v1,u2,v2) with res_ld = 4, `slope` = max_residue:
  * offset channels -> slope*tanh(v) + flow.flip, mask channels (last third) -> sigmoid(v) */
