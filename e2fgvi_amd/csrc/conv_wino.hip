@@ -144,18 +144,35 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
 
     // Chunks past the end (odd chunk count, prefetch overrun) need no guards: their weight loads fall outside the
     // group's buffer range and return zeros, so whatever patch data is re-read contributes nothing.
+    // The parameters of the source being walked live in (scalar) registers and are re-read from the kernel arguments only
+    // when the walk crosses into the next source -- indexing p.src[s] / p.ld[s] / ... per chunk would put two dependent
+    // scalar-memory round trips in front of every chunk's patch loads.
     int s = 0, c0 = 0;              // next chunk to load: source, first channel inside the group's slice
+    const float* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int cur_cpg = p.cpg[0];
     f32x4 rraw[SC][RAW_IT];
     auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
-        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
-        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
-        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u + raw_kq16;
-        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < p.cpg[s];   // a source may end in the middle of a chunk (cpg % 8 == 4)
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const unsigned chan = cur_chan + (unsigned)c0 * 4u + raw_kq16;
+        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;   // a source may end in the middle of a chunk (cpg % 8 == 4)
 #pragma unroll
-        for (int it = 0; it < RAW_IT; ++it)
-            q[it] = buf_load4(arsrc, (cvalid && raw_off[it] != OOB) ? raw_off[it] * ld4 + chan : OOB);
+        for (int it = 0; it < RAW_IT; ++it) {
+            const unsigned off = raw_off[it] * cur_ld4 + chan;
+            q[it] = buf_load4(arsrc, (cvalid && raw_off[it] != OOB) ? off : OOB);
+        }
         c0 += 8;
-        if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
+        if (c0 >= cur_cpg) {
+            c0 = 0;
+            ++s;
+            if (s == p.nsrc) s = 0;
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld4 = (unsigned)p.ld[s] * 4u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 4u; cur_cpg = p.cpg[s];
+            }
+        }
     };
     auto store_raw = [&](int buf) {
         unsigned char* base = smem + buf * STAGE_BYTES;

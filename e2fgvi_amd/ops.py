@@ -181,7 +181,7 @@ class PackedConv:
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
         use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and not out_nchw
-                                               and tile in (0, 32, 64, 132, 164))
+                                               and (tile in (0, 32, 64, 132, 164) or tile > 1000))
         d.wpacked = (self.wino_packed if use_wino else self.wpacked).data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         dev = srcs[0][0].device
