@@ -137,12 +137,20 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void conv_igemm_kernel(const C
     // D register stages: this group's next D chunks are in flight while the current one is multiplied
     f32x4 ra[D][A_IT], rb[D][B_IT];
 
+    // parameters of the source being walked, carried in scalar registers and re-read from the kernel arguments only when
+    // the walk moves to another source (indexing p.src[s] ... per chunk costs two dependent scalar-memory round trips)
+    const float* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int cur_cpg = p.cpg[0];
+
     auto load_tile = [&](int kt, f32x4 (&qa)[A_IT], f32x4 (&qb)[B_IT]) {
         const bool tile_ok = kt < KT;                                   // past the end: everything reads as zero
-        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
-        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
-        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0 + c4 * 4) * 4u;
-        const bool cok = tile_ok && (c0 + c4 * 4) < p.cpg[s];
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const unsigned ld4 = cur_ld4;
+        const unsigned chan = cur_chan + (unsigned)(c0 + c4 * 4) * 4u;
+        const bool cok = tile_ok && (c0 + c4 * 4) < cur_cpg;
         const int tap = ky * p.W + kx;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
@@ -173,13 +181,17 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void conv_igemm_kernel(const C
     };
     auto advance1 = [&]() {
         c0 += BK;
-        if (c0 >= p.cpg[s]) {
+        if (c0 >= cur_cpg) {
             c0 = 0;
             ++s;
             if (s == p.nsrc) {
                 s = 0;
                 ++kx;
                 if (kx == p.KW) { kx = 0; ++ky; }
+            }
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld4 = (unsigned)p.ld[s] * 4u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 4u; cur_cpg = p.cpg[s];
             }
         }
     };
@@ -370,11 +382,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
     const int nblk = p.chunks_per_tap;       // channel blocks over all sources
     int s = 0, c0 = 0;                       // source / first channel of the block being LOADED
 
+    // current source's parameters in scalar registers (see conv_igemm_kernel)
+    const float* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int cur_cpg = p.cpg[0];
     auto load_patch = [&](bool valid) {
-        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
-        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
-        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u;
-        const int cpg = p.cpg[s];
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const unsigned ld4 = cur_ld4;
+        const unsigned chan = cur_chan + (unsigned)c0 * 4u;
+        const int cpg = cur_cpg;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const bool ok = valid && pp_pix[it] >= 0 && (c0 + pp_c4[it] * 4) < cpg;
@@ -388,7 +406,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_halo_kernel(const ConvPar
     };
     auto advance_blk = [&]() {
         c0 += CB;
-        if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
+        if (c0 >= cur_cpg) {
+            c0 = 0; ++s; if (s == p.nsrc) s = 0;
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld4 = (unsigned)p.ld[s] * 4u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 4u; cur_cpg = p.cpg[s];
+            }
+        }
     };
     // weight stage = taps [tap0, tap0+TG) of channel block `blk`; chunk index in the packing is tap*nblk + blk
     auto load_b = [&](int tap0, int blk, bool valid) {
@@ -570,11 +594,17 @@ __global__ __launch_bounds__(64 * WGM) void conv_halo16_kernel(const ConvParams 
     f32x4 rp[P_IT], rb[B_IT];
     const int nblk = p.chunks_per_tap;
     int s = 0, c0 = 0;
+    // current source's parameters in scalar registers (see conv_igemm_kernel)
+    const float* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int cur_cpg = p.cpg[0];
     auto load_patch = [&](bool valid) {
-        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
-        const unsigned ld4 = (unsigned)p.ld[s] * 4u;
-        const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0) * 4u;
-        const int cpg = p.cpg[s];
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const unsigned ld4 = cur_ld4;
+        const unsigned chan = cur_chan + (unsigned)c0 * 4u;
+        const int cpg = cur_cpg;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const bool ok = valid && pp_pix[it] >= 0 && (c0 + pp_c4[it] * 4) < cpg;
@@ -588,7 +618,13 @@ __global__ __launch_bounds__(64 * WGM) void conv_halo16_kernel(const ConvParams 
     };
     auto advance_blk = [&]() {
         c0 += CB;
-        if (c0 >= p.cpg[s]) { c0 = 0; ++s; if (s == p.nsrc) s = 0; }
+        if (c0 >= cur_cpg) {
+            c0 = 0; ++s; if (s == p.nsrc) s = 0;
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld4 = (unsigned)p.ld[s] * 4u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 4u; cur_cpg = p.cpg[s];
+            }
+        }
     };
     auto load_b = [&](int tap0, int blk, bool valid) {
 #pragma unroll

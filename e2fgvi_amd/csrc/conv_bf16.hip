@@ -112,9 +112,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_bf16_kernel(const C
     f32x4 ra[D][2][A_IT];
     u32x4 rb[D][B_IT];
 
+    // current source's parameters in scalar registers (see conv.hip::conv_igemm_kernel)
+    const float* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int cur_cpg = p.cpg[0];
     auto advance = [&]() {
         c0 += 32;
-        if (c0 >= p.cpg[s]) {
+        if (c0 >= cur_cpg) {
             c0 = 0;
             ++s;
             if (s == p.nsrc) {
@@ -122,16 +128,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_bf16_kernel(const C
                 ++kx;
                 if (kx == p.KW) { kx = 0; ++ky; }
             }
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld4 = (unsigned)p.ld[s] * 4u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 4u; cur_cpg = p.cpg[s];
+            }
         }
     };
     auto load_step = [&](int step, f32x4 (&qa)[2][A_IT], u32x4 (&qb)[B_IT]) {
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc) {
             const bool chunk_ok = (2 * step + sc) < KT32;
-            const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.src[s], p.src_bytes[s]);
-            const unsigned ld4 = (unsigned)p.ld[s] * 4u;
-            const unsigned chan = (unsigned)(p.coff[s] + g * p.cpg[s] + c0 + c4 * 4) * 4u;
-            const bool cok = chunk_ok && (c0 + c4 * 4) < p.cpg[s];
+            const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+            const unsigned ld4 = cur_ld4;
+            const unsigned chan = cur_chan + (unsigned)(c0 + c4 * 4) * 4u;
+            const bool cok = chunk_ok && (c0 + c4 * 4) < cur_cpg;
             const int tap = ky * p.W + kx;
 #pragma unroll
             for (int ia = 0; ia < A_IT; ++ia) {
