@@ -63,6 +63,9 @@ __global__ __launch_bounds__(64 * NW * KS) void focal_attn_kernel(const float* _
     constexpr int L_IT = (F4 + NT - 1) / NT;
     constexpr unsigned OOB = 0xFFFFFFFFu;
     __shared__ __attribute__((aligned(16))) float smem[KS * 4 * TK * LDK];
+    __shared__ int stab[256];                   // the window's key table (<= 210 entries): looked up once per staged row,
+                                                // from LDS -- a global lookup put a dependent L2 round trip in front of
+                                                // every tile's K loads
     static_assert(KS == 1 || 4 * TK * LDK >= 66 * NT, "merge scratch must fit one group's rings");
 
     const int kg = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT));
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(64 * NW * KS) void focal_attn_kernel(const float* _
     const int NK = T * nv;
     const int ntiles = (NK + TK - 1) / TK;
     const int* tab = key_tab + (long long)win * tab_ld;
+    for (int e = threadIdx.x; e < nv && e < 256; e += KS * NT) stab[e] = tab[e];
+    __syncthreads();
 
     // staging: thread handles float4 f = tid + it*NT  -> row f>>5, column chunk f&31
     f32x4 stg[L_IT];
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(64 * NW * KS) void focal_attn_kernel(const float* _
             // next tile of this group is KS*TK rows further (nv >= 165 > KS*TK: at most one wrap)
             kt_s[it] += KS * TK;
             if (kt_s[it] >= nv) { kt_s[it] -= nv; kt_t[it] += 1; }
-            const int ref = tab[s];
+            const int ref = stab[s];
             const bool pooled = ref < 0;
             const unsigned rowi = pooled ? (unsigned)((b * T + t) * nWin + (-(ref + 1))) : (unsigned)((b * T + t) * ntok + ref);
             koff[it] = ok ? rowi * (unsigned)(CQ * 4) + (unsigned)((512 + head * HD + c * 4) * 4) +
