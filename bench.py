@@ -89,15 +89,6 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-
     import importlib
     from e2fgvi_amd import runner
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
@@ -109,6 +100,24 @@ def main():
     net = net.to(dev).eval()
     x, _ = synth_clip(b, t, 240, 432, seed=100 + rank)
     x = x.to(dev)
+    # Build the engine (weight re-layout, tile tuning, stream creation) BEFORE RCCL comes up: measured on MI355X, a
+    # forward whose engine was built after init_process_group runs ~4 % slower (17.8 vs 17.15 ms; tools note in DESIGN.md)
+    net(x, lt)
+    torch.cuda.synchronize()
+
+    dist = None
+    if world > 1 or args.force_dist:
+        if rank != 0:
+            # only rank 0 reports: keep the other ranks' stdout (RCCL prints its version banner there when NCCL_DEBUG is set)
+            # from landing after the JSON line
+            sys.stdout.flush()
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
 
     # HIP-graph replay only for the single-process run: with RCCL's watchdog thread alive, stream capture is an
     # avoidable risk, and the forward is device-bound anyway (eager = graph within 1 %)
@@ -116,6 +125,7 @@ def main():
                               force_gather=args.force_dist)
     for _ in range(args.warmup):
         step.run()
+    step.finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -125,6 +135,7 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         step.run()
+    step.finish()                         # the last step's (pipelined) all-gather joins the timed region
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -171,10 +182,13 @@ def main():
         out["roofline"]["dominant_kernel"] = dom
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, t, lt)
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)        # C stdio first (RCCL's banner), so that the JSON line is the last line on stdout
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

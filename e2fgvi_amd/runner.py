@@ -82,12 +82,40 @@ class ShardedStep:
         else:
             out = self._forward()
         if self.world > 1 or self.force_gather:
-            if self.gathered is None:
-                self.gathered = torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype,
-                                            device=out.device)
-            gather_frames(out, self.world, out=self.gathered, force=self.force_gather)
-            return self.gathered
+            return self._gather_pipelined(out)
         return out
+
+    def _gather_pipelined(self, out):
+        """All-gather of this step's frames on RCCL's stream while the NEXT step's forward runs: the call returns the
+        gathered frames of the previous step (None on the first call); `finish()` returns the last ones.  Two gather
+        buffers alternate; the forward's output tensor is kept alive until its gather has completed."""
+        import torch.distributed as dist
+        if self.graph is not None:                         # static output buffer: it would be overwritten under the gather
+            if self.gathered is None:
+                self.gathered = [torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype,
+                                             device=out.device)]
+            gather_frames(out, self.world, out=self.gathered[0], force=self.force_gather)
+            return self.gathered[0]
+        if self.gathered is None:
+            self.gathered = [torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+                             for _ in range(2)]
+            self._pending = None
+        buf = self.gathered[self._calls & 1]
+        work = dist.all_gather_into_tensor(buf, out.contiguous(), async_op=True)
+        prev, self._pending = self._pending, (work, out, buf)
+        if prev is None:
+            return None
+        prev[0].wait()                                     # stream-level wait; that gather finished a whole forward ago
+        return prev[2]
+
+    def finish(self):
+        """Frames of the last step (waits for its gather)."""
+        if getattr(self, "_pending", None) is None:
+            return self.out if self.graph is not None else None
+        work, _, buf = self._pending
+        work.wait()
+        self._pending = None
+        return buf
 
 
 def dominant_kernel_probe(net, dev, iters=20):
