@@ -42,3 +42,15 @@ def calc_psnr_and_ssim(img1, img2, device="cuda"):
 def calculate_epe(flow1, flow2):
     """core/metrics.py:13-18 (end point error of two flow fields [N,2,H,W]); a reduction torch already does on device."""
     return torch.sum((flow1 - flow2) ** 2, dim=1).sqrt().view(-1).mean().item()
+
+
+def evaluate_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, win_size=65):
+    """evaluate.py:75-125 for one video on the device: the sliding-window completion (no mask dilation, no padding --
+    the dataset delivers frames at the model's size with binary masks) followed by per-frame PSNR / SSIM of the blended
+    frames against the originals.  Returns (psnr[L], ssim[L]) float64 numpy arrays; their means are the video's scores."""
+    from . import video
+    comp = video.inpaint_video(model, frames_u8, masks_u8, neighbor_stride, ref_length, -1, dilate=False, pad=False,
+                               keep_float=True)
+    ori = torch.as_tensor(np.ascontiguousarray(frames_u8)).to(comp.device).float()
+    r = psnr_ssim(ori, comp, win_size).cpu().numpy()
+    return r[:, 0], r[:, 1]

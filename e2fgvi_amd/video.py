@@ -67,16 +67,19 @@ def prepare_masks(masks_u8, size_hw, device, dilate=True):
 
 @torch.no_grad()
 def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, num_ref=-1, dilate=True,
-                  device=None, pad=True, batch_windows=1):
+                  device=None, pad=True, batch_windows=1, keep_float=False):
     """frames_u8: uint8 [L,H,W,3]; masks_u8: [L,Hm,Wm] (non-zero = hole; resized to the frames with NEAREST like
     read_mask).  Returns uint8 [L,H,W,3] composited frames, computed like test.py:129-179.
     ``model(masked[b,t,3,H',W'], n_local) -> (pred[b*t,3,H',W'], _)`` on the device.
 
     ``batch_windows`` > 1 runs windows of equal shape (same number of local and reference frames) as one forward of
     b clips -- clips are independent, so the predictions are the same; the compositing / blending is still applied in
-    the reference's window order (the 0.5/0.5 blend is order dependent)."""
+    the reference's window order (the 0.5/0.5 blend is order dependent).
+
+    keep_float=True returns the blended frames as the fp32 device tensor [L,H,W,3] they are before the final
+    ``astype(uint8)`` -- what evaluate.py:113-114 feeds to calc_psnr_and_ssim."""
     if device is None:
-        device = next(model.parameters()).device
+        device = next(model.parameters()).device if hasattr(model, "parameters") else torch.device("cuda")
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("inpaint_video runs on the MI355X (cuda) device only; there is no CPU path")
@@ -114,4 +117,6 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
         ops.composite(preds[i].contiguous(), ids_dev[i][:len(neighbor_ids)].contiguous(), first, frames_d, masks01, comp)
         for j in neighbor_ids:
             seen[j] = True
+    if keep_float:
+        return comp
     return ops.float_to_u8(comp).cpu().numpy()

@@ -30,7 +30,7 @@ def dilate_cross_np(m, iterations=4):
     return m.astype(np.uint8)
 
 
-def run(model_fn, frames, masks, neighbor_stride=5, ref_length=10, num_ref=-1):
+def run(model_fn, frames, masks, neighbor_stride=5, ref_length=10, num_ref=-1, pad=True, as_float=False):
     """frames: list of uint8 [h,w,3]; masks: list of uint8 [h,w] (already binary 0/1, dilated)."""
     video_length = len(frames)
     h, w = frames[0].shape[:2]
@@ -45,8 +45,8 @@ def run(model_fn, frames, masks, neighbor_stride=5, ref_length=10, num_ref=-1):
         selected_masks = mt[:1, neighbor_ids + ref_ids]
         masked_imgs = selected_imgs * (1 - selected_masks)
         mod_size_h, mod_size_w = 60, 108
-        h_pad = (mod_size_h - h % mod_size_h) % mod_size_h
-        w_pad = (mod_size_w - w % mod_size_w) % mod_size_w
+        h_pad = (mod_size_h - h % mod_size_h) % mod_size_h if pad else 0      # evaluate.py:86-92 does not pad
+        w_pad = (mod_size_w - w % mod_size_w) % mod_size_w if pad else 0
         masked_imgs = torch.cat([masked_imgs, torch.flip(masked_imgs, [3])], 3)[:, :, :, :h + h_pad, :]
         masked_imgs = torch.cat([masked_imgs, torch.flip(masked_imgs, [4])], 4)[:, :, :, :, :w + w_pad]
         pred_imgs = model_fn(masked_imgs, len(neighbor_ids))
@@ -60,4 +60,6 @@ def run(model_fn, frames, masks, neighbor_stride=5, ref_length=10, num_ref=-1):
                 comp_frames[idx] = img
             else:
                 comp_frames[idx] = comp_frames[idx].astype(np.float32) * 0.5 + img.astype(np.float32) * 0.5
+    if as_float:                                                           # evaluate.py:113 passes these on as they are
+        return [c for c in comp_frames]
     return np.stack([c.astype(np.uint8) for c in comp_frames])

@@ -71,3 +71,22 @@ def test_calc_psnr_and_ssim_api(dev):
     assert metrics.calc_psnr_and_ssim(a, a) == (float("inf"), 1.0)
     with pytest.raises(Exception):
         metrics.psnr_ssim(torch.zeros(1, 40, 40, 3, device=dev), torch.zeros(1, 40, 40, 3, device=dev))   # window > image
+
+
+@pytest.mark.gpu
+def test_evaluate_video_matches_reference_loop(dev):
+    """evaluate.py's per-video loop: completion (no dilation / padding) + per-frame PSNR / SSIM of the blended float frames,
+    device path vs numpy reference loop + metrics oracle, with a stand-in model on the CPU in both"""
+    from e2fgvi_amd import metrics
+    from oracle import video_ref
+    rng = np.random.RandomState(5)
+    L, h, w = 13, 70, 90
+    frames = [np.clip(rng.randint(0, 256, (h, w, 3)) * 0.3 + 90 + 20 * i, 0, 255).astype(np.uint8) for i in range(L)]
+    masks = [np.zeros((h, w), np.uint8) for _ in range(L)]
+    for i, m in enumerate(masks):
+        m[20 + i:45 + i, 30:60] = 1
+    fake = lambda x, n: torch.tanh(x.reshape(-1, 3, h, w) * 0.6)
+    ref_comp = video_ref.run(fake, frames, masks, 5, 10, -1, pad=False, as_float=True)
+    ref = np.array([metrics_ref.calc_psnr_and_ssim(o, c, 65) for o, c in zip(frames, ref_comp)])
+    psnr, ssim = metrics.evaluate_video(lambda x, n: (fake(x.cpu(), n).to(dev), None), np.stack(frames), np.stack(masks))
+    assert np.abs(psnr - ref[:, 0]).max() <= 1e-9 * ref[:, 0].max() and np.abs(ssim - ref[:, 1]).max() <= 1e-9
