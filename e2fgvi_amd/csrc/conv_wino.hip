@@ -87,11 +87,13 @@ __device__ __forceinline__ i32x4 rsrc_words(const void* base, unsigned bytes) {
     return r;
 }
 __device__ __forceinline__ void buf_load4_pinned(f32x4& v, i32x4 rsrc, unsigned byte_off) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc));
+    // "memory": the compiler's own loads (the patch prefetch) must keep their program order around these, the explicit
+    // vmcnt counts below depend on it
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
