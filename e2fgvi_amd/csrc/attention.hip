@@ -222,10 +222,14 @@ __global__ __launch_bounds__(64 * NW * KS) void focal_attn_kernel(const float* _
             }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            // rescale the accumulators only when some query's running maximum moved: after the first tiles it rarely
+            // does, alpha is then exactly 1 and the 64 multiplies (+ their accumulator-register moves) are skipped
+            if (__any(alpha != 1.0f)) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int krow = (r & 3) + 8 * (r >> 2) + 4 * h;

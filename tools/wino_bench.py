@@ -22,6 +22,9 @@ LAYERS = [  # name, N, H, W, cpg, groups, Cout
     ("prop off.6 128->432 x1", 1, 60, 108, [128], 1, 432),
     ("prop bb.0 256->128 x1", 1, 60, 108, [128, 128], 1, 128),
     ("prop bb.0 384->128 x1", 1, 60, 108, [128, 128, 128], 1, 128),
+    ("prop   128->128 x2", 2, 60, 108, [128], 1, 128),
+    ("prop   128->128 x4", 4, 60, 108, [128], 1, 128),
+    ("prop off.0 388->128 x2", 2, 60, 108, [128, 128, 128, 4], 1, 128),
 ]
 if os.environ.get("WINO_ONLY_PROP"):
     LAYERS = [l for l in LAYERS if l[0].startswith("prop")]
