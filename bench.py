@@ -179,6 +179,14 @@ def main():
             pass
     if rank == 0:
         dom = runner.dominant_kernel_probe(net, dev)
+        dfile = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+        dom["traffic"] = None
+        if os.path.exists(dfile):
+            try:
+                dom["traffic"] = round(json.load(open(dfile))["hbm_bytes_per_launch"])
+                dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_dominant_kernel_traffic.json)"
+            except Exception:
+                pass
         out["roofline"]["dominant_kernel"] = dom
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, t, lt)
