@@ -35,8 +35,8 @@ SHAPES = {
     "enc0_b16": (10, 240, 432, [4], 1, 64, 3, 2, 1, 16),
     "spy5": (18, 64, 128, [16], 1, 2, 7, 1, 3, 16),
 }
-ALLW = [0, 121, 221, 211, 111, 1111, 1121, 222, 212, 122, 1122, 1222, 123, 223, 233, 213, 1223, 1123, 226, 216, 1226, 1126, 126, 218, 228, 118, 219, 119]
-CODES = {"qkv": ALLW, "proj": ALLW, "fc1": ALLW, "fc2_bk32": ALLW, "fc2_bk16": ALLW, "sc": ALLW, "ss": ALLW}
+ALLW = [0, 223, 213, 222, 212, 122, 1122, 1222, 224, 214, 1224, 225, 215, 1225, 3225, 227, 217, 1227, 2227, 2123, 2223, 3123, 1233, 1133, 1213, 2213, 3213, 228, 118, 211, 219]
+CODES = {"proj": ALLW, "fc2_bk32": ALLW, "fc2_bk16": ALLW, "sc": ALLW}
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 g = torch.Generator(); g.manual_seed(0)
