@@ -133,9 +133,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     const unsigned b_step = (unsigned)(BK / 4) * (unsigned)p.Npad * 16u;
 
     float r_dy[A_IT], r_dx[A_IT], r_mk[A_IT], r_fu[A_IT], r_fv[A_IT];   // raw words of the chunk after next
-    f32x4 c00[A_IT], c01[A_IT], c10[A_IT], c11[A_IT];
-    float w00[A_IT], w01[A_IT], w10[A_IT], w11[A_IT];
-    f32x4 rb[B_IT];
+    // two register sets: the corner fetches / weights of chunk k+2 are issued while those of chunk k+1 (issued one
+    // iteration earlier) are blended into LDS -- a whole MFMA block plus another group's turn covers the gather latency
+    f32x4 c00[2][A_IT], c01[2][A_IT], c10[2][A_IT], c11[2][A_IT];
+    float w00[2][A_IT], w01[2][A_IT], w10[2][A_IT], w11[2][A_IT];
+    f32x4 rb[2][B_IT];
 
     // ---- unit decode through a table in LDS.  A K-chunk is two units (uu = 0 / 1 by lane); unit u = ((g * KK) + tap) * cgq + cq.
     // Everything a lane needs from (g, tap, cq) -- offset / mask / flow word offsets, the tap's (ky, kx) * dilation, the
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         }
     };
     // turn the raw words (loaded for chunk kt) into corner fetches for chunk kt
-    auto issue_corners = [&](int kt) {
+    auto issue_corners = [&](int kt, int S) {
         // both units of a chunk read the same source (host guarantees an even unit count in source 0)
         const bool second_src = (kt * 2) >= p.units0;
         const __amdgpu_buffer_rsrc_t rs = second_src ? r_src1 : r_src0;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
             const bool vy0 = inside && y0 >= 0, vy1 = inside && y1 <= p.H - 1, vx0 = x0 >= 0, vx1 = x1 <= p.W - 1;
             const float mm = inside ? mk : 0.f;
-            w00[ia] = hy * hx * mm; w01[ia] = hy * lx * mm; w10[ia] = ly * hx * mm; w11[ia] = ly * lx * mm;
+            w00[S][ia] = hy * hx * mm; w01[S][ia] = hy * lx * mm; w10[S][ia] = ly * hx * mm; w11[S][ia] = ly * lx * mm;
             // 24-bit multiplies (full rate): pixel indices and pixel strides are < 2^24 (checked on the host).  The products
             // are formed from the row y1 and column x1, which are >= 0 whenever the sample is inside; the y0 / x0 addresses
             // follow by subtraction (they may wrap when y0 or x0 is -1 -- those corners are replaced by OOB below)
@@ -222,32 +224,32 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             const unsigned a01 = __umul24(r0 + (unsigned)x1, ld4) + ch;
             const unsigned a11 = __umul24(r1 + (unsigned)x1, ld4) + ch;
             const unsigned a00 = a01 - ld4, a10 = a11 - ld4;
-            c00[ia] = buf_load4(rs, (vy0 && vx0) ? a00 : OOB);
-            c01[ia] = buf_load4(rs, (vy0 && vx1) ? a01 : OOB);
-            c10[ia] = buf_load4(rs, (vy1 && vx0) ? a10 : OOB);
-            c11[ia] = buf_load4(rs, (vy1 && vx1) ? a11 : OOB);
+            c00[S][ia] = buf_load4(rs, (vy0 && vx0) ? a00 : OOB);
+            c01[S][ia] = buf_load4(rs, (vy0 && vx1) ? a01 : OOB);
+            c10[S][ia] = buf_load4(rs, (vy1 && vx0) ? a10 : OOB);
+            c11[S][ia] = buf_load4(rs, (vy1 && vx1) ? a11 : OOB);
         }
     };
-    auto load_w = [&](int kt) {
+    auto load_w = [&](int kt, int S) {
         const bool tile_ok = kt < KT;
 #pragma unroll
         for (int ib = 0; ib < B_IT; ++ib)
-            rb[ib] = buf_load4(r_w, (b_off[ib] == OOB || !tile_ok) ? OOB : b_off[ib] + (unsigned)kt * b_step);
+            rb[S][ib] = buf_load4(r_w, (b_off[ib] == OOB || !tile_ok) ? OOB : b_off[ib] + (unsigned)kt * b_step);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int S) {
         float* sA = sbase + buf * STAGE;
         float* sB = sA + BM * LDA;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             if (A_ITEMS % NG == 0 || (tid + ia * NG) < A_ITEMS) {
-                const f32x4 v = c00[ia] * w00[ia] + c01[ia] * w01[ia] + c10[ia] * w10[ia] + c11[ia] * w11[ia];
+                const f32x4 v = c00[S][ia] * w00[S][ia] + c01[S][ia] * w01[S][ia] + c10[S][ia] * w10[S][ia] + c11[S][ia] * w11[S][ia];
                 *reinterpret_cast<f32x4*>(sA + it_row[ia] * LDA + it_uu[ia] * 16 + it_c4[ia] * 4) = v;
             }
         }
 #pragma unroll
         for (int ib = 0; ib < B_IT; ++ib) {
             const int f = tid + ib * NG;
-            if (B_F4 % NG == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[ib];
+            if (B_F4 % NG == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[S][ib];
         }
     };
 
@@ -260,25 +262,34 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     // this group's chunks: kt = kg + it*KS.  Chunks past the end read zeros, so no guards are needed.
-    const int nIter = (KT + KS - 1) / KS;
+    // chunks: kt = kg + it*KS.  Chunks past the end read zeros, so no guards are needed and the iteration count is rounded
+    // up to even (the loop is unrolled by two so that the register sets alternate with compile-time indices).
+    const int nIter = ((KT + KS - 1) / KS + 1) & ~1;
     load_offsets(kg);
-    issue_corners(kg);
-    load_w(kg);
-    store_tile(0);
+    issue_corners(kg, 0);
+    load_w(kg, 0);
+    store_tile(0, 0);
     load_offsets(kg + KS);
+    issue_corners(kg + KS, 1);               // chunk kg+KS in flight in set 1
+    load_w(kg + KS, 1);
+    load_offsets(kg + 2 * KS);
     __syncthreads();
 
     int cur = 0;
-    for (int it = 0; it < nIter; ++it) {
-        const int kt = kg + it * KS;
-        issue_corners(kt + KS);              // consumes r_* (raw words of chunk kt+KS)
-        load_w(kt + KS);
-        load_offsets(kt + 2 * KS);
-        mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
-                                       wn * TN * 32, lane);
-        store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    for (int it = 0; it < nIter; it += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int kt = kg + (it + par) * KS;
+            // set (par) is free: its chunk went to LDS in the previous step.  Chunk kt+KS waits in set (par ^ 1).
+            issue_corners(kt + 2 * KS, par);     // consumes r_* (raw words of chunk kt+2KS)
+            load_w(kt + 2 * KS, par);
+            load_offsets(kt + 3 * KS);
+            mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
+                                           wn * TN * 32, lane);
+            store_tile(cur ^ 1, par ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     if (KS > 1) {
