@@ -49,6 +49,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
@@ -80,6 +84,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
 
     __shared__ __attribute__((aligned(16))) float smem[KS * 2 * STAGE];
     __shared__ __attribute__((aligned(16))) int utab[MAX_UNITS * 8];
+    // raw offset / mask (/ flow) words of a chunk: one 32-byte slot per (pixel row, unit) = {dy, dx, mask, -, fu, fv, -, -},
+    // fetched by the first 2 BM threads of the group (3 loads) instead of by every item's four channel lanes
+    // (20 loads per wave and chunk, mostly distinct cache lines); two buffers per group
+    constexpr int SLOTS = 2 * BM;
+    static_assert(SLOTS % 64 == 0 && SLOTS <= NG, "loader threads are whole waves of the group");
+    __shared__ __attribute__((aligned(16))) float sraw[KS * 2 * SLOTS * 8];
 
     const int kg = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NG));
     const int tid = threadIdx.x - kg * NG;
@@ -132,7 +142,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     }
     const unsigned b_step = (unsigned)(BK / 4) * (unsigned)p.Npad * 16u;
 
-    float r_dy[A_IT], r_dx[A_IT], r_mk[A_IT], r_fu[A_IT], r_fv[A_IT];   // raw words of the chunk after next
     // two register sets: the corner fetches / weights of chunk k+2 are issued while those of chunk k+1 (issued one
     // iteration earlier) are blended into LDS -- a whole MFMA block plus another group's turn covers the gather latency
     f32x4 c00[2][A_IT], c01[2][A_IT], c10[2][A_IT], c11[2][A_IT];
@@ -160,34 +169,42 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     }
     __syncthreads();
     const unsigned c_W = (unsigned)__builtin_amdgcn_readfirstlane(p.W);
-    // per-item constant parts of the offset / mask / flow addresses
-    unsigned po_base[A_IT], pm_base[A_IT], pf_base[A_IT];
-#pragma unroll
-    for (int ia = 0; ia < A_IT; ++ia) {
-        po_base[ia] = it_pix[ia] * (unsigned)p.off_ld * 4u;
-        pm_base[ia] = it_pix[ia] * (unsigned)p.msk_ld * 4u;
-        pf_base[ia] = it_pix[ia] * 16u;
-    }
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-
+    // ---- loader threads (tid < SLOTS): slot = (pixel row, unit in chunk)
+    float* const graw = sraw + kg * (2 * SLOTS * 8);
+    const bool loader = tid < SLOTS;                       // wave-uniform
+    unsigned l_po = 0, l_pm = 0, l_pf = 0;
+    bool l_ok = false;
+    {
+        const int m = m0 + (tid >> 1);
+        l_ok = loader && m < p.M;
+        const unsigned pix = l_ok ? (unsigned)m : 0u;
+        l_po = pix * (unsigned)p.off_ld * 4u;
+        l_pm = pix * (unsigned)p.msk_ld * 4u;
+        l_pf = pix * 16u;
+    }
+    f32x2 l_d = {0.f, 0.f}, l_f = {0.f, 0.f};
+    float l_mk = 0.f;
     auto load_offsets = [&](int kt) {
-#pragma unroll
-        for (int ia = 0; ia < A_IT; ++ia) {
-            const int u = 2 * kt + it_uu[ia];
-            const bool ok = kt < KT && u < p.units && it_ok[ia];
+        if (loader) {
+            const int u = 2 * kt + (tid & 1);
+            const bool ok = kt < KT && u < p.units && l_ok;
             const i32x4 e = *reinterpret_cast<const i32x4*>(utab + (ok ? u : 0) * 8);
-            const unsigned po = po_base[ia] + (unsigned)e[0];
-            const unsigned pm = pm_base[ia] + (unsigned)e[1];
-            const unsigned pf = pf_base[ia] + (unsigned)e[2];
-            r_dy[ia] = buf_load1(r_off, ok ? po : OOB);
-            r_dx[ia] = buf_load1(r_off, ok ? po + 4u : OOB);
-            r_mk[ia] = buf_load1(r_msk, ok ? pm : OOB);
-            r_fu[ia] = buf_load1(r_flw, ok ? pf : OOB);
-            r_fv[ia] = buf_load1(r_flw, ok ? pf + 4u : OOB);
+            l_d = buf_load2(r_off, ok ? l_po + (unsigned)e[0] : OOB);
+            l_mk = buf_load1(r_msk, ok ? l_pm + (unsigned)e[1] : OOB);
+            l_f = buf_load2(r_flw, ok ? l_pf + (unsigned)e[2] : OOB);
+        }
+    };
+    auto store_offsets = [&](int buf) {
+        if (loader) {
+            float* d = graw + (buf * SLOTS + tid) * 8;
+            const f32x4 a = {l_d[0], l_d[1], l_mk, 0.f};
+            *reinterpret_cast<f32x4*>(d) = a;
+            *reinterpret_cast<f32x2*>(d + 4) = l_f;
         }
     };
     // turn the raw words (loaded for chunk kt) into corner fetches for chunk kt
-    auto issue_corners = [&](int kt, int S) {
+    auto issue_corners = [&](int kt, int S, int rbuf) {
         // both units of a chunk read the same source (host guarantees an even unit count in source 0)
         const bool second_src = (kt * 2) >= p.units0;
         const __amdgpu_buffer_rsrc_t rs = second_src ? r_src1 : r_src0;
@@ -200,11 +217,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             const int* e = utab + (uok ? u : 0) * 8;
             const int dyk = e[3], dxk = e[4];
             const unsigned ch = (unsigned)e[5] - cbase4 + (unsigned)it_c4[ia] * 16u;
-            float dy = r_dy[ia], dx = r_dx[ia], mk = r_mk[ia];
+            const float* slot = graw + (rbuf * SLOTS + it_row[ia] * 2 + it_uu[ia]) * 8;
+            const f32x4 rw = *reinterpret_cast<const f32x4*>(slot);
+            float dy = rw[0], dx = rw[1], mk = rw[2];
             if (p.flows) {
+                const f32x2 fl = *reinterpret_cast<const f32x2*>(slot + 4);
                 // tanh / sigmoid through v_exp_f32 + v_rcp_f32 (abs error ~2e-7: <1e-5 px on the residual offset)
-                dy = p.max_residue * fast_tanh(dy) + r_fv[ia];     // flip: dy takes the v (y) component
-                dx = p.max_residue * fast_tanh(dx) + r_fu[ia];
+                dy = p.max_residue * fast_tanh(dy) + fl[1];        // flip: dy takes the v (y) component
+                dx = p.max_residue * fast_tanh(dx) + fl[0];
                 mk = fast_sigmoid(mk);
             }
             const float py = (float)(it_by[ia] + dyk) + dy;
@@ -265,14 +285,23 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     // chunks: kt = kg + it*KS.  Chunks past the end read zeros, so no guards are needed and the iteration count is rounded
     // up to even (the loop is unrolled by two so that the register sets alternate with compile-time indices).
     const int nIter = ((KT + KS - 1) / KS + 1) & ~1;
+    // software pipeline over this group's chunk sequence j = 0, 1, 2 ... (chunk kg + j KS); at the top of step i:
+    //   tile i in the LDS ring, corners + weights of chunk i+1 in flight in register set (i+1)&1,
+    //   raw words of chunk i+2 in sraw buffer i&1, raw words of chunk i+3 in the loader's registers
     load_offsets(kg);
-    issue_corners(kg, 0);
-    load_w(kg, 0);
-    store_tile(0, 0);
+    store_offsets(0);
     load_offsets(kg + KS);
-    issue_corners(kg + KS, 1);               // chunk kg+KS in flight in set 1
-    load_w(kg + KS, 1);
+    __syncthreads();
+    issue_corners(kg, 0, 0);
+    load_w(kg, 0);
+    store_offsets(1);
     load_offsets(kg + 2 * KS);
+    store_tile(0, 0);
+    __syncthreads();
+    issue_corners(kg + KS, 1, 1);
+    load_w(kg + KS, 1);
+    store_offsets(0);
+    load_offsets(kg + 3 * KS);
     __syncthreads();
 
     int cur = 0;
@@ -280,13 +309,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const int kt = kg + (it + par) * KS;
-            // set (par) is free: its chunk went to LDS in the previous step.  Chunk kt+KS waits in set (par ^ 1).
-            issue_corners(kt + 2 * KS, par);     // consumes r_* (raw words of chunk kt+2KS)
+            issue_corners(kt + 2 * KS, par, par);            // raw words of chunk i+2 from sraw buffer i&1
             load_w(kt + 2 * KS, par);
-            load_offsets(kt + 3 * KS);
             mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
                                            wn * TN * 32, lane);
-            store_tile(cur ^ 1, par ^ 1);
+            store_tile(cur ^ 1, par ^ 1);                    // chunk i+1
+            store_offsets(par ^ 1);                          // chunk i+3 (that buffer's readers passed the last barrier)
+            load_offsets(kt + 4 * KS);
             __syncthreads();
             cur ^= 1;
         }
@@ -414,6 +443,7 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
                    d->Wo == (d->W + 2 * d->pad - (d->dil * (d->KW - 1) + 1)) / d->stride + 1,
                E2FGVI_EINVAL, "mdcn: Ho/Wo inconsistent");
     E2_REQUIRE(d->offset && d->mask && d->wpacked && d->dst, E2FGVI_EINVAL, "mdcn: null pointer");
+    E2_REQUIRE(d->off_ld % 2 == 0, E2FGVI_EINVAL, "mdcn: off_ld must be even (dy, dx are fetched as one 8-byte word)");
     E2_REQUIRE((C / 16) * d->KH * d->KW <= MAX_UNITS, E2FGVI_EUNSUP, "mdcn: C/16 * KH * KW exceeds the %d-entry unit table", MAX_UNITS);
     E2_REQUIRE((long long)d->N * d->H * d->W + d->W < (1 << 24) && d->src_ld[0] * 4 < (1 << 24) &&
                    (d->nsrc == 1 || d->src_ld[1] * 4 < (1 << 24)),
