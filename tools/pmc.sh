@@ -30,12 +30,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res[c] = tot
     per_kernel[c] = pk.most_common(8)
     res[c + "_dispatches"] = n
-forwards = 3   # 1 warm-up + 2 timed (plus the one-off weight packing, negligible)
+forwards = 4   # engine-building forward + 1 warm-up + 2 timed (plus the one-off weight packing, negligible)
 fetch_b = res["FETCH_SIZE"] * 1024 * 2 / forwards     # gfx950: x2 on the read side
 write_b = res["WRITE_SIZE"] * 1024 / forwards
 js = {"fetch_bytes_per_forward": fetch_b, "write_bytes_per_forward": write_b, "hbm_bytes_per_forward": fetch_b + write_b,
       "raw_kib": res, "forwards": forwards,
-      "note": "FETCH_SIZE/WRITE_SIZE (KiB) summed over all dispatches of bench.py --steps 2 --warmup 1, / 3 forwards; "
+      "note": "FETCH_SIZE/WRITE_SIZE (KiB) summed over all dispatches of bench.py --steps 2 --warmup 1, / 4 forwards; "
               "read side doubled per the gfx950 calibration in MI355X_MICROARCH.md",
       "top_fetch_kernels_kib": per_kernel["FETCH_SIZE"], "top_write_kernels_kib": per_kernel["WRITE_SIZE"]}
 json.dump(js, open(out + "/traffic.json", "w"), indent=1)
