@@ -215,9 +215,27 @@ def test_mdcn_e2fgvi_fused(dev):
     ref = modulated_deform_conv2d(torch.cat([a, c], 1), torch.cat([q1, q2], 1), torch.sigmoid(m), w, b, 1, 1, 1, 1, dg)
     layer = ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)
     flows = nhwc(torch.cat([f1, f2], 1)).to(dev)
-    for tile in (1, 2):
+    for tile in (0, 1, 2, 4, 5, 6):          # incl. the K-group (split-K) tiles the 60x108 propagation uses
         out = layer([nhwc(a).to(dev), nhwc(c).to(dev)], nhwc(raw).to(dev), flows=flows, max_residue=10.0, tile=tile)
         assert_close(nchw(out.cpu()), ref, 5e-5, "mdcn fused tile %d" % tile)
+    # the engine's form: offsets / masks already post-processed (ACT_DCNPOST epilogue of conv_offset.6), no flows
+    final = torch.cat([q1, q2, torch.sigmoid(m)], 1)
+    for tile in (0, 5):
+        out = layer([nhwc(a).to(dev), nhwc(c).to(dev)], nhwc(final).to(dev), tile=tile)
+        assert_close(nchw(out.cpu()), ref, 5e-5, "mdcn finished offsets tile %d" % tile)
+
+
+def test_mdcn_argument_errors(dev):
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.lib import HipError
+    layer = ops.PackedDcn(torch.randn(32, 32, 3, 3, device=dev), None, 2, pad=1)
+    x = torch.randn(1, 8, 8, 32, device=dev)
+    with pytest.raises(HipError):                                      # odd offset row stride (dy, dx are one 8-byte load)
+        layer([x], torch.randn(1, 8, 8, 55, device=dev))
+    with pytest.raises(ValueError):
+        layer([x], torch.randn(1, 8, 8, 20, device=dev))               # fused tensor narrower than dg * 3 * K
+    with pytest.raises(ValueError):
+        layer([torch.randn(1, 8, 8, 16, device=dev)], torch.randn(1, 8, 8, 54, device=dev))
 
 
 @pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 2, 15, 45)])
