@@ -54,3 +54,54 @@ def test_uneven_batch_is_rejected():
     from e2fgvi_amd.runner import inpaint_sharded
     with pytest.raises(ValueError):
         inpaint_sharded(_fake_net, torch.zeros(3, 2, 3, 4, 4), 2, 0, 2)
+
+
+class _StepNet:
+    """stand-in whose output depends on the rank and on how often it was called (so that steps are distinguishable)"""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, 0
+
+    def __call__(self, x, lt):
+        self.calls += 1
+        b, t, c, H, W = x.shape
+        return torch.full((b * t, c, H, W), 100.0 * self.rank + self.calls), None
+
+
+def _step_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from e2fgvi_amd.runner import ShardedStep
+    step = ShardedStep(_StepNet(rank), torch.zeros(1, 2, 3, 4, 4), 2, group_world=world, use_graph=False)
+    got = []
+    for _ in range(3):
+        r = step.run()                       # gathered frames of the PREVIOUS step (pipelined), None at first
+        got.append(None if r is None else r.clone())
+    last = step.finish().clone()
+    ok = got[0] is None
+    for k, g in ((1, got[1]), (2, got[2]), (3, last)):
+        # step k: rank 0 contributed the value k, rank 1 the value 100 + k; rank-major order
+        ok = ok and tuple(g.shape) == (world * 2, 3, 4, 4) and bool((g[:2] == float(k)).all()) and bool((g[2:] == 100.0 + k).all())
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_pipelined_step():
+    """ShardedStep: the all-gather of step k is returned by run() of step k+1 / finish(), in rank-major order"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, True), (1, True)]
