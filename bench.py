@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: inpainted frames/sec at 432x240, T=10 (BASELINE.json), fp32, on N MI355X.
 
-One "step" = one InpaintGenerator forward over this rank's batch of synthetic 432x240 T=10 clips
-(all frames local, l_t = t: the configuration that maximises propagation work), inputs
-already resident in HBM.  With N > 1 the clips are sharded over ranks (one process per GPU, RCCL) and
-every step ends with the all-gather of the output frames over xGMI; per-GPU work is fixed (weak
-scaling).  Prints ONE JSON line on rank 0.
+One "step" = one InpaintGenerator forward over this rank's batch of synthetic clips (all frames local, l_t = t: the
+configuration that maximises propagation work), inputs already resident in HBM.
+
+    N = 1 (default)  BASELINE.json configs[1]: e2fgvi 432x240 T=10, ONE clip per forward, fp32.
+    N > 1 (default)  BASELINE.json configs[2]: the same clip, 8 clips per GPU per forward (64 at N=8), clips sharded
+                     over ranks (one process per GPU), every step ends with the RCCL all-gather of the output frames
+                     (uint8, the form test.py saves) over xGMI; per-GPU work is fixed (weak scaling).  Note for anyone
+                     computing a scaling efficiency: the like-for-like single-GPU number of config 3 is
+                     `--gpus 1 --clips-per-gpu 8`, not the 1-clip default of N = 1.
+    --model e2fgvi_hq --hw 720x1296 --precision bf16      BASELINE.json configs[3] (and [4] with --hw 1080x1944 --t 20)
+
+Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 20 --warmup 3
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -23,48 +31,71 @@ if ROOT not in sys.path:
 
 import torch
 
-GFLOP_PER_CLIP = {  # algorithmic conv/linear/matmul work, 2 x MAC, e2fgvi 432x240
-    (10, 10): 2039.1, (5, 5): 932.5, (10, 5): 1718.8,
-}
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+PEAK_TFLOPS = {"fp32": 157.3,     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz (= the fp32 vector peak)
+               "bf16": 2500.0}    # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); AMD's 5 PF figure includes 2:1 sparsity
 
 
-def flops_per_clip(t, lt):
-    """analytic GFLOP (2 x MAC) per clip of the base model at 432x240 (formulas of SURVEY.md 8d)."""
-    if (t, lt) in GFLOP_PER_CLIP:
-        return GFLOP_PER_CLIP[(t, lt)]
-    H, W = 240, 432
-    p4, p2, n = (H // 4) * (W // 4), (H // 2) * (W // 2), 720
+def flops_per_clip(H, W, t, lt, hq):
+    """analytic GFLOP (2 x MAC of conv / linear / matmul) per clip, formulas of SURVEY.md 8(d)"""
+    p4, p2 = (H // 4) * (W // 4), (H // 2) * (W // 2)
+    fh, fw = (H // 4 + 6 - 7) // 3 + 1, (W // 4 + 6 - 7) // 3 + 1
+    n = fh * fw
     nw = n // 45
+    hu, wu = -(-(H // 4) // 32) * 32, -(-(W // 4) // 32) * 32
     enc = t * (p2 * (64 * 27 + 64 * 576) + p4 * (128 * 576 + 256 * 1152 + 384 * 2304 + 512 * 2880 + 384 * 1728 + 256 * 720 + 128 * 4608))
-    spy = 2 * (lt - 1) * 239904 * sum(64 * 128 // 4 ** l for l in range(6))
+    spy = 2 * (lt - 1) * 239904 * sum(hu * wu // 4 ** l for l in range(6))
     off = 2 * (lt - 1) * p4 * 9 * (388 * 128 + 2 * 128 * 128 + 128 * 432)
     dcn = 2 * (lt - 1) * p4 * 128 * 2304
     bb = lt * p4 * 9 * (256 * 128 + 384 * 128 + 2 * 128 * 128)
     fus = lt * p4 * 128 * 256
-    ss = 2 * t * n * 6272 * 512
+    ss = 2 * t * n * 6272 * 512 + (t * p4 * 128 * 1152 if hq else 0)
     blk = 8 * (t * n * 512 * 2048 + nw * t * (512 * 1536 + 45 * 512) + nw * 4 * (45 * t) * (210 * t) * 128 * 2 + t * n * 512 * 1960 * 2)
     dec = t * (p2 * 9 * (128 * 128 + 128 * 64) + 4 * p2 * 9 * (64 * 64 + 64 * 3))
     return 2e-9 * (enc + spy + off + dcn + bb + fus + ss + blk + dec)
 
 
-def cpu_baseline(sd, t, lt):
-    """The CPU restatement of the reference forward (oracle/e2fgvi_oracle.py, kind "port": the reference's own
-    Python cannot travel to the GPU box) timed on this host's cores on a bounded sample of the same workload."""
+def traced_work(net, x, lt):
+    """One eager forward with launch tracing on: sums of the algorithmic MACs (what the reference's layers compute) and of
+    the MACs actually ISSUED to the matrix pipe (Winograd layers issue 16/36 of theirs, x block / channel padding) over
+    every conv / linear / deformable-conv / attention launch."""
+    from e2fgvi_amd import lib
+    lib.TRACE = []
+    try:
+        net(x, lt)
+        torch.cuda.synchronize()
+        rows = [r["meta"] for r in lib.TRACE if r["meta"] and "macs" in r["meta"]]
+    finally:
+        lib.TRACE = None
+    return 2e-9 * sum(r["macs"] for r in rows), 2e-9 * sum(r["issued"] for r in rows), len(rows)
+
+
+def cpu_baseline(sd, model, H, W, t, lt):
+    """The CPU restatement of the reference forward (oracle/e2fgvi_oracle.py, kind "port": the reference's own Python
+    cannot travel to the GPU box) timed on this host's cores on a bounded sample of the same workload: ONE clip,
+    1 warm-up + median of 3 forwards for the 432x240 workload; the HQ resolutions take minutes per
+    clip on a CPU, there the sample is one un-warmed forward of a 2-frame clip of the same resolution."""
     from e2fgvi_amd.synth import synth_clip
     from oracle import e2fgvi_oracle as O
-    # Bounded sample: ONE clip of the same workload (about 10-15 s), on at most 16 threads -- torch's intra-op
-    # pool stops scaling on these small ops (with the box's 256 hardware threads it collapses to minutes).
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    host = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling on these small ops (with the GPU box's 256 hardware threads it collapses to
+    # minutes per forward): 16 threads is the fastest setting measured there
+    cores = max(1, min(host, 16))
     torch.set_num_threads(cores)
-    ts, ls = t, lt
-    x, _ = synth_clip(1, ts, 240, 432, seed=100)
-    t0 = time.perf_counter()
-    O.forward(sd, x, ls, "e2fgvi")
-    dt = time.perf_counter() - t0
-    return {"value": round(ts / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "one forward of one 432x240 T=%d l_t=%d clip (%.1f s, torch CPU fp32, %d threads, no warm-up); "
-                      "frames/s = %d frames / that time" % (ts, ls, dt, cores, ts)}
+    small = (H, W) == (240, 432)
+    ts, ls = (t, lt) if small else (2, 2)
+    x, _ = synth_clip(1, ts, H, W, seed=0, smooth=False)
+    times = []
+    for k in range(4 if small else 1):
+        t0 = time.perf_counter()
+        O.forward(sd, x, ls, model)
+        times.append(time.perf_counter() - t0)
+    timed = times[1:] if small else times
+    dt = statistics.median(timed)
+    return {"value": round(ts / dt, 4), "unit": "frames/s", "cores": cores, "host_cores": host, "kind": "port",
+            "sample": "one %s %dx%d T=%d l_t=%d clip, torch CPU fp32 on %d threads (host has %d): %s; frames/s = %d frames / "
+                      "that time" % (model, W, H, ts, ls, cores, host,
+                                     "1 warm-up + median of 3 forwards (%.1f s each)" % dt if small else
+                                     "one un-warmed forward (%.1f s)" % dt, ts)}
 
 
 def main():
@@ -72,9 +103,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips-per-gpu", type=int, default=1, help="clips per forward on each GPU (reference inference: 1)")
+    ap.add_argument("--clips-per-gpu", type=int, default=0,
+                    help="clips per forward on each GPU; default 1 at N=1 (BASELINE config 2), 8 at N>1 (config 3)")
+    ap.add_argument("--model", default="e2fgvi", choices=("e2fgvi", "e2fgvi_hq"))
+    ap.add_argument("--hw", default="240x432", help="HxW of the (already padded) clip; the base model is fixed to 240x432")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"))
     ap.add_argument("--t", type=int, default=10)
-    ap.add_argument("--lt", type=int, default=10)
+    ap.add_argument("--lt", type=int, default=0, help="local frames (default: all t)")
+    ap.add_argument("--gather", default="u8", choices=("u8", "f32"), help="dtype of the frames in the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (self-test)")
@@ -93,17 +129,26 @@ def main():
     from e2fgvi_amd import runner
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
 
-    b, t, lt = args.clips_per_gpu, args.t, args.lt
-    sd = synth_state_dict("e2fgvi", "default", 0)          # random-init distribution of the reference
-    net = importlib.import_module("model.e2fgvi").InpaintGenerator()
+    H, W = [int(v) for v in args.hw.lower().split("x")]
+    if H > W:                                            # tolerate WxH
+        H, W = W, H
+    t = args.t
+    lt = args.lt or t
+    b = args.clips_per_gpu or (1 if world == 1 else 8)
+    hq = args.model == "e2fgvi_hq"
+    sd = synth_state_dict(args.model, "default", 0)        # random-init distribution of the reference
+    net = importlib.import_module("model." + args.model).InpaintGenerator()
     net.load_state_dict(sd)
     net = net.to(dev).eval()
-    x, _ = synth_clip(b, t, 240, 432, seed=100 + rank)
+    net.precision = args.precision
+    # frames = torch.rand(b,t,3,H,W, generator=seed) * 2 - 1, box mask [H/4:H/2, W/4:W/2]
+    x, _ = synth_clip(b, t, H, W, seed=rank, smooth=False)
     x = x.to(dev)
     # Build the engine (weight re-layout, tile tuning, stream creation) BEFORE RCCL comes up: measured on MI355X, a
-    # forward whose engine was built after init_process_group runs ~4 % slower (17.8 vs 17.15 ms; tools note in DESIGN.md)
+    # forward whose engine was built after init_process_group runs ~4 % slower (17.8 vs 17.15 ms)
     net(x, lt)
     torch.cuda.synchronize()
+    gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)      # per forward of b clips
 
     dist = None
     if world > 1 or args.force_dist:
@@ -119,10 +164,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    # HIP-graph replay only for the single-process run: with RCCL's watchdog thread alive, stream capture is an
-    # avoidable risk, and the forward is device-bound anyway (eager = graph within 1 %)
-    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=(not args.no_graph) and dist is None,
-                              force_gather=args.force_dist)
+    # the forward replays from a HIP graph in every mode; the collective stays outside the graph (runner.ShardedStep)
+    step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=not args.no_graph, force_gather=args.force_dist,
+                              pack_u8=(dist is not None and args.gather == "u8"))
     for _ in range(args.warmup):
         step.run()
     step.finish()
@@ -151,45 +195,68 @@ def main():
     frames = world * b * t * args.steps
     value = frames / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
-    gflop_clip = flops_per_clip(t, lt)
-    achieved = (b * gflop_clip * args.steps / (dev_ms * 1e-3)) / 1e3        # TFLOP/s of this rank, device-timed
+    peak = PEAK_TFLOPS[args.precision]
+    analytic = b * flops_per_clip(H, W, t, lt, hq)
+    secs = dev_ms * 1e-3 / args.steps
+    tf_alg, tf_iss = gflop_alg / secs / 1e3, gflop_issued / secs / 1e3          # this rank, device-timed
+    config_no = 2 if (world == 1 and b == 1) else 3
+    if hq:
+        config_no = 4 if t <= 10 else 5
     out = {
-        "metric": "inpainted frames/sec at 432x240 T=%d" % t, "value": round(value, 3), "unit": "frames/s",
+        "metric": "inpainted frames/sec at %dx%d T=%d" % (W, H, t), "value": round(value, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "e2fgvi 432x240 T=%d l_t=%d, %d clip(s) per GPU per forward, random-init weights, box mask"
-                               % (t, lt, b), "clips_per_gpu": b, "parallelism": "clip-shard x%d + all-gather of frames" % world,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[%d]: %s %dx%d T=%d l_t=%d, %d clip(s) per GPU per forward (%d in the job), "
+                               "random-init weights, torch.rand frames + box mask (SURVEY.md 8d)"
+                               % (config_no - 1, args.model, W, H, t, lt, b, b * world),
+                   "clips_per_gpu": b, "precision": args.precision,
+                   "parallelism": "clip-shard x%d + all-gather of the %s frames" % (world, args.gather) if dist is not None
+                                  else "single GPU, no collective",
                    "hip_graph": bool(step.graphed)},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                     "note": "whole forward: %.1f algorithmic GFLOP per clip (SURVEY.md 8d) / device time of one forward "
-                             "(hip events on the launch stream)" % gflop_clip},
+        "roofline": {"bound": "mfma", "achieved": round(tf_iss, 3), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(tf_iss / peak, 4),
+                     "achieved_algorithmic": round(tf_alg, 3), "frac_algorithmic": round(tf_alg / peak, 4),
+                     "gflop_per_forward": {"algorithmic": round(gflop_alg, 1), "issued": round(gflop_issued, 1),
+                                           "analytic_survey_8d": round(analytic, 1), "mfma_launches": nlaunch},
+                     "traffic": None,
+                     "note": "whole forward, device time of one forward (hip events on the launch stream). `achieved` / `frac` count "
+                             "the FLOPs ISSUED to the matrix pipe (the Winograd F(2x2,3x3) layers issue 16/36 of their direct-"
+                             "convolution multiplies, plus block / channel padding: per-launch accounting of ops.PackedConv._work); "
+                             "`*_algorithmic` count the reference's direct-convolution FLOPs (SURVEY.md 8d) and can exceed the "
+                             "peak on Winograd layers"},
     }
     # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the
     # summary of the last collection is committed under profiles/ and quoted here (bytes per forward of one clip)
-    tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tfile) and b == 1 and (t, lt) == (10, 10):
-        try:
-            tj = json.load(open(tfile))
-            out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
-            out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, "
-                                               "separate passes (profiles/r01_hbm_traffic.json); fabric-side, includes "
-                                               "Infinity-Cache hits; algorithmic minimum is 0.19 GB/clip")
-        except Exception:
-            pass
+    if b == 1 and (t, lt) == (10, 10) and not hq and args.precision == "fp32":
+        for tag in ("r02", "r01"):
+            tfile = os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
+                    out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, "
+                                                       "separate passes (profiles/%s_hbm_traffic.json); fabric-side, includes "
+                                                       "Infinity-Cache hits; algorithmic minimum is 0.19 GB/clip" % tag)
+                    break
+                except Exception:
+                    pass
     if rank == 0:
-        dom = runner.dominant_kernel_probe(net, dev)
-        dfile = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        dom["traffic"] = None
-        if os.path.exists(dfile):
-            try:
-                dom["traffic"] = round(json.load(open(dfile))["hbm_bytes_per_launch"])
-                dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_dominant_kernel_traffic.json)"
-            except Exception:
-                pass
-        out["roofline"]["dominant_kernel"] = dom
+        if not hq and args.precision == "fp32":
+            dom = runner.dominant_kernel_probe(net, dev)
+            dom["traffic"] = None
+            for tag in ("r02", "r01"):
+                dfile = os.path.join(ROOT, "profiles", "%s_dominant_kernel_traffic.json" % tag)
+                if os.path.exists(dfile):
+                    try:
+                        dom["traffic"] = round(json.load(open(dfile))["hbm_bytes_per_launch"])
+                        dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s_dominant_kernel_traffic.json)" % tag
+                        break
+                    except Exception:
+                        pass
+            out["roofline"]["dominant_kernel"] = dom
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, t, lt)
+            out["cpu_baseline"] = cpu_baseline(sd, args.model, H, W, t, lt)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -166,6 +166,25 @@ class Engine:
         self.half = torch.full((4,), 0.5, device=self.device)
         self._tables = {}
         self._zeros = {}
+        # checkpoint names on the layers (launch traces: tools/layer_table.py, bench.py's FLOP accounting)
+        for k, i in enumerate((0, 2, 4, 6, 8, 10, 12, 14, 16)):
+            self.enc[k].name = "encoder.layers.%d" % i
+        for k, n in enumerate(("decoder.0.conv", "decoder.2", "decoder.4.conv", "decoder.6")):
+            self.dec[k].name = n
+        for d, (off, dcn, bb) in self.prop.items():
+            for k, c in enumerate(off):
+                c.name = "deform_align.%sconv_offset.%d" % (d, 2 * k)
+            dcn.name = "deform_align.%sdcn" % d
+            bb[0].name, bb[1].name = "backbone.%s0" % d, "backbone.%s2" % d
+        self.fusion.name, self.ss.name, self.sc.name = "fusion", "ss.embedding", "sc.embedding"
+        if self.hq:
+            self.sc_bias_conv.name = "sc.bias_conv"
+        for i, blk in enumerate(self.blocks):
+            for k in ("qkv", "proj", "fc1", "fc2"):
+                blk[k].name = "transformer.%d.%s" % (i, k)
+        for lv, convs in enumerate(self.spy):
+            for j, c in enumerate(convs):
+                c.name = "spynet.%d.%d" % (lv, j)
         if autotune and precision == "fp32" and os.environ.get("E2FGVI_AUTOTUNE", "1") != "0":
             # GEMM-shaped layers (token Linears, soft split / composite): the best implicit-GEMM tile depends on the
             # token count; time the candidates on the first call of each size (eager warm-up, never under graph capture)
@@ -359,10 +378,15 @@ class Engine:
                              "multiple of 108 (reference test.py:156-165)" % (fh, fw))
         if not self.hq and (h, w) != (60, 108):
             raise ValueError("model 'e2fgvi' is fixed to 432x240 inputs (sc.bias is [128,60,108]); use e2fgvi_hq")
-        if not (2 <= l_t <= t):
-            raise ValueError("num_local_frames must be in [2, t]")
+        if not (1 <= l_t <= t):
+            raise ValueError("num_local_frames must be in [1, t]")
         frames = ops._chk(frames.float().contiguous(), "masked_frames")
-        if self.overlap_flows:
+        if l_t == 1:
+            # a one-frame local window (test.py on a 1-frame video): the reference's flow tensors are empty
+            # [b,0,2,h,w] and each propagation direction is backbone(cat(x, 0)) (feat_prop.py:105,131-137)
+            fwd = bwd = torch.empty((b, 0, h, w, 2), dtype=torch.float32, device=frames.device)
+            enc = self.encode(frames)
+        elif self.overlap_flows:
             # SPyNet (many short, small-channel launches) and the encoder (few large launches) are independent:
             # run them on two HIP streams so the flow pyramid fills the gaps of the encoder (fork/join is
             # captured as two branches when the forward is recorded into a HIP graph)
@@ -402,6 +426,9 @@ class Engine:
         if trace is not None:
             trace["dec_in"] = dec_in
         out = self.decode(dec_in)
+        if l_t == 1:
+            empty = torch.empty((b, 0, 2, h, w), dtype=torch.float32, device=out.device)
+            return out, (empty, empty.clone())
         flows_out = (ops.nhwc_to_nchw(fwd.reshape(b * (l_t - 1), h, w, 2)).view(b, l_t - 1, 2, h, w),
                      ops.nhwc_to_nchw(bwd.reshape(b * (l_t - 1), h, w, 2)).view(b, l_t - 1, 2, h, w))
         return out, flows_out

@@ -160,37 +160,93 @@ class _InpaintGeneratorBase(nn.Module):
         self.ss = SoftSplit()
         self.sc = SoftComp(hq)
         self.transformer = nn.Sequential(*[TemporalFocalTransformerBlock() for _ in range(8)])
-        if init_weights:
-            self.init_weights()
-        self.update_spynet = SPyNet()        # built after init_weights, like the reference (e2fgvi.py:208)
         self._engine = None
         self._engine_key = None
+        if init_weights:
+            self.init_weights()
+            for m in self.modules():         # e2fgvi.py:202-205
+                if isinstance(m, SecondOrderDeformableAlignment):
+                    m.init_offset()
+        self.update_spynet = SPyNet()        # built after init_weights, like the reference (e2fgvi.py:208)
         # "fp32" (default, the parity configuration) or "bf16" (optional bf16-MFMA mode for the HQ configurations)
         self.precision = "fp32"
 
     def init_weights(self, init_type="normal", gain=0.02):
-        """Distribution of the reference's BaseNetwork.init_weights (e2fgvi.py:29-68) followed by
-        init_offset (e2fgvi.py:203-205): Conv*/Linear* weights N(0, gain), biases 0; the deformable conv's
-        main weight keeps its uniform init; conv_offset[-1] is zero."""
-        if init_type != "normal":
-            raise NotImplementedError("only the reference default init ('normal') is provided")
+        """The reference's BaseNetwork.init_weights (e2fgvi.py:29-68): every Conv*/Linear* weight is re-drawn with
+        ``init_type`` in normal | xavier | xavier_uniform | kaiming | orthogonal | none and its bias zeroed; the
+        deformable conv's main weight is not touched (the reference matches on class names containing 'Conv' /
+        'Linear', SecondOrderDeformableAlignment has neither).  The constructor then re-applies init_offset
+        (e2fgvi.py:200-205): conv_offset[-1] is zero."""
         for m in self.modules():
-            if isinstance(m, (nn.Conv2d, nn.Linear)):
+            if not isinstance(m, (nn.Conv2d, nn.Linear)):
+                continue
+            if init_type == "normal":
                 nn.init.normal_(m.weight.data, 0.0, gain)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias.data, 0.0)
-        for m in self.modules():
-            if isinstance(m, SecondOrderDeformableAlignment):
-                m.init_offset()
+            elif init_type == "xavier":
+                nn.init.xavier_normal_(m.weight.data, gain=gain)
+            elif init_type == "xavier_uniform":
+                nn.init.xavier_uniform_(m.weight.data, gain=1.0)
+            elif init_type == "kaiming":
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+            elif init_type == "orthogonal":
+                nn.init.orthogonal_(m.weight.data, gain=gain)
+            elif init_type == "none":
+                m.reset_parameters()
+            else:
+                raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+            if m.bias is not None:
+                nn.init.constant_(m.bias.data, 0.0)
+        self.refresh_engine()
 
     def print_network(self):
         n = sum(p.numel() for p in self.parameters())
         print("Network [%s] was created. Total number of parameters: %.1f million." % (type(self).__name__, n / 1e6))
 
     # -- engine cache -------------------------------------------------------------------------
+    # The engine holds re-laid-out COPIES of the weights.  It is dropped whenever this module's parameters can have
+    # changed through the nn.Module API (load_state_dict, .to()/.half()/.cuda() -> _apply, init_weights) and whenever
+    # the fingerprint below moves (optimizer-style in-place updates bump Parameter._version; `.data` swaps change a
+    # data_ptr).  Writes through `p.data.copy_()` are invisible to both: call refresh_engine() after such edits.
+    def refresh_engine(self):
+        """Drop the cached device plan; the next forward re-reads every parameter."""
+        self._engine = None
+        self._engine_key = None
+
+    def _apply(self, fn, *a, **k):
+        self.refresh_engine()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **k):
+        self.refresh_engine()
+        return super().load_state_dict(state_dict, strict=strict, **k)
+
+    def load_checkpoint(self, path, map_location=None, strict=True):
+        """Load a checkpoint FILE in any of the layouts the reference ecosystem writes: a bare generator state_dict
+        (release_model/E2FGVI-CVPR22.pth, E2FGVI-HQ-CVPR22.pth -- test.py:119-120 does torch.load + load_state_dict),
+        the trainer's gen_*.pth (also bare, core/trainer.py:240), a ``{'state_dict': ...}`` wrapper (mmcv style -- the
+        SPyNet file flow_comp.py:59-72 downloads), and keys carrying a DataParallel / DDP ``module.`` prefix.  A
+        SPyNet-only file (keys ``basic_module.*``) is loaded into ``update_spynet``."""
+        sd = torch.load(path, map_location=map_location or "cpu")
+        if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+            sd = sd["state_dict"]
+        if not isinstance(sd, dict) or not sd:
+            raise ValueError("%s does not contain a state_dict" % path)
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        if all(k.startswith(("basic_module.", "mean", "std")) for k in sd):
+            self.refresh_engine()
+            return self.update_spynet.load_state_dict(sd, strict=strict)
+        return self.load_state_dict(sd, strict=strict)
+
+    def train(self, mode=True):
+        if mode:
+            raise RuntimeError("this InpaintGenerator is the MI355X INFERENCE forward (SURVEY.md 8): the parameter "
+                               "containers have no autograd path; train with the reference implementation and load the "
+                               "checkpoint here (load_state_dict / load_checkpoint)")
+        return super().train(False)
+
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
-        return (str(ps[0].device), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:8]), self.precision)
+        return (str(ps[0].device), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps), self.precision)
 
     def engine(self):
         from .engine import Engine
@@ -231,3 +287,18 @@ class InpaintGenerator(_InpaintGeneratorBase):
 class InpaintGeneratorHQ(_InpaintGeneratorBase):
     """Arbitrary-resolution model (reference model/e2fgvi_hq.py:134)."""
     MODEL = "e2fgvi_hq"
+
+
+# ----------------------------------------------------------------------------- training-side names (stubs)
+class Discriminator(nn.Module):
+    """The reference's T-PatchGAN discriminator (model/e2fgvi.py:271-344) belongs to training (core/trainer.py),
+    which is out of scope of this inference implementation."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("model.e2fgvi.Discriminator is training-only; this package implements the MI355X "
+                                  "inference forward (InpaintGenerator).  Train with the reference implementation.")
+
+
+def spectral_norm(module, mode=True):
+    """model/e2fgvi.py:347-350 -- only the discriminator uses it (training-only, see Discriminator)."""
+    raise NotImplementedError("spectral_norm is training-only; see Discriminator")

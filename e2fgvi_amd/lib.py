@@ -81,6 +81,36 @@ SYMBOLS = {
 
 _lib = None
 
+# Launch tracing (tools/layer_table.py, bench.py's FLOP accounting): while TRACE is a list, every C-ABI call that takes a
+# stream is bracketed by two events on the current stream and recorded together with the metadata the operator layer
+# announced for it (layer name, shape, algorithmic / issued MACs).  None = off: one attribute test per call.
+TRACE = None
+NEXT_META = None
+
+
+def annotate(**meta):
+    """metadata for the next traced launch (ignored when tracing is off)"""
+    global NEXT_META
+    if TRACE is not None:
+        NEXT_META = meta
+
+
+def _traced(name, fn):
+    def call(*args):
+        global NEXT_META
+        if TRACE is None:
+            return fn(*args)
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        TRACE.append({"symbol": name, "e0": e0, "e1": e1, "meta": NEXT_META})
+        NEXT_META = None
+        return rc
+    call.__name__ = name
+    return call
+
 
 class HipLibraryMissing(ImportError):
     pass
@@ -100,6 +130,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+        if args and args[-1] is _fp and res is C.c_int:      # asynchronous launch on a stream
+            setattr(lib, name, _traced(name, fn))
     _lib = lib
     return lib
 

@@ -1,8 +1,15 @@
-"""MI355X stand-ins for the two mmcv symbols the reference imports (model/modules/feat_prop.py:7):
-``modulated_deform_conv2d`` and ``ModulatedDeformConv2d``, same signatures / argument meaning as
-mmcv-full 1.4.8, NCHW torch tensors in and out, computed by the HIP kernel behind
-``e2fgvi_mdcn_nhwc`` (include/e2fgvi_hip.h).  Inference only."""
+"""MI355X stand-ins for every mmcv symbol the reference imports -- the inner operator boundary of SURVEY.md 8(b):
+
+    mmcv.ops.modulated_deform_conv2d / ModulatedDeformConv2d     model/modules/feat_prop.py:7,13,55-58
+    mmcv.cnn.ConvModule                                          model/modules/flow_comp.py:7,181-215
+    mmcv.cnn.constant_init                                       model/modules/feat_prop.py:8,33
+    mmcv.runner.load_checkpoint                                  model/modules/flow_comp.py:8,72
+
+Same signatures / argument meaning as mmcv-full 1.4.8, NCHW torch tensors in and out; the arithmetic runs in the HIP
+kernels behind ``e2fgvi_mdcn_nhwc`` / ``e2fgvi_conv2d_nhwc`` (include/e2fgvi_hip.h).  With these, INTEGRATION.md's
+"keep the reference's Python, replace only mmcv" route needs nothing from ``oracle/``.  Inference only."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -58,3 +65,70 @@ class ModulatedDeformConv2d(nn.Module):
     def forward(self, x, offset, mask):
         return modulated_deform_conv2d(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
                                        self.dilation, self.groups, self.deform_groups)
+
+
+# ----------------------------------------------------------------------------- mmcv.cnn / mmcv.runner
+def constant_init(module, val, bias=0):
+    """mmcv.cnn.constant_init (used at feat_prop.py:33 to zero conv_offset[-1])."""
+    if getattr(module, "weight", None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+class ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule as SPyNet uses it (flow_comp.py:181-215): ``conv`` (nn.Conv2d parameters, mmcv's default
+    kaiming-normal fan_out init, zero bias) + optional ``activate`` (ReLU); child names matter for the checkpoint keys
+    ``...basic_module.N.conv.weight``.  forward runs the HIP implicit-GEMM / halo conv kernel with the ReLU fused."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias="auto",
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), inplace=True, **kwargs):
+        super().__init__()
+        if norm_cfg is not None or conv_cfg is not None or dilation != 1 or kwargs:
+            raise NotImplementedError("ConvModule stand-in: only conv (+ReLU), as the reference uses it")
+        if act_cfg is not None and act_cfg.get("type") != "ReLU":
+            raise NotImplementedError("ConvModule stand-in: act_cfg must be None or ReLU")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, groups=groups,
+                              bias=(bias is True or bias == "auto"))
+        self.with_activation = act_cfg is not None
+        if self.with_activation:
+            self.activate = nn.ReLU(inplace=inplace)
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode="fan_out", nonlinearity="relu")
+        if self.conv.bias is not None:
+            nn.init.constant_(self.conv.bias, 0)
+        self._packed = None
+
+    def forward(self, x):
+        c = self.conv
+        key = (c.weight.data_ptr(), c.weight._version, None if c.bias is None else (c.bias.data_ptr(), c.bias._version))
+        if self._packed is None or self._packed[0] != key:
+            cin_g = c.in_channels // c.groups
+            pad_c = (-cin_g) % 4                                  # NHWC sources are addressed in 16-byte units
+            if pad_c and c.groups != 1:
+                raise NotImplementedError("ConvModule stand-in: grouped conv needs in_channels/groups % 4 == 0")
+            w = c.weight.detach().float()
+            if pad_c:
+                w = torch.cat([w, w.new_zeros(w.shape[0], pad_c, *w.shape[2:])], 1)
+            layer = ops.PackedConv(w.contiguous(), None if c.bias is None else c.bias.detach().float(), [cin_g + pad_c],
+                                   groups=c.groups, stride=_one(c.stride), pad=_one(c.padding))
+            self._packed = (key, layer, cin_g + pad_c if c.groups == 1 else c.in_channels)
+        _, layer, ld = self._packed
+        with torch.no_grad():
+            xh = ops.nchw_to_nhwc(x.float().contiguous(), ld=ld)
+            y = layer([xh], act=ops.ACT_RELU if self.with_activation else ops.ACT_NONE)
+            return ops.nhwc_to_nchw(y)
+
+
+def load_checkpoint(model, filename, map_location="cpu", strict=False, logger=None):
+    """mmcv.runner.load_checkpoint for LOCAL files.  flow_comp.py:59-72 passes the download URL of the pretrained
+    SPyNet by default; without network access a URL (or a missing file) is skipped with a message instead of
+    failing -- SPyNet's weights then come with the generator checkpoint (``update_spynet.*`` keys)."""
+    if isinstance(filename, str) and os.path.isfile(filename):
+        sd = torch.load(filename, map_location=map_location)
+        if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):
+            sd = sd["state_dict"]
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        model.load_state_dict(sd, strict=strict)
+        return sd
+    print("load_checkpoint: %r is not a local file -- skipped (no network access)" % (filename,))
+    return None

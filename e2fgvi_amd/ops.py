@@ -6,6 +6,7 @@ hand-written HIP kernels behind the C ABI (include/e2fgvi_hip.h).  Activations a
 and raises on error -- there is no eager fallback.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -68,6 +69,7 @@ class PackedConv:
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
         self.tune = False          # time TUNE_CANDIDATES on the first call of every new input size and keep the fastest
+        self.name = "conv"         # layer name for launch traces (the engine sets the checkpoint key)
         if algo not in ("igemm", "winograd", "auto"):
             raise ValueError("algo must be 'igemm', 'winograd' or 'auto'")
         wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 4 for c in self.cpg)
@@ -143,6 +145,30 @@ class PackedConv:
     def out_hw(self, H, W):
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
 
+    def _work(self, N, H, W, Ho, Wo, use_wino, tile):
+        """Launch-trace record: algorithmic MACs (direct convolution) and the MACs the matrix pipe is ISSUED.
+        Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs and input channel instead of 36, on pixel blocks of 16x16 /
+        8x16 and 32 / 64-wide cout tiles (the tile rule of e2fgvi_conv3x3_winograd), input channels in chunks of 8.
+        Implicit GEMM: output channels padded to 32, every source's channels to the K granule."""
+        cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
+        macs = N * Ho * Wo * self.Cout * cin_g * K2
+        if use_wino:
+            if not tile:
+                big = N * -(-H // 16) * -(-W // 16) * -(-cout_g // 64) * self.groups
+                tile = 64 if (cout_g >= 256 and big >= 128) else 132
+            mt, bn = (2, tile) if tile < 100 else (1, tile - 100)
+            pix = N * (-(-H // (8 * mt)) * 8 * mt) * (-(-W // 16) * 16)
+            cin_p = sum(-(-c // 8) * 8 for c in self.cpg)
+            issued = pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * 4       # 16 positions per 4 pixels
+            kern = "conv_wino<%d,%d>" % (mt, bn)
+        else:
+            g = 32 if self.precision == "bf16" else self.bk
+            cin_p = sum(-(-c // g) * g for c in self.cpg)
+            issued = N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2
+            kern = "conv_igemm_bf16" if self.precision == "bf16" else "conv_igemm/halo tile=%d" % tile
+        return dict(layer=self.name, kernel=kern, shape="N%d %dx%d %d->%d k%d s%d g%d" % (
+            N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups), macs=macs, issued=issued)
+
     def __call__(self, sources, out=None, out_coff=0, residual=None, res_coff=0, act=ACT_NONE, slope=0.0,
                  out_nchw=False, tile=0):
         """sources: list of NHWC tensors or (tensor, channel_offset) pairs, one per cpg entry."""
@@ -205,13 +231,17 @@ class PackedConv:
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
         if tile == 0 and self.tune and not use_wino and self.precision == "fp32" and N * Ho * Wo >= 2048:
-            key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk, N, H, W,
-                   residual is not None, act)
+            # one decision per (layer geometry, size class): row counts within a quarter octave share the tile, so the
+            # slightly different window lengths of a video (t = 17 ... 21 frames) do not each pay for a tuning pass
+            key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk,
+                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act)
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
                 best = _TUNED[key] = self._autotune(lib, d)
             d.tile = best or 0
+        if _L.TRACE is not None:
+            _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile))
         if use_wino:
             _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
         elif self.precision == "bf16":
@@ -253,6 +283,7 @@ class PackedDcn:
         _L.check(lib.e2fgvi_pack_dcn_weight(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
                                             deform_groups, _stream()), "pack_dcn_weight")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        self.name = "dcn"
 
     def __call__(self, sources, offset, mask=None, off_cols=None, flows=None, max_residue=10.0, out=None, tile=0):
         """sources: 1 or 2 NHWC tensors (virtual concat).  offset: [N,Ho,Wo,*] pixel-major; if ``mask`` is None
@@ -297,6 +328,10 @@ class PackedDcn:
             out = empty_nhwc(N, Ho, Wo, self.Cout, sources[0].device)
         _chk(out, "out")
         d.dst, d.dst_ld, d.dst_coff, d.tile = out.data_ptr(), out.shape[3], 0, tile
+        if _L.TRACE is not None:
+            m = N * Ho * Wo * self.Cout * self.C * K
+            _L.annotate(layer=self.name, kernel="mdcn", shape="N%d %dx%d %d->%d dg%d" % (N, H, W, self.C, self.Cout, self.dg),
+                        macs=m, issued=m)
         _L.check(lib.e2fgvi_mdcn_nhwc(C.byref(d), _stream()), "mdcn_nhwc")
         return out
 
@@ -326,6 +361,14 @@ def focal_attention(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, waves=
             focal_attention(qkv[b0 * rpc:b1 * rpc], kv_pool[b0 * ppc:b1 * ppc], key_tab, nkeys, b1 - b0, T, fh, fw,
                             out=out[b0 * rpc:b1 * rpc], waves=waves)
         return out
+    if _L.TRACE is not None:
+        # algorithmic = the reference's [T*45] x [T*210] score and PV products per (window, head); issued = the keys the
+        # kernel actually multiplies (zero-padded pooled slots are handled analytically), in 32-key tiles, 32-query waves
+        nkl = nkeys.tolist()
+        alg = B * nwin * 4 * (45 * T) * (210 * T) * 128 * 2
+        qpad = -(-(45 * T) // 32) * 32
+        iss = B * 4 * qpad * 128 * 2 * sum(-(-(T * k) // 32) * 32 for k in nkl)
+        _L.annotate(layer="attention", kernel="focal_attn", shape="B%d T%d grid %dx%d" % (B, T, fh, fw), macs=alg, issued=iss)
     _L.check(lib.e2fgvi_focal_attention(_ptr(qkv), _ptr(kv_pool), _ptr(key_tab), key_tab.shape[1], _ptr(nkeys),
                                         _ptr(out), B, T, fh, fw, waves, _stream()), "focal_attention")
     return out

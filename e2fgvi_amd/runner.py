@@ -12,7 +12,7 @@ def shard_range(n_items, rank, world):
 
 
 def gather_frames(local_out, world, group=None, out=None, force=False):
-    """All-gather equal-sized per-rank outputs [n,3,H,W] into [world*n,3,H,W] (rank-major = clip order)."""
+    """All-gather equal-sized per-rank outputs [n,...] into [world*n,...] (rank-major = clip order)."""
     if world == 1 and not force:
         return local_out
     import torch.distributed as dist
@@ -41,88 +41,104 @@ def inpaint_sharded(net, clips, num_local_frames, rank, world, group=None, pack_
 
 
 class ShardedStep:
-    """One benchmark / serving step: forward of this rank's clips (+ all-gather)."""
+    """One benchmark / serving step: forward of this rank's clips (+ optional uint8 packing) + all-gather of the frames.
 
-    def __init__(self, net, x, lt, group_world=1, use_graph=True, force_gather=False):
+    The forward (and the packing kernel) replays from a HIP graph once captured; the collective is NOT part of the graph.
+    With a gather, step k's frames are first copied out of the forward's (static, under graph replay) output into one of
+    two staging buffers, the all-gather of that buffer is issued asynchronously (RCCL's own stream) and runs under step
+    k+1's forward; ``run()`` returns the gathered frames of the PREVIOUS step (None on the first call) and ``finish()``
+    those of the last one; a returned buffer is valid until the next ``run()`` (two gather buffers alternate).
+    Without a gather ``run()`` / ``finish()`` return this step's frames directly."""
+
+    def __init__(self, net, x, lt, group_world=1, use_graph=True, force_gather=False, pack_u8=False, group=None):
         self.net, self.x, self.lt, self.world = net, x, lt, group_world
-        self.force_gather = force_gather
+        self.gather = group_world > 1 or force_gather
+        self.pack_u8, self.group = pack_u8, group
         self.graph = None
         self.graphed = False
-        self.out = None
-        self.gathered = None
+        self.out = None            # output of the last forward (static buffer once graphed)
         self.use_graph = use_graph
         self._calls = 0
+        self._stage = None         # two staging buffers (this rank's frames), two gather buffers
+        self._gathered = None
+        self._pending = None       # (work, gathered buffer) of the step whose gather is in flight
+        self._last = None
 
     def _forward(self):
         out, _ = self.net(self.x, self.lt)
+        if self.pack_u8:
+            from . import ops
+            out = ops.pred_to_u8(out.contiguous())
         return out
+
+    def _capture(self):
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._forward()                       # warm the allocator on the capture stream
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.out = self._forward()
+            self.graph, self.graphed = g, True
+        except Exception as e:                         # capture unsupported -> stay eager, say so
+            print("HIP graph capture failed (%s); running eagerly" % (str(e).splitlines()[0],), flush=True)
+            self.use_graph = False
+            self.graph = None
+            torch.cuda.synchronize()
 
     def run(self):
         if self.use_graph and self.graph is None and self._calls >= 1:
-            try:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    self._forward()                       # warm allocator on the side stream
-                torch.cuda.current_stream().wait_stream(s)
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self.out = self._forward()
-                self.graph, self.graphed = g, True
-            except Exception as e:                         # capture unsupported -> stay eager, say so
-                print("HIP graph capture failed (%s); running eagerly" % (str(e).splitlines()[0],), flush=True)
-                self.use_graph = False
-                torch.cuda.synchronize()
+            self._capture()
         self._calls += 1
         if self.graph is not None:
             self.graph.replay()
-            out = self.out
         else:
-            out = self._forward()
-        if self.world > 1 or self.force_gather:
-            return self._gather_pipelined(out)
-        return out
+            self.out = self._forward()
+        if not self.gather:
+            self._last = self.out
+            return self.out
+        return self._gather_pipelined(self.out)
 
     def _gather_pipelined(self, out):
-        """All-gather of this step's frames on RCCL's stream while the NEXT step's forward runs: the call returns the
-        gathered frames of the previous step (None on the first call); `finish()` returns the last ones.  Two gather
-        buffers alternate; the forward's output tensor is kept alive until its gather has completed."""
         import torch.distributed as dist
-        if self.graph is not None:                         # static output buffer: it would be overwritten under the gather
-            if self.gathered is None:
-                self.gathered = [torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype,
-                                             device=out.device)]
-            gather_frames(out, self.world, out=self.gathered[0], force=self.force_gather)
-            return self.gathered[0]
-        if self.gathered is None:
-            self.gathered = [torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-                             for _ in range(2)]
-            self._pending = None
-        buf = self.gathered[self._calls & 1]
-        work = dist.all_gather_into_tensor(buf, out.contiguous(), async_op=True)
-        prev, self._pending = self._pending, (work, out, buf)
+        if self._stage is None:
+            self._stage = [torch.empty_like(out) for _ in range(2)]
+            self._gathered = [torch.empty((self.world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype,
+                                          device=out.device) for _ in range(2)]
+        k = self._calls & 1
+        prev, self._pending = self._pending, None
+        if prev is not None:
+            prev[0].wait()                  # step k-1's gather (it had a whole forward to finish): frees stage / gather [k^1]...
+        # ... and stage[k] / gathered[k] were released when step k-2's gather was waited for, one call ago
+        self._stage[k].copy_(out)           # the forward's output buffer is free for the next replay after this copy
+        work = dist.all_gather_into_tensor(self._gathered[k], self._stage[k], group=self.group, async_op=True)
+        self._pending = (work, self._gathered[k])
         if prev is None:
             return None
-        prev[0].wait()                                     # stream-level wait; that gather finished a whole forward ago
-        return prev[2]
+        self._last = prev[1]
+        return prev[1]
 
     def finish(self):
-        """Frames of the last step (waits for its gather)."""
-        if getattr(self, "_pending", None) is None:
-            return self.out if self.graph is not None else None
-        work, _, buf = self._pending
-        work.wait()
-        self._pending = None
-        return buf
+        """Frames of the last step (all ranks' frames when gathering); waits for the gather in flight."""
+        if self._pending is not None:
+            work, buf = self._pending
+            work.wait()
+            self._pending = None
+            self._last = buf
+        return self._last
 
 
 def dominant_kernel_probe(net, dev, iters=20):
     """Device time of the dominant kernel (conv_wino_kernel, fp32 Winograd F(2x2,3x3) on the fp32 MFMA pipe) on its
     heaviest single launch of the north-star clip: encoder layer 10 (640 -> 512 in 2 groups, 3x3, 10 frames of 60x108),
-    hip events on the launch stream.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s, so it can exceed the MFMA
-    peak: the kernel executes 16/36 of those multiplies (x the block padding)."""
+    hip events on the launch stream.  `achieved` / `frac` count the FLOPs ISSUED to the matrix pipe (16 of the 36
+    direct-convolution multiplies per 2x2 outputs, on 16x16-pixel blocks: 64x112 padded pixels per frame);
+    `achieved_algorithmic` counts the direct-convolution FLOPs and can exceed the peak."""
     from . import ops
     eng = net.engine()
     layer = eng.enc[5]
@@ -137,15 +153,12 @@ def dominant_kernel_probe(net, dev, iters=20):
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
-    gflop = 2 * 10 * 60 * 108 * 9 * 320 * 512 * 1e-9
-    tf = gflop / (us * 1e-6) / 1e3
     wino = layer.algo == "auto"
-    # multiplies actually issued: 16 per 2x2 outputs and input channel instead of 36, on 64x112 padded pixels per frame
-    executed = tf * (16.0 / 36.0) * (64 * 112) / (60 * 108) if wino else tf
-    name = ("conv_wino_kernel<2,64,2> (Winograd F(2x2,3x3), encoder.layers.10: 3x3 640->512 g2 on 10x60x108)" if wino else
-            "conv_igemm_kernel (encoder.layers.10: 3x3 640->512 g2 on 10x60x108)")
-    return {"kernel": name, "avg_us": round(us, 2), "gflop_per_launch": round(gflop, 3), "achieved": round(tf, 2),
-            "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-            "mfma_executed": round(executed, 2), "mfma_frac": round(executed / 157.3, 4),
-            "note": "achieved = algorithmic (direct conv) FLOPs / time; Winograd issues 16/36 of them, mfma_executed is what "
-                    "the matrix pipe actually did"}
+    wk = layer._work(10, 60, 108, 60, 108, wino, 0)
+    gflop, gflop_iss = 2e-9 * wk["macs"], 2e-9 * wk["issued"]
+    tf, tf_iss = gflop / (us * 1e-6) / 1e3, gflop_iss / (us * 1e-6) / 1e3
+    return {"kernel": "%s (encoder.layers.10: 3x3 640->512 g2 on 10x60x108)" % wk["kernel"], "avg_us": round(us, 2),
+            "gflop_per_launch": round(gflop_iss, 3), "gflop_per_launch_algorithmic": round(gflop, 3),
+            "achieved": round(tf_iss, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf_iss / 157.3, 4),
+            "achieved_algorithmic": round(tf, 2), "frac_algorithmic": round(tf / 157.3, 4),
+            "note": "achieved = FLOPs issued to the matrix pipe / time; *_algorithmic = direct-convolution FLOPs / time"}

@@ -88,7 +88,16 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
     masks01 = prepare_masks(masks_u8, (h, w), device, dilate)
     Hp, Wp = padded_size(h, w) if pad else (h, w)
     windows = plan_windows(L, neighbor_stride, ref_length, num_ref)
+    # every host->device upload happens here, before the first forward: frame ids of each window and the
+    # "first prediction of this frame" flags of the reference's comp_frames[idx] is None test (test.py:172-176)
     ids_dev = [torch.tensor(nb + rf, dtype=torch.int32, device=device) for nb, rf in windows]
+    seen = [False] * L
+    first_dev = []
+    for nb, _ in windows:
+        first_dev.append(torch.tensor([0 if seen[j] else 1 for j in nb], dtype=torch.uint8, device=device))
+        for j in nb:
+            seen[j] = True
+    comp = torch.empty((L, h, w, 3), dtype=torch.float32, device=device)
 
     def predict(group):
         x = torch.cat([ops.masked_clip(frames_d, masks01, ids_dev[i], Hp, Wp) for i in group], 0) if len(group) > 1 \
@@ -98,25 +107,35 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
         t = x.shape[1]
         return [pred[k * t:k * t + n_local] for k in range(len(group))]
 
-    preds = [None] * len(windows)
+    def composite(i, pred):
+        n = len(windows[i][0])
+        ops.composite(pred.contiguous(), ids_dev[i][:n], first_dev[i], frames_d, masks01, comp)
+
     if batch_windows <= 1:
-        order = [[i] for i in range(len(windows))]
+        # like the reference: every window is composited right after its forward, nothing is kept
+        for i in range(len(windows)):
+            composite(i, predict([i])[0])
     else:
         by_shape = {}
         for i, (nb, rf) in enumerate(windows):
             by_shape.setdefault((len(nb), len(rf)), []).append(i)
-        order = [idx[k:k + batch_windows] for idx in by_shape.values() for k in range(0, len(idx), batch_windows)]
-    for grp in order:
-        for i, p in zip(grp, predict(grp)):
-            preds[i] = p
-
-    comp = torch.empty((L, h, w, 3), dtype=torch.float32, device=device)
-    seen = [False] * L
-    for i, (neighbor_ids, _) in enumerate(windows):
-        first = torch.tensor([0 if seen[j] else 1 for j in neighbor_ids], dtype=torch.uint8, device=device)
-        ops.composite(preds[i].contiguous(), ids_dev[i][:len(neighbor_ids)].contiguous(), first, frames_d, masks01, comp)
-        for j in neighbor_ids:
-            seen[j] = True
+        groups = sorted((idx[k:k + batch_windows] for idx in by_shape.values() for k in range(0, len(idx), batch_windows)),
+                        key=lambda g: g[0])
+        # the 0.5/0.5 blend is order dependent: predictions are composited in the reference's window order as soon as
+        # all earlier windows are done; a window that has to wait keeps only its local frames (a copy, so the batch
+        # output with the reference frames' predictions is released)
+        pending, nxt = {}, 0
+        for grp in groups:
+            for i, p in zip(grp, predict(grp)):
+                if i == nxt:
+                    composite(i, p)
+                    nxt += 1
+                else:
+                    pending[i] = p.clone()
+            while nxt in pending:
+                composite(nxt, pending.pop(nxt))
+                nxt += 1
+        assert not pending and nxt == len(windows)
     if keep_float:
         return comp
     return ops.float_to_u8(comp).cpu().numpy()

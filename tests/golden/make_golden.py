@@ -26,6 +26,11 @@ CASES = [
     ("g2_e2fgvi_stress_t4_lt3", "e2fgvi", "stress", (240, 432), 4, 3, 1, 12),
     ("g3_hq_stress_120x216_t4_lt3", "e2fgvi_hq", "stress", (120, 216), 4, 3, 1, 13),
     ("g4_hq_default_60x108_t3_lt2_b2", "e2fgvi_hq", "default", (60, 108), 3, 2, 2, 14),
+    # BASELINE.json configs 4 / 5 resolutions (720x1280 -> 720x1296, 1080x1920 -> 1080x1944 after test.py's padding):
+    # 12x12 / 18x18 window grids, i.e. fully valid pooled neighbourhoods (210 keys per frame) and circular wrap-around
+    # over the whole grid -- branches the small fixtures never reach.  Few frames keep the CPU run to minutes.
+    ("g5_hq_stress_720x1296_t3_lt2", "e2fgvi_hq", "stress", (720, 1296), 3, 2, 1, 15),
+    ("g6_hq_stress_1080x1944_t2_lt2", "e2fgvi_hq", "stress", (1080, 1944), 2, 2, 1, 16),
 ]
 OUT_STRIDE, FLOW_STRIDE = 8, 4
 
@@ -37,7 +42,10 @@ def stats(t):
 
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
+    only = set(sys.argv[1:])
     for name, model, kind, (H, W), t, lt, b, seed in CASES:
+        if only and name not in only:
+            continue
         sd = synth_state_dict(model, kind, 0)
         net = ref_import.build_reference_model(model, sd)
         x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)

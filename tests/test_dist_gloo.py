@@ -68,6 +68,17 @@ class _StepNet:
         return torch.full((b * t, c, H, W), 100.0 * self.rank + self.calls), None
 
 
+class _StaticNet(_StepNet):
+    """like a HIP-graph replay: every call rewrites ONE static output buffer in place"""
+
+    def __call__(self, x, lt):
+        out, _ = super().__call__(x, lt)
+        if not hasattr(self, "buf"):
+            self.buf = torch.empty_like(out)
+        self.buf.copy_(out)
+        return self.buf, None
+
+
 def _step_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -84,6 +95,19 @@ def _step_worker(rank, world, port, q):
     for k, g in ((1, got[1]), (2, got[2]), (3, last)):
         # step k: rank 0 contributed the value k, rank 1 the value 100 + k; rank-major order
         ok = ok and tuple(g.shape) == (world * 2, 3, 4, 4) and bool((g[:2] == float(k)).all()) and bool((g[2:] == 100.0 + k).all())
+    # the same with a net that reuses one output buffer (what graph replay does): the staging copy must protect the
+    # frames of step k from step k+1's forward, and finish() must return the LAST step's gather
+    step = ShardedStep(_StaticNet(rank), torch.zeros(1, 2, 3, 4, 4), 2, group_world=world, use_graph=False)
+    outs = []
+    for _ in range(4):
+        o = step.run()                       # valid until the next run(): two gather buffers alternate
+        outs.append(None if o is None else o.clone())
+    outs.append(step.finish().clone())
+    ok = ok and outs[0] is None
+    for k in range(1, 5):
+        g = outs[k]
+        ok = ok and bool((g[:2] == float(k)).all()) and bool((g[2:] == 100.0 + k).all())
+    ok = ok and step.finish() is not None and bool((step.finish()[:2] == 4.0).all())       # idempotent
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -103,7 +103,9 @@ E2E = [("e2fgvi", "stress", (240, 432), 3, 3, 1), ("e2fgvi", "default", (240, 43
        ("e2fgvi", "stress", (240, 432), 6, 2, 1), ("e2fgvi", "stress", (240, 432), 3, 2, 2),
        # non-square window grids: 3x2 windows (token grid 15x18), 1x2 windows, a single window
        ("e2fgvi_hq", "stress", (180, 216), 3, 3, 1), ("e2fgvi_hq", "stress", (60, 216), 4, 2, 1),
-       ("e2fgvi_hq", "default", (60, 108), 2, 2, 3)]
+       ("e2fgvi_hq", "default", (60, 108), 2, 2, 3),
+       # a single local frame (test.py on a 1-frame video): empty flow tensors, propagation without neighbours
+       ("e2fgvi_hq", "stress", (60, 108), 3, 1, 1), ("e2fgvi", "stress", (240, 432), 1, 1, 1)]
 
 
 @pytest.mark.parametrize("model,kind,hw,t,lt,b", E2E)
@@ -118,12 +120,14 @@ def test_end_to_end(dev, model, kind, hw, t, lt, b):
         got, (ff, fb) = net(x.to(dev), lt)
     assert tuple(got.shape) == (b * t, 3, hw[0], hw[1])
     d, r = err(got, out)
-    df, rf = err(ff, flows[0])
-    db, rb = err(fb, flows[1])
-    print("e2e %s %s: out max abs %.3e (%.2e x rms), flows %.3e / %.3e" % (model, kind, d, r, df, db))
+    assert tuple(ff.shape) == tuple(flows[0].shape) == (b, lt - 1, 2, hw[0] // 4, hw[1] // 4) and tuple(fb.shape) == tuple(ff.shape)
+    if lt > 1:
+        df, rf = err(ff, flows[0])
+        db, rb = err(fb, flows[1])
+        assert df <= 1e-3 * max(1.0, flows[0].abs().max().item()) and db <= 1e-3 * max(1.0, flows[1].abs().max().item())
+    print("e2e %s %s: out max abs %.3e (%.2e x rms)" % (model, kind, d, r))
     assert torch.isfinite(got).all()
     assert d <= 1e-3, "output max abs err %.3e" % d
-    assert df <= 1e-3 * max(1.0, flows[0].abs().max().item()) and db <= 1e-3 * max(1.0, flows[1].abs().max().item())
     assert r <= 2e-2, "output err relative to rms %.3e" % r
 
 
@@ -133,7 +137,7 @@ import os
 
 import numpy as np
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g[0-9]_*.npz")))
 
 
 @pytest.mark.parametrize("path", GOLD, ids=os.path.basename)
@@ -210,7 +214,7 @@ def test_argument_errors(dev):
     hq = importlib.import_module("model.e2fgvi_hq").InpaintGenerator().to(dev).eval()
     x = torch.zeros(1, 3, 3, 240, 432, device=dev)
     with pytest.raises(ValueError):
-        base(x, 1)                                   # l_t must be >= 2 (flows of l_t-1 pairs)
+        base(x, 0)                                   # l_t must be >= 1
     with pytest.raises(ValueError):
         base(x, 4)                                   # l_t > t
     with pytest.raises(ValueError):
@@ -219,6 +223,36 @@ def test_argument_errors(dev):
         hq(torch.zeros(1, 3, 3, 100, 216, device=dev), 2)        # H not a multiple of 60 (caller must pad)
     with pytest.raises(RuntimeError):
         hq(torch.zeros(1, 3, 3, 60, 108), 2)                     # CPU tensor
+
+
+def test_sharded_step_over_rccl(dev):
+    """runner.ShardedStep with backend "nccl" (= RCCL), world_size 1, force_gather: the pipelined all-gather (fp32 and the
+    uint8 form) around the HIP-graph replay returns exactly the plain forward's frames, step after step."""
+    import importlib
+    import socket
+    import torch.distributed as dist
+    from e2fgvi_amd import ops, runner
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    net = importlib.import_module("model.e2fgvi_hq").InpaintGenerator()
+    net.load_state_dict(synth_state_dict("e2fgvi_hq", "stress", 0))
+    net = net.to(dev).eval()
+    x = synth_clip(2, 3, 60, 108, seed=43, moving=True)[0].to(dev)
+    eager, _ = net(x, 2)
+    torch.cuda.synchronize()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for pack in (False, True):
+            step = runner.ShardedStep(net, x, 2, group_world=1, use_graph=True, force_gather=True, pack_u8=pack)
+            want = ops.pred_to_u8(eager) if pack else eager
+            got = [step.run() for _ in range(4)]
+            assert got[0] is None and step.graphed
+            for g in got[1:]:
+                assert torch.equal(g, want)
+            assert torch.equal(step.finish(), want)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_graph_replay_equals_eager(dev):

@@ -264,6 +264,86 @@ def test_focal_attention(dev, B, T, fh, fw):
         assert_close(out.cpu(), ref, 5e-5, "attention waves=%d" % waves)
 
 
+@pytest.mark.parametrize("B,T,fh,fw,far", [(1, 4, 60, 108, False), (1, 4, 90, 162, False), (1, 4, 60, 108, True)])
+def test_focal_attention_large_grids(dev, B, T, fh, fw, far):
+    """the BASELINE HQ token grids (720x1296 -> 60x108 = 12x12 windows, 1080x1944 -> 90x162 = 18x18): interior windows
+    see a fully valid pooled neighbourhood (210 keys per frame, no analytic -100 mass), border windows wrap around the
+    whole grid.  ``far``: qkv and kv_pool more than 4 GiB apart, so one buffer resource cannot cover both (the
+    kernel's two-resource path, attention.hip ONE_RSRC = false).  Reference: tfocal_transformer_hq.py:231-425."""
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.engine import build_key_table
+    from e2fgvi_amd.synth import rolled_valid_index
+    from oracle import e2fgvi_oracle as O
+    g = _gen(60 + fh)
+    Cc = 512
+    xn = torch.randn(B, T, fh, fw, Cc, generator=g)
+    sd = {"a.qkv.weight": torch.randn(1536, Cc, generator=g) / math.sqrt(Cc) * 2.0,
+          "a.qkv.bias": torch.randn(1536, generator=g) * 0.1,
+          "pool_layers.0.weight": torch.full((1, 45), 1 / 45.) + 0.02 * torch.randn(1, 45, generator=g),
+          "pool_layers.0.bias": torch.zeros(1)}
+    xp = O.pool_windows(sd, "", xn)
+    pre = O.window_attention(sd, "a.", xn, xp, preproj=True)
+    ref = O.window_reverse(pre, B, T, fh, fw).reshape(-1, Cc)
+    qkv = F.linear(xn.reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
+    kvp = F.linear(xp.permute(0, 3, 1, 2, 4).reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
+    tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
+    assert nk.max() == 210 and nk.min() < 210
+    if far:
+        span = 5 * (1 << 30)
+        arena = torch.empty(span + kvp.numel() * 4 + 256, dtype=torch.uint8, device=dev)
+        q_d = arena[:qkv.numel() * 4].view(torch.float32).view(qkv.shape)
+        p_d = arena[span:span + kvp.numel() * 4].view(torch.float32).view(kvp.shape)
+        q_d.copy_(qkv); p_d.copy_(kvp)
+        assert abs(q_d.data_ptr() - p_d.data_ptr()) >= (1 << 32)
+    else:
+        q_d, p_d = qkv.to(dev), kvp.to(dev)
+    for waves in (0, 14):
+        out = ops.focal_attention(q_d, p_d, torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev), B, T, fh, fw,
+                                  waves=waves)
+        assert_close(out.cpu(), ref, 5e-5, "attention %dx%d far=%s waves=%d" % (fh, fw, far, waves))
+
+
+def test_conv_batch_chunking_across_4gib(dev):
+    """sources of a batch spanning >= 4 GiB are processed in image chunks (32-bit buffer resources inside the kernels,
+    PackedConv.__call__): images on both sides of every chunk boundary must equal the single-image result."""
+    from e2fgvi_amd import ops
+    g = _gen(77)
+    cin, cout, H, W, N = 512, 8, 512, 512, 9                   # 512 MiB per image, 4.5 GiB per batch
+    w = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    bias = torch.randn(cout, generator=g)
+    layer = ops.PackedConv(w.to(dev), bias.to(dev), [cin])
+    x = torch.empty(N, H, W, cin, device=dev)
+    for n in range(N):
+        x[n].normal_(generator=None)
+    assert x.numel() * 4 >= (1 << 32)
+    res = torch.randn(N, H, W, cout, device=dev)
+    out = layer([x], residual=res, act=ops.ACT_LRELU, slope=0.1)
+    step = ((1 << 32) - 2) // (H * W * cin * 4)
+    for n in sorted({0, step - 1, step, N - 1}):
+        one = layer([x[n:n + 1].contiguous()], residual=res[n:n + 1].contiguous(), act=ops.ACT_LRELU, slope=0.1)
+        assert torch.equal(out[n:n + 1], one), "image %d differs from its single-image run" % n
+    ref = F.leaky_relu(F.conv2d(nchw(x[step].cpu()[None]), w, bias) + nchw(res[step].cpu()[None]), 0.1)
+    assert_close(nchw(out[step:step + 1].cpu()), ref, REL, "chunked conv vs torch")
+    del x, out
+
+
+def test_mmcv_convmodule_standin(dev):
+    """e2fgvi_amd.mmcv_ops.ConvModule (flow_comp.py:181-215's building block) == conv2d + ReLU, NCHW in / out"""
+    from e2fgvi_amd import mmcv_ops
+    torch.manual_seed(5)
+    m = mmcv_ops.ConvModule(8, 32, 7, 1, 3, norm_cfg=None, act_cfg=dict(type="ReLU")).to(dev)
+    x = torch.randn(2, 8, 24, 40)
+    ref = F.relu(F.conv2d(x, m.conv.weight.cpu(), m.conv.bias.cpu(), padding=3))
+    assert_close(m(x.to(dev)).cpu(), ref, REL, "ConvModule")
+    m2 = mmcv_ops.ConvModule(16, 2, 7, 1, 3, norm_cfg=None, act_cfg=None).to(dev)
+    x2 = torch.randn(1, 16, 16, 32)
+    assert_close(m2(x2.to(dev)).cpu(), F.conv2d(x2, m2.conv.weight.cpu(), m2.conv.bias.cpu(), padding=3), REL, "ConvModule no act")
+    lin = torch.nn.Conv2d(4, 4, 3)
+    mmcv_ops.constant_init(lin, 0.5, bias=0.25)
+    assert float(lin.weight.min()) == 0.5 and float(lin.bias.max()) == 0.25
+    assert mmcv_ops.load_checkpoint(lin, "https://example.invalid/spynet.pth") is None
+
+
 def test_layout_roundtrip(dev):
     from e2fgvi_amd import ops
     g = _gen(7)

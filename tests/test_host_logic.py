@@ -129,16 +129,63 @@ def test_shard_range_partitions():
 
 
 def test_flops_formula_matches_survey():
+    """bench.flops_per_clip == the evaluated figures of SURVEY.md 8(d) (GMAC x 2) for every BASELINE config"""
     import bench
-    saved, bench.GFLOP_PER_CLIP = bench.GFLOP_PER_CLIP, {}
-    try:
-        assert abs(bench.flops_per_clip(10, 10) - 2039.1) < 0.5
-        assert abs(bench.flops_per_clip(5, 5) - 932.5) < 0.5
-        assert abs(bench.flops_per_clip(10, 5) - 2 * 859.4) < 0.5
-    finally:
-        bench.GFLOP_PER_CLIP = saved
+    assert abs(bench.flops_per_clip(240, 432, 10, 10, False) - 2039.1) < 0.5
+    assert abs(bench.flops_per_clip(240, 432, 5, 5, False) - 932.5) < 0.5
+    assert abs(bench.flops_per_clip(240, 432, 10, 5, False) - 2 * 859.4) < 0.5
+    assert abs(bench.flops_per_clip(720, 1296, 10, 10, True) - 2 * 9226.7) < 2
+    assert abs(bench.flops_per_clip(1080, 1944, 20, 20, True) - 2 * 46980.8) < 10
 
 
 def test_token_grid():
     from e2fgvi_amd.engine import token_grid
     assert token_grid(60, 108) == (20, 36) and token_grid(180, 324) == (60, 108) and token_grid(270, 486) == (90, 162)
+
+
+def test_init_weights_variants_and_inference_only_guards():
+    """model/e2fgvi.py:29-68: every init_type of the reference; DCN main weight untouched, conv_offset[-1] zero after
+    construction; the module is inference-only and says so."""
+    import importlib
+    import pytest
+    mod = importlib.import_module("model.e2fgvi_hq")
+    net = mod.InpaintGenerator()
+    dcn_w = net.feat_prop_module.deform_align["forward_"].weight.clone()
+    assert float(net.feat_prop_module.deform_align["forward_"].conv_offset[-1].weight.abs().max()) == 0.0
+    w = net.encoder.layers[4].weight                       # [128, 64, 3, 3]
+    for kind, std in (("normal", 0.02), ("kaiming", (2.0 / (64 * 9)) ** 0.5), ("xavier", 0.02 * (2.0 / ((64 + 128) * 9)) ** 0.5)):
+        net.init_weights(kind)
+        assert abs(float(w.std()) / std - 1) < 0.05, kind
+        assert float(net.encoder.layers[4].bias.abs().max()) == 0.0
+    net.init_weights("xavier_uniform")
+    bound = (6.0 / ((64 + 128) * 9)) ** 0.5
+    assert float(w.abs().max()) <= bound and float(w.abs().max()) > 0.9 * bound
+    net.init_weights("none")
+    net.ss.embedding.weight.data.zero_()
+    net.init_weights("orthogonal", gain=1.0)
+    q = net.transformer[0].attn.proj.weight                # square: orthogonal up to the gain
+    assert torch.allclose(q @ q.t(), torch.eye(512), atol=1e-4)
+    assert torch.equal(net.feat_prop_module.deform_align["forward_"].weight, dcn_w)
+    with pytest.raises(NotImplementedError):
+        net.init_weights("bogus")
+    with pytest.raises(RuntimeError):
+        net.train()
+    assert net.eval() is net and not net.training
+    with pytest.raises(NotImplementedError):
+        mod.Discriminator()
+    with pytest.raises(NotImplementedError):
+        mod.spectral_norm(torch.nn.Conv2d(1, 1, 1))
+
+
+def test_engine_cache_is_dropped_when_parameters_can_change():
+    import importlib
+    net = importlib.import_module("model.e2fgvi_hq").InpaintGenerator()
+    sentinel = object()
+    for change in (lambda: net.load_state_dict(net.state_dict()), lambda: net.init_weights(), lambda: net.float(),
+                   lambda: net.refresh_engine()):
+        net._engine, net._engine_key = sentinel, "k"
+        change()
+        assert net._engine is None and net._engine_key is None
+    a = net._fingerprint()
+    net.decoder[6].weight.data = net.decoder[6].weight.data.clone()          # a .data swap far down the parameter list
+    assert net._fingerprint() != a
