@@ -8,7 +8,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libe2fgvi_hip.so")
 SOURCES = ["error.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "mdcn.hip", "attention.hip", "misc.hip", "video.hip", "metrics.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+# -packed-fp32-ops: no kernel of this library may contain v_pk_{mul,add,fma}_f32.  Measured on MI355X (tools/probe/
+# overlap_probe.hip, profiles/r02_overlap_probe_*.txt, DESIGN.md "Stream overlap"): the results of packed-fp32 VALU
+# instructions of a wave are corrupted in lanes 48-63 when that wave shares a SIMD with the bf16 implicit-GEMM tile
+# that keeps four v_mfma_f32_32x32x16_bf16 back to back -- independent of memory waits and cache policy, never with the
+# scalar-fp32 form of the same arithmetic.  The side-stream kernels (SPyNet next to the encoder) were the victims.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc():

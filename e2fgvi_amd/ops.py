@@ -41,6 +41,8 @@ def empty_nhwc(n, h, w, c, device):
 # implicit-GEMM tile codes worth timing on GEMM-shaped layers (64x64 / 128x128 / 64x128 / 128x256 / 256x128 shapes with
 # 16- and 32-deep K steps); 0 = the library's static choice
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
+# Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
+WINO_CANDIDATES = (64, 132, 164, 32)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 
 
@@ -118,22 +120,23 @@ class PackedConv:
                                              len(self.cpg), arr, bk, _stream()), "pack_conv_weight")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
 
-    def _autotune(self, lib, d):
+    def _autotune(self, lib, d, wino=False):
         """Device time of every candidate tile code on this exact call (2 launches each, hip events); the launches
         rewrite the same output, so the result of the call is unaffected."""
         best, best_ms = 0, float("inf")
         st = _stream()
         d.tile = 0
+        fn = lib.e2fgvi_conv3x3_winograd if wino else lib.e2fgvi_conv2d_nhwc
         for _ in range(3):                                       # bring clocks / caches to steady state first
-            lib.e2fgvi_conv2d_nhwc(C.byref(d), st)
-        for code in TUNE_CANDIDATES:
+            fn(C.byref(d), st)
+        for code in (WINO_CANDIDATES if wino else TUNE_CANDIDATES):
             d.tile = code
-            if lib.e2fgvi_conv2d_nhwc(C.byref(d), st) != 0:      # not instantiated / not applicable to this packing
+            if fn(C.byref(d), st) != 0:                          # not instantiated / not applicable to this packing
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(2):
-                lib.e2fgvi_conv2d_nhwc(C.byref(d), st)
+                fn(C.byref(d), st)
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1)
@@ -230,15 +233,15 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
-        if tile == 0 and self.tune and not use_wino and self.precision == "fp32" and N * Ho * Wo >= 2048:
+        if tile == 0 and self.tune and self.precision == "fp32" and N * Ho * Wo >= 2048:
             # one decision per (layer geometry, size class): row counts within a quarter octave share the tile, so the
             # slightly different window lengths of a video (t = 17 ... 21 frames) do not each pay for a tuning pass
             key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk,
-                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act)
+                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino)
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
-                best = _TUNED[key] = self._autotune(lib, d)
+                best = _TUNED[key] = self._autotune(lib, d, use_wino)
             d.tile = best or 0
         if _L.TRACE is not None:
             _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile))

@@ -38,6 +38,7 @@ x = synth_clip(a.clips, a.t, H, W, seed=0, smooth=False)[0].to(dev)
 for _ in range(3):
     net(x, a.t)
 torch.cuda.synchronize()
+serial = net.engine().overlap_flows
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5):
@@ -46,12 +47,14 @@ e1.record()
 torch.cuda.synchronize()
 fwd_ms = e0.elapsed_time(e1) / 5
 runs = []
+net.engine().overlap_flows = False      # traced launches are timed one by one: no second stream sharing the CUs
 for _ in range(3):
     lib.TRACE = []
     net(x, a.t)
     torch.cuda.synchronize()
     runs.append(lib.TRACE)
     lib.TRACE = None
+net.engine().overlap_flows = serial
 assert len({len(r) for r in runs}) == 1
 rows = []
 for k, r in enumerate(runs[0]):
@@ -79,7 +82,8 @@ json.dump({"summary": summary, "rows": rows}, open(a.out + ".json", "w"), indent
 # grouped view: same (layer-name-without-index, kernel, shape) collapsed
 groups = {}
 for r in rows:
-    key = (r["layer"] or r["symbol"], r["kernel"], r["shape"])
+    import re
+    key = (re.sub(r"transformer\.\d+", "transformer.*", r["layer"] or r["symbol"]), r["kernel"], r["shape"])
     g = groups.setdefault(key, {"n": 0, "us": 0.0, "gflop": 0.0, "iss": 0.0})
     g["n"] += 1; g["us"] += r["us"]; g["gflop"] += r.get("gflop", 0.0); g["iss"] += r.get("gflop_issued", 0.0)
 with open(a.out + ".md", "w") as f:
