@@ -7,14 +7,22 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libe2fgvi_hip.so")
-SOURCES = ["error.hip", "conv.hip", "conv_bf16.hip", "conv_wino.hip", "mdcn.hip", "attention.hip", "misc.hip", "video.hip", "metrics.hip"]
-# -packed-fp32-ops: no kernel of this library may contain v_pk_{mul,add,fma}_f32.  Measured on MI355X (tools/probe/
-# overlap_probe.hip, profiles/r02_overlap_probe_*.txt, DESIGN.md "Stream overlap"): the results of packed-fp32 VALU
-# instructions of a wave are corrupted in lanes 48-63 when that wave shares a SIMD with the bf16 implicit-GEMM tile
-# that keeps four v_mfma_f32_32x32x16_bf16 back to back -- independent of memory waits and cache policy, never with the
-# scalar-fp32 form of the same arithmetic.  The side-stream kernels (SPyNet next to the encoder) were the victims.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+# No packed-fp32 VALU (v_pk_{mul,add,fma}_f32) in kernels that may run beside the bf16 MFMA tiles on another stream.
+# Measured on MI355X (tools/probe/overlap_probe.hip, profiles/r02_overlap_probe_*.txt, DESIGN.md "Stream overlap"): a
+# packed-fp32 instruction that consumes registers freshly written by vector-memory loads returns wrong values in lanes
+# 48-63 when its wave shares a SIMD with a wave that streams 2x2 v_mfma_f32_32x32x16_bf16 tiles fed by ds_read_b128 --
+# regardless of s_waitcnt / idle cycles / cache policy, never with scalar fp32 instructions on the same registers.
+NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# (source, object, extra flags).  The HBM-bound kernels lose nothing without packed math; the fp32 conv kernels keep it in
+# their normal build (6-8 % on the MFMA kernels' transforms / epilogues, profiles/r02_c2_*) and get a second, packed-free
+# build for the side-stream launches (SPyNet).
+UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
+         ("conv_bf16.hip", "conv_bf16.o", []), ("conv_bf16x.hip", "conv_bf16x.o", []), ("conv_wino.hip", "conv_wino.o", []),
+         ("mdcn.hip", "mdcn.o", []), ("attention.hip", "attention.o", []), ("misc.hip", "misc.o", NOPK),
+         ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]
+NOPK_OBJECTS = ("conv_nopk.o", "misc.o", "video.o", "metrics.o")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
 def _hipcc():
@@ -28,18 +36,21 @@ def _stale(out, deps):
     return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+def build(force=False, verbose=False, nopk_all=False, lib=None):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
+    nopk_all: build every unit without packed-fp32 VALU (A/B measurements) into ``lib``."""
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_nopk" if nopk_all else "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "e2fgvi_hip.h")]
+    out = lib or (os.path.join(CSRC, "libe2fgvi_hip_nopk.so") if nopk_all else LIB)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "e2fgvi_hip.h"), os.path.abspath(__file__)]
     jobs = []
-    for s in SOURCES:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+    for src, obj, extra in UNITS:
+        sp, op = os.path.join(CSRC, src), os.path.join(objdir, obj)
+        if nopk_all and not any(f == "-packed-fp32-ops" for f in extra):
+            extra = extra + NOPK
+        if force or _stale(op, [sp] + headers):
+            jobs.append([hipcc] + FLAGS + extra + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -48,11 +59,45 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    objs = [os.path.join(objdir, obj) for _, obj, _ in UNITS]
+    if force or jobs or _stale(out, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    if jobs:
+        verify_isa(objdir)
+    return out
+
+
+def device_isa(obj):
+    """Disassembly of the gfx950 code object embedded in a host object file."""
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="e2isa")
+    try:
+        local = os.path.join(d, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", os.path.basename(obj)], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        dev = [f for f in os.listdir(d) if "gfx950" in f]
+        if not dev:
+            return ""
+        return subprocess.run([OBJDUMP, "-d", os.path.join(d, dev[0])], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def verify_isa(objdir=None):
+    """Build-time check of the generated code: the units that must be free of packed-fp32 VALU instructions are."""
+    import re
+    objdir = objdir or os.path.join(CSRC, "build")
+    if not os.path.exists(OBJDUMP):
+        return
+    for obj in NOPK_OBJECTS:
+        isa = device_isa(os.path.join(objdir, obj))
+        bad = re.findall(r"v_pk_(?:mul|add|fma)_f32", isa)
+        if bad or not isa:
+            raise RuntimeError("%s: %s" % (obj, "%d packed-fp32 instructions in a unit that must have none" % len(bad) if isa
+                                           else "no gfx950 code object found"))
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, nopk_all="--nopk-all" in sys.argv))

@@ -1,0 +1,454 @@
+// Implicit-GEMM convolution / linear layer of the bf16 data path (gfx950): bf16 NHWC activations in HBM, bf16 packed
+// weights, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 epilogue, bf16 and / or fp32 stores.
+//
+// Both operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 bytes per lane, 1 KiB per wave
+// instruction): no staging registers, no ds_write pass, out-of-range lanes (image halo, channel tails, rows past M,
+// columns past Npad) are given an out-of-range buffer offset and land as zeros.  The DMA writes LDS linearly in lane
+// order, so the bank-conflict-free image is produced on the SOURCE side: lane (row, slot) of the A tile fetches the
+// 16-byte channel chunk  slot ^ ((row >> 1) & 7)  of its pixel -- the 8 lanes of a row still cover one contiguous
+// 128-byte run of the pixel's channels, only permuted.
+//   LDS A stage: [BM rows][8 chunks of 8 bf16]   chunk c of row r at 16-byte slot  r*8 + (c ^ ((r >> 1) & 7))
+//   LDS B stage: [8 k-octets][BN][8 bf16]        (the packed weight layout, lane-linear)
+//   MFMA operands (v_mfma_f32_32x32x16_bf16): lane l supplies 8 consecutive k (k-octet 2*kk + (l >> 5)) of row / column
+//   (l & 31): one ds_read_b128 each; the XOR swizzle makes the 16-lane groups of a b128 read hit 16 distinct slots.
+// K loop: one 64-deep step (64 input channels of one (tap, source)) per barrier, two LDS stages: the DMA of step s+1 is
+// issued before the MFMAs of step s and drained (s_waitcnt vmcnt(0)) at the barrier that ends step s.
+// Epilogue: every wave parks its accumulator tiles in LDS (the stages are free by then) and reads them back row-wise,
+// 8 consecutive output channels per lane: bias, residual (fp32 or bf16), activation or the DCN offset / mask
+// post-processing, then 16-byte bf16 stores and / or 2 x 16-byte fp32 stores -- whole 128 / 256-byte rows per wave.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct ConvXParams {
+    const void* src[E2FGVI_MAX_SRC];
+    int ld[E2FGVI_MAX_SRC];
+    int coff[E2FGVI_MAX_SRC];
+    int cpg[E2FGVI_MAX_SRC];
+    unsigned src_bytes[E2FGVI_MAX_SRC];
+    int nsrc;
+    int N, H, W, Ho, Wo, KH, KW, stride, pad;
+    int Cout, Cout_g, Npad;
+    int M;
+    int tilesM, tilesN;
+    int nsteps;                           // KH * KW * (64-channel blocks per tap)
+    unsigned wgroup_bytes;
+    long long wgroup_elems;
+    const __bf16* w;
+    const float* bias;
+    const void* res;
+    int res_ld, res_coff, res_bf16;
+    void* dst;
+    int dst_ld, dst_coff, dst_bf16;
+    __bf16* dst2;
+    int dst2_ld, dst2_coff;
+    int act;
+    float slope;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float dcn_post(float v, int co, int C, const f32x4& fl, float max_residue) {
+    const int noff = (C / 3) * 2;
+    if (co >= noff) return 1.f / (1.f + expf(-v));
+    const int which = (co * 2 >= noff) ? 2 : 0;
+    return max_residue * tanhf(v) + fl[which + ((co & 1) ? 0 : 1)];
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one 64-deep stage of each operand
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte DMA items per thread
+    constexpr int R = TM * 32, CN = TN * 32, LDE = CN + 4;      // a wave's epilogue region: R rows of LDE floats
+    constexpr int EPI = WGM * WGN * R * LDE * 4;
+    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int g = blockIdx.y;
+    const int logical = xcd_remap(blockIdx.x, p.tilesM * p.tilesN);
+    const int tile_m = logical / p.tilesN, tile_n = logical - tile_m * p.tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- DMA bookkeeping of this thread's A items (step invariant): item = tid + it * NT -> (row, 16-byte slot)
+    int a_pix[A_IT], a_by[A_IT], a_bx[A_IT], a_chunk[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int item = tid + it * NT;
+        const int row = item >> 3, slot = item & 7;
+        a_chunk[it] = slot ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int img = mm / HoWo;
+        const int rem = mm - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_by[it] = ok ? oy * p.stride - p.pad : -(1 << 28);
+        a_bx[it] = ox * p.stride - p.pad;
+        a_pix[it] = (img * p.H + oy * p.stride - p.pad) * p.W + ox * p.stride - p.pad;
+    }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int item = tid + it * NT;
+        const int koct = item / BN, n = item - koct * BN;
+        b_off[it] = (n0 + n) < p.Npad ? (unsigned)((koct * p.Npad + n0 + n) * 16) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_elems, p.wgroup_bytes);
+    const unsigned b_step = 8u * (unsigned)p.Npad * 16u;          // packed-weight bytes per K-step
+
+    // walk of the K-steps: tap (ky, kx) -> source s -> 64-channel block c0; the parameters of the source being walked
+    // live in scalar registers (indexing the kernel-argument arrays per step costs two dependent scalar loads)
+    int ky = 0, kx = 0, s = 0, c0 = 0;
+    const void* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld2 = (unsigned)p.ld[0] * 2u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 2u;
+    int cur_cpg = p.cpg[0];
+
+    auto issue = [&](int stage, int step) {
+        unsigned char* sa = smem + stage * STAGE;
+        unsigned char* sb = sa + A_BYTES;
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const int tap = ky * p.W + kx;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int c = c0 + a_chunk[it] * 8;
+            const bool ok = c < cur_cpg && (unsigned)(a_by[it] + ky) < (unsigned)p.H && (unsigned)(a_bx[it] + kx) < (unsigned)p.W;
+            const unsigned off = (unsigned)(a_pix[it] + tap) * cur_ld2 + cur_chan + (unsigned)c * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + (it * NT + wave * 64) * 16), 16, ok ? off : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(sb + (it * NT + wave * 64) * 16), 16,
+                                                     b_off[it] == OOB ? OOB : b_off[it] + (unsigned)step * b_step, 0, 0, 0);
+        // advance the walk
+        c0 += 64;
+        if (c0 >= cur_cpg) {
+            c0 = 0;
+            ++s;
+            if (s == p.nsrc) {
+                s = 0;
+                ++kx;
+                if (kx == p.KW) { kx = 0; ++ky; }
+            }
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld2 = (unsigned)p.ld[s] * 2u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 2u; cur_cpg = p.cpg[s];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int i = lane & 31, h = lane >> 5;
+    // LDS byte offsets of this lane's operand reads inside a stage (kk = 0); kk advances the chunk by 2
+    int a_rd[TM], a_key[TM], b_rd[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = (wm * TM + tm) * 32 + i;
+        a_rd[tm] = row * 128;
+        a_key[tm] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b_rd[tn] = A_BYTES + ((wn * TN + tn) * 32 + i) * 16;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int step = 0; step < p.nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < p.nsteps) issue(cur ^ 1, step + 1);
+        const unsigned char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                a[tm] = *reinterpret_cast<const bf16x8*>(st + a_rd[tm] + (((2 * kk + h) ^ a_key[tm]) << 4));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                b[tn] = *reinterpret_cast<const bf16x8*>(st + b_rd[tn] + (2 * kk + h) * (BN * 16));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed (this wave's share)
+        __syncthreads();                                        // ... everybody's, and this stage's readers are done
+    }
+
+    // ---- epilogue through LDS
+    float* E = reinterpret_cast<float*>(smem) + wave * (R * LDE);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + i] = acc[tm][tn][r];
+    __syncthreads();
+    constexpr int LPR = CN / 8;            // lanes per row (8 channels each)
+    constexpr int RPP = 64 / LPR;          // rows per pass
+    const int col0 = (lane % LPR) * 8;
+    const int n = n0 + wn * CN + col0;     // first of this lane's 8 channels inside the group
+    if (n < p.Cout_g) {
+        const int co = g * p.Cout_g + n;
+        const bool full = n + 7 < p.Cout_g;
+        float bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = (p.bias && (full || n + c < p.Cout_g)) ? p.bias[co + c] : 0.f;
+        const bool vec_d = full && ((p.dst_ld | p.dst_coff | co) & 7) == 0;
+        const bool vec_r = full && p.res && ((p.res_ld | p.res_coff | co) & 7) == 0;
+        const bool vec_2 = full && p.dst2 && ((p.dst2_ld | p.dst2_coff | co) & 7) == 0;
+#pragma unroll
+        for (int ps = 0; ps < R / RPP; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int m = m0 + wm * R + row;
+            if (m >= p.M) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] += bv[c];
+            if (p.act == E2FGVI_ACT_DCNPOST) {
+                const f32x4 fl = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (long long)m * 4);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = dcn_post(v[c], co + c, p.Cout, fl, p.slope);
+            } else {
+                if (p.res) {
+                    const long long ro = (long long)m * p.res_ld + p.res_coff + co;
+                    if (p.res_bf16) {
+                        const unsigned short* rp = reinterpret_cast<const unsigned short*>(p.res) + ro;
+                        if (vec_r) {
+                            const u32x4 q = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                v[2 * c] += __builtin_bit_cast(float, q[c] << 16);
+                                v[2 * c + 1] += __builtin_bit_cast(float, q[c] & 0xFFFF0000u);
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) v[c] += bf16_bits_to_f32(rp[c]);
+                        }
+                    } else {
+                        const float* rp = reinterpret_cast<const float*>(p.res) + ro;
+                        if (vec_r) {
+                            const f32x4 q0 = *reinterpret_cast<const f32x4*>(rp), q1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { v[c] += q0[c]; v[4 + c] += q1[c]; }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) v[c] += rp[c];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+            }
+            bf16x8 hv;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) hv[c] = (__bf16)v[c];
+            const long long dof = (long long)m * p.dst_ld + p.dst_coff + co;
+            if (p.dst_bf16) {
+                __bf16* o = reinterpret_cast<__bf16*>(p.dst) + dof;
+                if (vec_d) *reinterpret_cast<bf16x8*>(o) = hv;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) o[c] = hv[c];
+                }
+            } else {
+                float* o = reinterpret_cast<float*>(p.dst) + dof;
+                if (vec_d) {
+                    f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(o) = w0;
+                    *reinterpret_cast<f32x4*>(o + 4) = w1;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) o[c] = v[c];
+                }
+            }
+            if (p.dst2) {
+                __bf16* o = p.dst2 + (long long)m * p.dst2_ld + p.dst2_coff + co;
+                if (vec_2) *reinterpret_cast<bf16x8*>(o) = hv;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) o[c] = hv[c];
+                }
+            }
+        }
+    }
+#endif
+}
+
+struct PackX {
+    int Cout, groups, KH, KW, nsrc;
+    int cpg[E2FGVI_MAX_SRC];
+    int Cout_g, Npad, Cin_g, steps_per_tap;
+    long long total, wgroup_elems;        // bf16 elements
+};
+
+bool geometry_x(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* cpg, PackX* q) {
+    if (Cout <= 0 || groups <= 0 || Cout % groups || KH <= 0 || KW <= 0 || nsrc < 1 || nsrc > E2FGVI_MAX_SRC) return false;
+    q->Cout = Cout; q->groups = groups; q->KH = KH; q->KW = KW; q->nsrc = nsrc;
+    q->Cout_g = Cout / groups;
+    q->Npad = round_up(q->Cout_g, 32);
+    q->Cin_g = 0;
+    q->steps_per_tap = 0;
+    for (int s = 0; s < E2FGVI_MAX_SRC; ++s) q->cpg[s] = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (cpg[s] <= 0 || cpg[s] % 8) return false;
+        q->cpg[s] = cpg[s];
+        q->Cin_g += cpg[s];
+        q->steps_per_tap += cdiv(cpg[s], 64);
+    }
+    q->wgroup_elems = (long long)KH * KW * q->steps_per_tap * 64 * q->Npad;
+    q->total = q->wgroup_elems * groups;
+    return true;
+}
+
+__global__ void pack_conv_weight_bf16x_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const PackX p) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.total) return;
+    const int g = (int)(idx / p.wgroup_elems);
+    long long rem = idx - (long long)g * p.wgroup_elems;
+    const int e = (int)(rem & 7);
+    rem >>= 3;
+    const int n = (int)(rem % p.Npad);
+    rem /= p.Npad;
+    const int koct = (int)(rem & 7);
+    const int step = (int)(rem >> 3);
+    const int tap = step / p.steps_per_tap;
+    int blk = step - tap * p.steps_per_tap;
+    int s = 0, prefix = 0;
+    while (blk >= (p.cpg[s] + 63) / 64) { blk -= (p.cpg[s] + 63) / 64; prefix += p.cpg[s]; ++s; }
+    const int c = blk * 64 + koct * 8 + e;
+    float v = 0.f;
+    if (c < p.cpg[s] && n < p.Cout_g)
+        v = w[((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + c) * (p.KH * p.KW) + tap];
+    wp[idx] = (__bf16)v;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_x(ConvXParams& p, int groups, hipStream_t st) {
+    p.tilesM = cdiv(p.M, BM);
+    p.tilesN = cdiv(p.Cout_g, BN);
+    hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+    E2_LAUNCH_CHECK("conv2d_bf16x");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t e2fgvi_packed_conv_weight_bf16x_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW, int32_t nsrc,
+                                                        const int32_t* src_cpg) {
+    PackX q;
+    if (!src_cpg || !geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q)) {
+        e2fgvi_set_error("packed_conv_weight_bf16x_size: bad geometry (channels per source must be multiples of 8)");
+        return E2FGVI_EINVAL;
+    }
+    return q.total;
+}
+
+extern "C" int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH,
+                                             int32_t KW, int32_t nsrc, const int32_t* src_cpg, void* stream) {
+    PackX q;
+    E2_REQUIRE(w && wpacked && src_cpg, E2FGVI_EINVAL, "pack_conv_weight_bf16x: null pointer");
+    E2_REQUIRE(geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q), E2FGVI_EINVAL, "pack_conv_weight_bf16x: bad geometry");
+    hipLaunchKernelGGL(pack_conv_weight_bf16x_kernel, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (__bf16*)wpacked, q);
+    E2_LAUNCH_CHECK("pack_conv_weight_bf16x");
+    return 0;
+}
+
+extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
+    E2_REQUIRE(d, E2FGVI_EINVAL, "conv2d_bf16x: null descriptor");
+    PackX q;
+    E2_REQUIRE(geometry_x(d->Cout, d->groups, d->KH, d->KW, d->nsrc, d->src_cpg, &q), E2FGVI_EINVAL,
+               "conv2d_bf16x: bad geometry (channels per source must be multiples of 8)");
+    E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->stride > 0 && d->pad >= 0, E2FGVI_EINVAL,
+               "conv2d_bf16x: bad sizes");
+    E2_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+               E2FGVI_EINVAL, "conv2d_bf16x: Ho/Wo inconsistent with H/W/k/stride/pad");
+    E2_REQUIRE((long long)d->N * d->Ho * d->Wo < 2147483647LL, E2FGVI_EUNSUP, "conv2d_bf16x: more than 2^31 output pixels");
+    E2_REQUIRE(d->wpacked && d->dst, E2FGVI_EINVAL, "conv2d_bf16x: null weight/dst");
+    E2_REQUIRE((d->dst_dtype == E2FGVI_F32 || d->dst_dtype == E2FGVI_BF16) && (d->res_dtype == E2FGVI_F32 || d->res_dtype == E2FGVI_BF16),
+               E2FGVI_EINVAL, "conv2d_bf16x: dtype must be E2FGVI_F32 or E2FGVI_BF16");
+    ConvXParams p;
+    for (int s = 0; s < E2FGVI_MAX_SRC; ++s) { p.src[s] = nullptr; p.ld[s] = 0; p.coff[s] = 0; p.cpg[s] = 0; p.src_bytes[s] = 0; }
+    for (int s = 0; s < d->nsrc; ++s) {
+        E2_REQUIRE(d->src[s], E2FGVI_EINVAL, "conv2d_bf16x: null source %d", s);
+        E2_REQUIRE(d->src_ld[s] % 8 == 0 && d->src_coff[s] % 8 == 0 && ((uintptr_t)d->src[s] & 15) == 0, E2FGVI_EINVAL,
+                   "conv2d_bf16x: source %d not 16-byte addressable (ld / coff multiples of 8 bf16)", s);
+        E2_REQUIRE(d->src_coff[s] + d->groups * d->src_cpg[s] <= d->src_ld[s], E2FGVI_EINVAL,
+                   "conv2d_bf16x: source %d channel range exceeds its pixel stride", s);
+        const long long bytes = (long long)d->N * d->H * d->W * d->src_ld[s] * 2;
+        E2_REQUIRE(bytes < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: source %d spans >= 4 GiB (split the batch)", s);
+        p.src[s] = d->src[s]; p.ld[s] = d->src_ld[s]; p.coff[s] = d->src_coff[s]; p.cpg[s] = d->src_cpg[s];
+        p.src_bytes[s] = (unsigned)bytes;
+    }
+    E2_REQUIRE(q.wgroup_elems * 2 < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: packed weight group >= 4 GiB");
+    E2_REQUIRE(((uintptr_t)d->wpacked & 15) == 0, E2FGVI_EINVAL, "conv2d_bf16x: packed weight not 16-byte aligned");
+    E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst slice exceeds dst_ld");
+    E2_REQUIRE(((uintptr_t)d->dst & 15) == 0 && (!d->dst2 || ((uintptr_t)d->dst2 & 15) == 0) &&
+               (!d->residual || ((uintptr_t)d->residual & 15) == 0), E2FGVI_EINVAL, "conv2d_bf16x: dst / dst2 / residual not 16-byte aligned");
+    if (d->dst2) E2_REQUIRE(d->dst2_coff >= 0 && d->dst2_coff + d->Cout <= d->dst2_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst2 slice exceeds dst2_ld");
+    if (d->act == E2FGVI_ACT_DCNPOST)
+        E2_REQUIRE(d->residual && d->res_dtype == E2FGVI_F32 && d->Cout % 3 == 0 && d->groups == 1, E2FGVI_EINVAL,
+                   "conv2d_bf16x: ACT_DCNPOST needs the fp32 [pixel][4] flows as residual, Cout %% 3 == 0, groups == 1");
+    p.nsrc = d->nsrc;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
+    p.M = d->N * d->Ho * d->Wo;
+    p.nsteps = d->KH * d->KW * q.steps_per_tap;
+    p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * 2);
+    p.w = (const __bf16*)d->wpacked; p.bias = d->bias;
+    p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff; p.res_bf16 = d->res_dtype == E2FGVI_BF16;
+    p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_bf16 = d->dst_dtype == E2FGVI_BF16;
+    p.dst2 = (__bf16*)d->dst2; p.dst2_ld = d->dst2_ld; p.dst2_coff = d->dst2_coff;
+    p.act = d->act; p.slope = d->slope;
+    hipStream_t st = (hipStream_t)stream;
+    int tile = d->tile;
+    if (!tile) {
+        if (p.Cout_g <= 32) tile = 3;
+        else if (p.Cout_g <= 64) tile = 2;
+        else tile = ((long long)cdiv(p.M, 128) * cdiv(p.Cout_g, 128) * d->groups >= 384) ? 1 : 4;
+    }
+    switch (tile) {
+        case 1: return launch_x<128, 128, 2, 2>(p, d->groups, st);
+        case 2: return launch_x<128, 64, 2, 2>(p, d->groups, st);
+        case 3: return launch_x<128, 32, 4, 1>(p, d->groups, st);
+        case 4: return launch_x<64, 128, 2, 2>(p, d->groups, st);
+        case 5: return launch_x<64, 64, 2, 2>(p, d->groups, st);
+        case 6: return launch_x<256, 128, 4, 2>(p, d->groups, st);
+        default: break;
+    }
+    e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);
+    return E2FGVI_EINVAL;
+}

@@ -106,32 +106,24 @@ class Engine:
                     PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)
-        # A convolution is linear in its input channels, so the two layers whose input is a concat of recurrent and
-        # non-recurrent features are split:  conv(cat(a, b)) = conv_a(a) + conv_b(b).  The non-recurrent part (the
-        # current frame's features; for the forward direction also the backward features of the same frame) is computed
-        # for ALL frames in one batched launch before the frame-by-frame chain starts (`*_pre`, bias included); the chain
-        # step convolves only the recurrent sources and takes that result as its residual.  Same arithmetic, one more
-        # rounding per output (fp32 sum order), a third (conv_offset.0) to two thirds (forward backbone.0) of those
-        # layers' MACs out of the 2 l_t dependent steps.
+        # (Measured and rejected in round 2: splitting conv_offset.0 / backbone.0 into a batched non-recurrent half for all
+        # frames + a per-step recurrent half.  The per-step Winograd launches are dominated by their fixed cost, not by
+        # the K loop: 42 -> 34 us and 37 -> 26 us per step, but the four extra batched launches cost 537 us -- a net loss
+        # of 170 us per forward at one clip, profiles/r02_c2_layer_fp32_base.md.)
         self.prop = {}
         for d, nparts in (("backward_", 2), ("forward_", 3)):
             p = "feat_prop_module.deform_align.%s." % d
-            # conv_offset.0 input = cat(cond_n1, cur, cond_n2, flow_1, flow_2)
-            w0, b0 = f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias")
-            w0_step = torch.cat([w0[:, :128], w0[:, 256:]], 1).contiguous()       # sources (cond|0), (cond|128), flows4
-            off = [PackedConv(w0_step, None, [128, 128, 4], pad=1, **ww),
+            # conv_offset.0 input = cat(cond_n1, cur, cond_n2, flow_1, flow_2): sources (cond|0), cur, (cond|128), flows4
+            off = [PackedConv(f(p + "conv_offset.0.weight"), f(p + "conv_offset.0.bias"), [128, 128, 128, 4], pad=1, **ww),
                    PackedConv(f(p + "conv_offset.2.weight"), f(p + "conv_offset.2.bias"), [128], pad=1, **ww),
                    PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1, **ww),
                    PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1,
                               algo=ww["algo"])]
-            off_pre = PackedConv(w0[:, 128:256].contiguous(), b0, [128], pad=1, **ww)
             dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1)
             b = "feat_prop_module.backbone.%s." % d
-            wb, bbias = f(b + "0.weight"), f(b + "0.bias")                      # input = cat(cur, [backward feat,] feat_prop)
-            bb = [PackedConv(wb[:, -128:].contiguous(), None, [128], pad=1, **ww),
+            bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **ww),
                   PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **ww)]
-            bb_pre = PackedConv(wb[:, :-128].contiguous(), bbias, [128] * (nparts - 1), pad=1, **ww)
-            self.prop[d] = (off, dcn, bb, off_pre, bb_pre)
+            self.prop[d] = (off, dcn, bb)
         self.fusion = PackedConv(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128], **pw)
 
         # ---- soft split / composite (tfocal_transformer.py:19-72)
@@ -169,6 +161,7 @@ class Engine:
             for j, cin in enumerate((8, 32, 64, 32, 16)):
                 p = "update_spynet.basic_module.%d.basic_module.%d.conv." % (lv, j)
                 convs.append(PackedConv(f(p + "weight"), f(p + "bias"), [cin], pad=3))
+                convs[-1].nopk = True      # SPyNet runs on a side stream: the build without packed-fp32 VALU (build.py)
             self.spy.append(convs)
         mean = f("update_spynet.mean").view(3)
         std = f("update_spynet.std").view(3)
@@ -183,12 +176,11 @@ class Engine:
             self.enc[k].name = "encoder.layers.%d" % i
         for k, n in enumerate(("decoder.0.conv", "decoder.2", "decoder.4.conv", "decoder.6")):
             self.dec[k].name = n
-        for d, (off, dcn, bb, off_pre, bb_pre) in self.prop.items():
+        for d, (off, dcn, bb) in self.prop.items():
             for k, c in enumerate(off):
                 c.name = "deform_align.%sconv_offset.%d" % (d, 2 * k)
             dcn.name = "deform_align.%sdcn" % d
             bb[0].name, bb[1].name = "backbone.%s0" % d, "backbone.%s2" % d
-            off_pre.name, bb_pre.name = "deform_align.%sconv_offset.0(cur, all frames)" % d, "backbone.%s0(cur, all frames)" % d
         self.fusion.name, self.ss.name, self.sc.name = "fusion", "ss.embedding", "sc.embedding"
         if self.hq:
             self.sc_bias_conv.name = "sc.bias_conv"
@@ -207,7 +199,7 @@ class Engine:
             self.ss.tune = self.sc.tune = self.fusion.tune = True
             # Winograd layers: the best block shape (16x16 / 8x16 pixels x 32 / 64 couts) depends on how many blocks the
             # call has -- one 60x108 frame per propagation step vs 10 frames in the encoder
-            for c in self.enc + self.dec + [q for off, _, bb, op, bp in self.prop.values() for q in off + bb + [op, bp]]:
+            for c in self.enc + self.dec + [q for off, _, bb in self.prop.values() for q in off + bb]:
                 if c.algo == "auto":
                     c.tune = True
             if self.hq:
@@ -308,13 +300,8 @@ class Engine:
         zero = self._zero((b, h, w, ch))
         lk = dict(act=ACT_LRELU, slope=0.1)
         for name, flows in (("backward_", flows_a), ("forward_", flows_b)):
-            off_convs, dcn, bb, off_pre, bb_pre = self.prop[name]
+            off_convs, dcn, bb = self.prop[name]
             store = torch.empty((l_t, b, h, w, ch), dtype=torch.float32, device=dev)
-            # non-recurrent halves of conv_offset.0 / backbone.0 for every frame at once (see __init__)
-            loc_all = loc.view(l_t * b, h, w, ch)
-            pre_off = off_pre([loc_all]).view(l_t, b, h, w, ch) if l_t > 1 else None
-            pre_bb = bb_pre([loc_all, feats["backward_"].view(l_t * b, h, w, ch)] if name == "forward_" else [loc_all])
-            pre_bb = pre_bb.view(l_t, b, h, w, ch)
             order = list(range(l_t))
             if name == "backward_":
                 order = order[::-1]
@@ -328,14 +315,15 @@ class Engine:
                     flow_b = flows[0, i - 2] if i > 1 else None
                     feat_n2 = hist[-2] if i > 1 else None
                     cond, fl = ops.prop_cond(feat_prop, feat_n2, flow_a, flow_b, img_stride)
-                    x = off_convs[0]([(cond, 0), (cond, ch), fl], residual=pre_off[idx], **lk)
+                    x = off_convs[0]([(cond, 0), cur, (cond, ch), fl], **lk)
                     x = off_convs[1]([x], **lk)
                     x = off_convs[2]([x], **lk)
                     # 10*tanh + flow.flip / sigmoid (feat_prop.py:38-53) applied in the epilogue of the last conv_offset
                     # layer: the deformable conv then reads finished offsets and masks
                     offs = off_convs[3]([x], residual=fl, act=ACT_DCNPOST, slope=10.0)
                     feat_prop = dcn([feat_prop, feat_n2 if feat_n2 is not None else zero], offs)
-                y = bb[0]([feat_prop], residual=pre_bb[idx], **lk)
+                srcs = [cur, feats["backward_"][idx], feat_prop] if name == "forward_" else [cur, feat_prop]
+                y = bb[0](srcs, **lk)
                 feat_prop = bb[1]([y], residual=feat_prop, out=store[idx])
                 hist.append(feat_prop)
             feats[name] = store

@@ -7,10 +7,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libe2fgvi_hip.so")
+LIB_PATH = os.environ.get("E2FGVI_LIB") or os.path.join(_HERE, "csrc", "libe2fgvi_hip.so")    # E2FGVI_LIB: A/B builds
 
 MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_DCNPOST = 0, 1, 2, 3, 4
+DT_F32, DT_BF16 = 0, 1
 
 _fp = C.c_void_p   # device pointers travel as plain addresses
 
@@ -24,6 +25,21 @@ class ConvDesc(C.Structure):
         ("groups", C.c_int32), ("Cout", C.c_int32), ("bk", C.c_int32),
         ("wpacked", _fp), ("bias", _fp), ("residual", _fp), ("res_ld", C.c_int32), ("res_coff", C.c_int32),
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("dst_nchw", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32),
+    ]
+
+
+class ConvXDesc(C.Structure):
+    _fields_ = [
+        ("src", _fp * MAX_SRC), ("src_ld", C.c_int32 * MAX_SRC), ("src_coff", C.c_int32 * MAX_SRC),
+        ("src_cpg", C.c_int32 * MAX_SRC), ("nsrc", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("groups", C.c_int32), ("Cout", C.c_int32),
+        ("wpacked", _fp), ("bias", _fp), ("residual", _fp), ("res_ld", C.c_int32), ("res_coff", C.c_int32),
+        ("res_dtype", C.c_int32),
+        ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("dst_dtype", C.c_int32),
+        ("dst2", _fp), ("dst2_ld", C.c_int32), ("dst2_coff", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32),
     ]
 
@@ -47,11 +63,15 @@ SYMBOLS = {
     "e2fgvi_last_error": (C.c_char_p, []),
     "e2fgvi_abi_version": (C.c_int, []),
     "e2fgvi_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "e2fgvi_conv2d_nhwc_nopk": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "e2fgvi_packed_conv_weight_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32]),
     "e2fgvi_pack_conv_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _fp]),
     "e2fgvi_packed_conv_weight_bf16_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_bf16": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "e2fgvi_conv2d_bf16x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
+    "e2fgvi_packed_conv_weight_bf16x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    "e2fgvi_pack_conv_weight_bf16x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_packed_winograd_weight_size": (_i64, [_i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_winograd_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_conv3x3_winograd": (C.c_int, [C.POINTER(ConvDesc), _fp]),

@@ -72,6 +72,7 @@ class PackedConv:
         self.precision = precision
         self.tune = False          # time TUNE_CANDIDATES on the first call of every new input size and keep the fastest
         self.name = "conv"         # layer name for launch traces (the engine sets the checkpoint key)
+        self.nopk = False          # True: the build without packed-fp32 VALU (side-stream launches beside bf16 MFMA tiles)
         if algo not in ("igemm", "winograd", "auto"):
             raise ValueError("algo must be 'igemm', 'winograd' or 'auto'")
         wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 4 for c in self.cpg)
@@ -249,8 +250,130 @@ class PackedConv:
             _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
         elif self.precision == "bf16":
             _L.check(lib.e2fgvi_conv2d_nhwc_bf16(C.byref(d), _stream()), "conv2d_nhwc_bf16")
+        elif self.nopk:
+            _L.check(lib.e2fgvi_conv2d_nhwc_nopk(C.byref(d), _stream()), "conv2d_nhwc_nopk")
         else:
             _L.check(lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+        return out
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return _L.DT_F32
+    if t.dtype == torch.bfloat16:
+        return _L.DT_BF16
+    raise TypeError("tensor must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _chk_any(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA (ROCm) tensor -- the HIP path has no CPU fallback" % name)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    _dt(t)
+    return t
+
+
+class PackedConvX:
+    """Conv / linear layer of the bf16 data path: bf16 NHWC sources (virtual concat, channels per source in multiples of
+    8), bf16 packed weights, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 epilogue (bias, fp32 / bf16 residual,
+    activation or the DCN offset post-processing), bf16 or fp32 result and an optional second bf16 copy (`out2`)."""
+
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0):
+        lib = _L.load()
+        if weight.dim() == 2:
+            weight = weight[:, :, None, None]
+        w = _chk(weight.detach().float().contiguous(), "weight")
+        self.Cout, cin_g, self.KH, self.KW = w.shape
+        self.cpg = [int(c) for c in cpg]
+        if sum(self.cpg) != cin_g:
+            raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
+        self.groups, self.stride, self.pad = groups, stride, pad
+        self.name = "conv"
+        arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+        n = lib.e2fgvi_packed_conv_weight_bf16x_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
+        if n < 0:
+            _L.check(int(n), "packed_conv_weight_bf16x_size")
+        self.wpacked = torch.empty(int(n), dtype=torch.bfloat16, device=w.device)
+        _L.check(lib.e2fgvi_pack_conv_weight_bf16x(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
+                                                   len(self.cpg), arr, _stream()), "pack_conv_weight_bf16x")
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+    def __call__(self, sources, out=None, out_dtype=torch.bfloat16, out_coff=0, residual=None, res_coff=0, act=ACT_NONE,
+                 slope=0.0, out2=None, tile=0):
+        lib = _L.load()
+        d = _L.ConvXDesc()
+        srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
+        if len(srcs) != len(self.cpg):
+            raise ValueError("expected %d sources, got %d" % (len(self.cpg), len(srcs)))
+        N, H, W, _ = srcs[0][0].shape
+        Ho, Wo = self.out_hw(H, W)
+        dev = srcs[0][0].device
+        if out is None:
+            out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=dev)
+        per_img = max(H * W * t.shape[3] * 2 for t, _ in srcs)
+        if N > 1 and N * per_img >= (1 << 32) - 1:                 # 32-bit buffer resources: image chunks
+            step = max(1, ((1 << 32) - 2) // per_img)
+            for n0 in range(0, N, step):
+                n1 = min(N, n0 + step)
+                self([(t[n0:n1], c) for t, c in srcs], out=out[n0:n1], out_coff=out_coff,
+                     residual=None if residual is None else residual[n0:n1], res_coff=res_coff, act=act, slope=slope,
+                     out2=None if out2 is None else out2[n0:n1], tile=tile)
+            return out
+        for i, (t, coff) in enumerate(srcs):
+            _chk(t, "source %d" % i, torch.bfloat16)
+            if t.dim() != 4 or tuple(t.shape[:3]) != (N, H, W):
+                raise ValueError("source %d shape %s does not match [%d,%d,%d,*]" % (i, tuple(t.shape), N, H, W))
+            d.src[i], d.src_ld[i], d.src_coff[i], d.src_cpg[i] = t.data_ptr(), t.shape[3], coff, self.cpg[i]
+        d.nsrc = len(srcs)
+        d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
+        d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
+        d.groups, d.Cout = self.groups, self.Cout
+        d.wpacked = self.wpacked.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        _chk_any(out, "out")
+        if out.dim() != 4 or tuple(out.shape[:3]) != (N, Ho, Wo):
+            raise ValueError("out shape %s != [%d,%d,%d,*]" % (tuple(out.shape), N, Ho, Wo))
+        d.dst, d.dst_ld, d.dst_coff, d.dst_dtype = out.data_ptr(), out.shape[3], out_coff, _dt(out)
+        if out2 is not None:
+            _chk(out2, "out2", torch.bfloat16)
+            if out2.dim() != 4 or tuple(out2.shape[:3]) != (N, Ho, Wo):
+                raise ValueError("out2 shape %s != [%d,%d,%d,*]" % (tuple(out2.shape), N, Ho, Wo))
+            d.dst2, d.dst2_ld, d.dst2_coff = out2.data_ptr(), out2.shape[3], 0
+        if residual is not None:
+            _chk_any(residual, "residual")
+            if residual.dim() != 4 or tuple(residual.shape[:3]) != (N, Ho, Wo):
+                raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
+            d.residual, d.res_ld, d.res_coff, d.res_dtype = residual.data_ptr(), residual.shape[3], res_coff, _dt(residual)
+        d.act, d.slope, d.tile = act, slope, tile
+        if _L.TRACE is not None:
+            cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
+            cin_p = sum(-(-c // 64) * 64 for c in self.cpg)
+            _L.annotate(layer=self.name, kernel="conv_bf16x tile=%d" % tile, shape="N%d %dx%d %d->%d k%d s%d g%d" % (
+                N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
+                macs=N * Ho * Wo * self.Cout * cin_g * K2,
+                issued=N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2)
+        _L.check(lib.e2fgvi_conv2d_bf16x(C.byref(d), _stream()), "conv2d_bf16x")
+        return out
+
+
+class PackedLinearX(PackedConvX):
+    """y[rows, Cout] = x[rows, Cin] @ W^T + b (+ residual) on the bf16 data path, rows treated as 1x1 images."""
+
+    def __init__(self, weight, bias):
+        super().__init__(weight, bias, [weight.shape[1]])
+
+    def __call__(self, x, out=None, out_dtype=torch.bfloat16, residual=None, act=ACT_NONE, slope=0.0, out2=None, tile=0):
+        rows = x.numel() // x.shape[-1]
+        if out is None:
+            out = torch.empty((rows, self.Cout), dtype=out_dtype, device=x.device)
+        r4 = None if residual is None else residual.view(rows, 1, 1, residual.shape[-1])
+        o2 = None if out2 is None else out2.view(rows, 1, 1, out2.shape[-1])
+        super().__call__([x.view(rows, 1, 1, x.shape[-1])], out=out.view(rows, 1, 1, out.shape[-1]), residual=r4, act=act,
+                         slope=slope, out2=o2, tile=tile)
         return out
 
 

@@ -111,6 +111,9 @@ typedef struct {
 } e2fgvi_conv_desc;
 
 int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream);
+/* The same operator from a build without packed-fp32 VALU instructions (v_pk_{mul,add,fma}_f32): for launches that run
+ * on a side stream concurrently with bf16 MFMA kernels -- SPyNet next to the encoder.  Identical results. */
+int e2fgvi_conv2d_nhwc_nopk(const e2fgvi_conv_desc* d, void* stream);
 
 /* number of floats of the packed weight buffer for the given geometry */
 int64_t e2fgvi_packed_conv_weight_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
@@ -255,6 +258,46 @@ int e2fgvi_ffn_unfold_gelu(const float* folded, float* out, int32_t F, int32_t f
 int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* residual,
                          float* dst, int32_t F, int32_t fh, int32_t fw, int32_t H, int32_t W,
                          int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 data path (BASELINE.json configs 4 / 5: e2fgvi_hq at 720p / 1080p, "bf16 MFMA").
+ * Activations live in HBM as bf16 NHWC (element (n,y,x,c) at ((n*H+y)*W+x)*ld + c, ld in ELEMENTS), weights are packed
+ * bf16, every product runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; bias / residual / activation are applied
+ * in fp32 and the result is stored as bf16 and / or fp32.  Same operators and call sites as e2fgvi_conv2d_nhwc.
+ * ---------------------------------------------------------------------------------------------- */
+#define E2FGVI_F32 0
+#define E2FGVI_BF16 1
+typedef struct {
+    const void* src[E2FGVI_MAX_SRC];   /* bf16 NHWC sources of the virtual concat                          */
+    int32_t src_ld[E2FGVI_MAX_SRC];    /* pixel stride, elements (multiple of 8)                           */
+    int32_t src_coff[E2FGVI_MAX_SRC];  /* first channel used by group 0 (multiple of 8)                    */
+    int32_t src_cpg[E2FGVI_MAX_SRC];   /* channels per group taken from this source (multiple of 8)        */
+    int32_t nsrc;
+    int32_t N, H, W, Ho, Wo;
+    int32_t KH, KW, stride, pad;
+    int32_t groups;
+    int32_t Cout;
+    const void* wpacked;               /* e2fgvi_pack_conv_weight_bf16x                                     */
+    const float* bias;                 /* fp32 [Cout] or NULL                                               */
+    const void* residual;              /* NHWC [N,Ho,Wo,*] of res_dtype, or the fp32 [P,4] flows of ACT_DCNPOST */
+    int32_t res_ld, res_coff, res_dtype;
+    void* dst;                         /* NHWC [N,Ho,Wo,dst_ld] of dst_dtype                                */
+    int32_t dst_ld, dst_coff, dst_dtype;
+    void* dst2;                        /* optional second copy of the result as bf16 NHWC, or NULL          */
+    int32_t dst2_ld, dst2_coff;
+    int32_t act;
+    float slope;
+    int32_t tile;                      /* 0 = auto                                                          */
+} e2fgvi_convx_desc;
+
+int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream);
+/* number of bf16 elements of the packed weight buffer: [group][K-step][8 k-octets][Npad][8], a K-step = 64 input
+ * channels of one (tap, source), sources padded to 64, Npad = Cout/groups rounded up to 32 */
+int64_t e2fgvi_packed_conv_weight_bf16x_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW, int32_t nsrc,
+                                             const int32_t* src_cpg);
+/* w: fp32 [Cout, sum(cpg), KH, KW] (torch OIHW) */
+int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
+                                  int32_t nsrc, const int32_t* src_cpg, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,136 @@
+"""Kernels of the bf16 data path (BASELINE.json configs 4 / 5) against torch fp32 references of the same operator on
+the SAME bf16-rounded operands: what is compared is the kernel's arithmetic (fp32 accumulation of bf16 products, fp32
+epilogue), so the tolerances are the fp32 ones (2e-5 x rms) for fp32 results and one bf16 rounding (2^-9 relative,
+<= 1e-2 x rms on O(4 rms) elements) for bf16 results."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def _act(x, act, slope):
+    from e2fgvi_amd import ops
+    if act == ops.ACT_RELU:
+        return F.relu(x)
+    if act == ops.ACT_LRELU:
+        return F.leaky_relu(x, slope)
+    if act == ops.ACT_TANH:
+        return torch.tanh(x)
+    return x
+
+
+# name, N, H, W, cpg (per source), groups, Cout, k, stride, pad, tiles
+CASES = [
+    ("3x3 128->128", 2, 20, 28, [128], 1, 128, 3, 1, 1, (0, 1, 2, 3, 4, 5, 6)),
+    ("3x3 concat 128+128+128+8 -> 128 (conv_offset.0)", 1, 12, 20, [128, 128, 128, 8], 1, 128, 3, 1, 1, (0, 1, 4)),
+    ("3x3 128 -> 432 (conv_offset.6)", 1, 10, 18, [128], 1, 432, 3, 1, 1, (0, 1, 5)),
+    ("3x3 groups 8, 32+48 -> 256 (encoder.14)", 2, 10, 12, [32, 48], 8, 256, 3, 1, 1, (0, 3, 5)),
+    ("3x3 groups 2, 128+192 -> 512 (encoder.10)", 1, 12, 12, [128, 192], 2, 512, 3, 1, 1, (0, 1)),
+    ("3x3 stride 2, 8 -> 64 (encoder.0)", 2, 24, 40, [8], 1, 64, 3, 2, 1, (0, 2)),
+    ("3x3 stride 2, 64 -> 128", 1, 22, 30, [64], 1, 128, 3, 2, 1, (0, 1)),
+    ("7x7 stride 3 pad 3, 128 -> 512 (soft split)", 2, 30, 54, [128], 1, 512, 7, 3, 3, (0, 1)),
+    ("1x1 256 -> 128 two sources (fusion)", 3, 9, 11, [128, 128], 1, 128, 1, 1, 0, (0, 1, 5)),
+    ("3x3 64 -> 24 (narrow N)", 1, 16, 16, [64], 1, 24, 3, 1, 1, (0, 3)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16x(dev, case):
+    from e2fgvi_amd import ops
+    name, N, H, W, cpg, groups, Cout, k, stride, pad, tiles = case
+    g = _gen(abs(hash(name)) % 1000)
+    cin = sum(cpg) * groups
+    w = torch.randn(Cout, sum(cpg), k, k, generator=g) / math.sqrt(sum(cpg) * k * k)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    # sources carry extra leading / trailing channels so that channel offsets and ld > C are exercised
+    srcs, parts = [], []
+    for c in cpg:
+        ld = c * groups + 16
+        t = torch.randn(N, H, W, ld, generator=g).bfloat16()
+        srcs.append(t)
+        parts.append(t[..., 8:8 + c * groups].float())
+    # virtual concat: group gi takes channels [gi*c, (gi+1)*c) of every source, in source order
+    x = torch.cat([torch.cat([p_[..., gi * c:(gi + 1) * c] for p_, c in zip(parts, cpg)], -1) for gi in range(groups)], -1)
+    wq = w.bfloat16().float()
+    ref0 = F.conv2d(nchw(x), wq, bias, stride=stride, padding=pad, groups=groups)
+    layer = ops.PackedConvX(w.to(dev), bias.to(dev), cpg, groups=groups, stride=stride, pad=pad)
+    src_d = [(s.to(dev), 8) for s in srcs]
+    res32 = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
+    res16 = res32.bfloat16()
+    for tile in tiles:
+        out = layer(src_d, out_dtype=torch.float32, act=ops.ACT_LRELU, slope=0.1, tile=tile)
+        assert_close(nchw(out.cpu()), F.leaky_relu(ref0, 0.1), 3e-5, "%s tile %d fp32 out" % (name, tile))
+    out2 = torch.empty(N, ref0.shape[2], ref0.shape[3], Cout, dtype=torch.bfloat16, device=dev)
+    out = layer(src_d, out_dtype=torch.float32, residual=res32.to(dev), act=ops.ACT_NONE, out2=out2)
+    ref = ref0 + nchw(res32)
+    assert_close(nchw(out.cpu()), ref, 3e-5, name + " fp32 residual")
+    assert torch.equal(out2.cpu(), out.cpu().bfloat16()), name + ": out2 is not the bf16 rounding of out"
+    out = layer(src_d, residual=res16.to(dev), act=ops.ACT_RELU)
+    assert out.dtype == torch.bfloat16
+    assert_close(nchw(out.float().cpu()), F.relu(ref0 + nchw(res16.float())), 1e-2, name + " bf16 out, bf16 residual")
+    # into a channel slice of a wider destination
+    wide = torch.zeros(N, ref0.shape[2], ref0.shape[3], Cout + 24, dtype=torch.bfloat16, device=dev)
+    layer(src_d, out=wide, out_coff=8)
+    assert_close(nchw(wide[..., 8:8 + Cout].float().cpu()), ref0, 1e-2, name + " slice store")
+    assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + Cout:].abs().max()) == 0
+
+
+def test_linear_bf16x(dev):
+    from e2fgvi_amd import ops
+    g = _gen(5)
+    for rows, cin, cout in ((7200, 512, 1536), (1000, 1960, 512), (333, 512, 6272), (130, 6272, 512)):
+        w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
+        b = torch.randn(cout, generator=g) * 0.1
+        x = torch.randn(rows, cin, generator=g).bfloat16()
+        res = torch.randn(rows, cout, generator=g)
+        layer = ops.PackedLinearX(w.to(dev), b.to(dev))
+        ref = F.linear(x.float(), w.bfloat16().float(), b) + res
+        out = layer(x.to(dev), out_dtype=torch.float32, residual=res.to(dev))
+        assert_close(out.cpu(), ref, 3e-5, "linear %dx%d->%d" % (rows, cin, cout))
+        out16 = layer(x.to(dev))
+        assert_close(out16.float().cpu(), ref - res, 1e-2, "linear bf16 out")
+
+
+def test_conv_bf16x_dcn_postprocess(dev):
+    """conv_offset's last layer with the offset / mask post-processing of feat_prop.py:38-53 in the epilogue"""
+    from e2fgvi_amd import ops
+    g = _gen(9)
+    N, H, W, dg = 1, 12, 20, 16
+    x = torch.randn(N, H, W, 128, generator=g).bfloat16()
+    w = torch.randn(27 * dg, 128, 3, 3, generator=g) * (0.3 / math.sqrt(128 * 9))
+    b = torch.randn(27 * dg, generator=g) * 0.2
+    fl = torch.randn(N, H, W, 4, generator=g) * 3
+    raw = F.conv2d(nchw(x.float()), w.bfloat16().float(), b, padding=1)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    f1, f2 = nchw(fl)[:, :2], nchw(fl)[:, 2:]
+    off = 10 * torch.tanh(torch.cat([o1, o2], 1))
+    q1, q2 = torch.chunk(off, 2, 1)
+    ref = torch.cat([q1 + f1.flip(1).repeat(1, q1.shape[1] // 2, 1, 1), q2 + f2.flip(1).repeat(1, q2.shape[1] // 2, 1, 1),
+                     torch.sigmoid(m)], 1)
+    layer = ops.PackedConvX(w.to(dev), b.to(dev), [128], pad=1)
+    for tile in (0, 1, 5):
+        out = layer([x.to(dev)], out_dtype=torch.float32, residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0, tile=tile)
+        assert_close(nchw(out.cpu()), ref, 5e-5, "dcn post tile %d" % tile)
+
+
+def test_conv_bf16x_argument_errors(dev):
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.lib import HipError
+    with pytest.raises(HipError):
+        ops.PackedConvX(torch.randn(32, 12, 3, 3, device=dev), None, [12], pad=1)            # channels not a multiple of 8
+    layer = ops.PackedConvX(torch.randn(32, 16, 3, 3, device=dev), None, [16], pad=1)
+    with pytest.raises(TypeError):
+        layer([torch.randn(1, 8, 8, 16, device=dev)])                                       # fp32 source
+    with pytest.raises(HipError):
+        layer([torch.randn(1, 8, 8, 20, device=dev).bfloat16()])                            # ld not a multiple of 8

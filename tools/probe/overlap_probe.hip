@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void spin_valu(float* sink, int iters) {
 typedef int (*conv_fn)(const e2fgvi_conv_desc*, void*);
 typedef int64_t (*size_bf_fn)(int32_t, int32_t, int32_t, int32_t, int32_t, const int32_t*);
 typedef int (*pack_bf_fn)(const float*, void*, int32_t, int32_t, int32_t, int32_t, int32_t, const int32_t*, void*);
+typedef int (*convx_fn)(const e2fgvi_convx_desc*, void*);
 typedef int64_t (*size_fn)(int32_t, int32_t, int32_t, int32_t, int32_t, const int32_t*, int32_t);
 typedef int (*pack_fn)(const float*, float*, int32_t, int32_t, int32_t, int32_t, int32_t, const int32_t*, int32_t, void*);
 
@@ -210,6 +211,9 @@ int main(int argc, char** argv) {
     pack_bf_fn pack_bf = (pack_bf_fn)dlsym(L, "e2fgvi_pack_conv_weight_bf16");
     size_fn size_f = (size_fn)dlsym(L, "e2fgvi_packed_conv_weight_size");
     pack_fn pack_f = (pack_fn)dlsym(L, "e2fgvi_pack_conv_weight");
+    convx_fn conv_x = (convx_fn)dlsym(L, "e2fgvi_conv2d_bf16x");
+    size_bf_fn size_x = (size_bf_fn)dlsym(L, "e2fgvi_packed_conv_weight_bf16x_size");
+    pack_bf_fn pack_x = (pack_bf_fn)dlsym(L, "e2fgvi_pack_conv_weight_bf16x");
     hipStream_t sa, sb;
     CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
 
@@ -244,6 +248,18 @@ int main(int argc, char** argv) {
     d.src[0] = x0; d.src[1] = x1; d.src_ld[0] = 256; d.src_ld[1] = 384; d.src_cpg[0] = 128; d.src_cpg[1] = 192; d.nsrc = 2;
     d.N = cN; d.H = cH; d.W = cW; d.Ho = cH; d.Wo = cW; d.KH = 3; d.KW = 3; d.stride = 1; d.pad = 1; d.groups = groups; d.Cout = Cout; d.bk = 32;
     d.dst = cout; d.dst_ld = Cout; d.act = 2; d.slope = 0.2f;
+    // the bf16-data-path kernel (bf16 sources; contents irrelevant: the fp32 buffers are re-read as bf16 with half the ld)
+    e2fgvi_convx_desc dx; memset(&dx, 0, sizeof(dx));
+    void* wpx = nullptr; float* coutx = nullptr;
+    if (conv_x) {
+        const int64_t nx = size_x(Cout, groups, 3, 3, 2, cpg);
+        CK(hipMalloc(&wpx, nx * 2)); CK(hipMalloc(&coutx, (size_t)cN * cH * cW * Cout * 4));
+        if (pack_x(wraw, wpx, Cout, groups, 3, 3, 2, cpg, 0)) { printf("pack_x failed\n"); return 1; }
+        CK(hipDeviceSynchronize());
+        dx.src[0] = x0; dx.src[1] = x1; dx.src_ld[0] = 256; dx.src_ld[1] = 384; dx.src_cpg[0] = 128; dx.src_cpg[1] = 192; dx.nsrc = 2;
+        dx.N = cN; dx.H = cH; dx.W = cW; dx.Ho = cH; dx.Wo = cW; dx.KH = 3; dx.KW = 3; dx.stride = 1; dx.pad = 1; dx.groups = groups; dx.Cout = Cout;
+        dx.wpacked = wpx; dx.dst = coutx; dx.dst_ld = Cout; dx.dst_dtype = 0; dx.act = 2; dx.slope = 0.2f;
+    }
     float* sink; CK(hipMalloc(&sink, 4));
     float* big; CK(hipMalloc(&big, (size_t)(1 << 24) * 4 + 4096)); CK(hipMemset(big, 0, (size_t)(1 << 24) * 4 + 4096));
 
@@ -271,6 +287,8 @@ int main(int argc, char** argv) {
             case 9: d.wpacked = (const float*)wpb; d.tile = 3; for (int k = 0; k < 6; ++k) conv_bf16(&d, st); break;
             case 10: hipLaunchKernelGGL(mfma_lds_aggr<1>, dim3(512), dim3(256), 0, st, big, sink, 6000); break;
             case 11: hipLaunchKernelGGL(mfma_lds_aggr<2>, dim3(512), dim3(256), 0, st, big, sink, 6000); break;
+            case 13: if (conv_x) { dx.tile = 1; for (int k = 0; k < 8; ++k) conv_x(&dx, st); } break;
+            case 14: if (conv_x) { dx.tile = 2; for (int k = 0; k < 8; ++k) conv_x(&dx, st); } break;
             case 12: hipLaunchKernelGGL(mfma_lds_aggr<3>, dim3(512), dim3(256), 0, st, big, sink, 6000); break;
             default: break;
         }
@@ -278,8 +296,9 @@ int main(int argc, char** argv) {
     const char* an[] = {"none", "bf16 conv tile 5 (product)", "bf16 conv tile 2 (product)", "mfma bf16 32x32x16 spin (registers only)",
                         "mfma f32 32x32x2 spin (registers only)", "VALU spin", "fp32 conv (product)", "bf16 conv tile 1 (product)",
                         "bf16 conv tile 6 (product)", "bf16 conv tile 3 (product)", "2x2 mfma bf16 + ds_read_b128",
-                        "2x2 mfma bf16 + ds_read + cvt_pk/ds_write", "2x2 mfma bf16 + ds_read + cvt/ds_write + loads"};
-    const int NA = 12;
+                        "2x2 mfma bf16 + ds_read + cvt_pk/ds_write", "2x2 mfma bf16 + ds_read + cvt/ds_write + loads",
+                        "bf16x conv tile 1 (128x128, LDS-DMA)", "bf16x conv tile 2 (128x64, LDS-DMA)"};
+    const int NA = 14;
     const char* vn[] = {"V0 product body", "V1 +vmcnt(0)", "V2 +vmcnt(0)+nops", "V3 nontemporal loads", "V4 no packed f32"};
     std::vector<float> got(out_n), ref(out_n);
     // how long do the aggressors run? (one timing each)
