@@ -36,7 +36,7 @@ struct DcnParams {
     float max_residue;
     const float* w;
     const float* bias;
-    float* dst; int dst_ld, dst_coff;
+    float* dst; int dst_ld, dst_coff, dst_bf16;
     int tilesM, tilesN;
     int units0;            // units (of 16 channels x tap) that live in source 0
     unsigned src_bytes[2], off_bytes, msk_bytes, flw_bytes, w_bytes;
@@ -358,7 +358,11 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int m = m0 + (wm * TM + tm) * 32 + row;
-                if (m < p.M) p.dst[(long long)m * p.dst_ld + p.dst_coff + n] = acc[tm][tn][r] + bv;
+                if (m < p.M) {
+                    const long long o = (long long)m * p.dst_ld + p.dst_coff + n;
+                    if (p.dst_bf16) reinterpret_cast<__bf16*>(p.dst)[o] = (__bf16)(acc[tm][tn][r] + bv);
+                    else p.dst[o] = acc[tm][tn][r] + bv;
+                }
             }
     }
 }
@@ -459,7 +463,7 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     p.off = d->offset; p.off_ld = d->off_ld; p.msk = d->mask; p.msk_ld = d->mask_ld;
     p.flows = d->flows; p.max_residue = d->max_residue;
     p.w = d->wpacked; p.bias = d->bias;
-    p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff;
+    p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_bf16 = d->dst_dtype == E2FGVI_BF16;
     // buffer bounds (all < 4 GiB) and the source split
     {
         const long long P = (long long)d->N * d->Ho * d->Wo;

@@ -8,8 +8,28 @@ namespace {
 
 constexpr int NTH = 256;
 
+// 4 consecutive channels as fp32, from / to fp32 (16 bytes) or bf16 (8 bytes) tensors -- the bf16 data path
+// (BASELINE.json configs 4 / 5) keeps its activations in HBM as bf16, every kernel here computes in fp32
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
+    const u32x2 q = *reinterpret_cast<const u32x2*>(p);
+    f32x4 v = {__builtin_bit_cast(float, q[0] << 16), __builtin_bit_cast(float, q[0] & 0xFFFF0000u),
+               __builtin_bit_cast(float, q[1] << 16), __builtin_bit_cast(float, q[1] & 0xFFFF0000u)};
+    return v;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
+    bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = h;
+}
+
 // ------------------------------------------------------------------------------------------ layout
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int ld,
+template <typename TO>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, TO* __restrict__ dst, int C, int HW, int ld,
                                     float scale, float shift) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z;
@@ -21,7 +41,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
         const int p = p0 + r, c = c0 + threadIdx.x;
-        if (p < HW && c < ld) dst[((long long)n * HW + p) * ld + c] = (c < C) ? tile[threadIdx.x][r] : 0.f;
+        if (p < HW && c < ld) dst[((long long)n * HW + p) * ld + c] = (TO)((c < C) ? tile[threadIdx.x][r] : 0.f);
     }
 }
 
@@ -82,7 +102,8 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ src, int src_nc
 }
 
 // NHWC -> NHWC, 4 channels per thread (16-byte loads/stores): the decoder's x2 upsample moves 130-400 MB per call
-__global__ void resize_bilinear_vec4_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
+template <typename T>
+__global__ void resize_bilinear_vec4_kernel(const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld,
                                             int N, int C4, int H, int W, int Ho, int Wo, int align, float sh, float sw,
                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                             long long total) {
@@ -99,15 +120,15 @@ __global__ void resize_bilinear_vec4_kernel(const float* __restrict__ src, int s
     src_index(oy, sh, align, H, y0, y1, ly);
     src_index(ox, sw, align, W, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* b = src + (long long)n * H * W * src_ld + c4 * 4;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((long long)y0 * W + x0) * src_ld);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((long long)y0 * W + x1) * src_ld);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((long long)y1 * W + x0) * src_ld);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((long long)y1 * W + x1) * src_ld);
+    const T* b = src + (long long)n * H * W * src_ld + c4 * 4;
+    const f32x4 v00 = ld4(b + ((long long)y0 * W + x0) * src_ld);
+    const f32x4 v01 = ld4(b + ((long long)y0 * W + x1) * src_ld);
+    const f32x4 v10 = ld4(b + ((long long)y1 * W + x0) * src_ld);
+    const f32x4 v11 = ld4(b + ((long long)y1 * W + x1) * src_ld);
     f32x4 v = (v00 * hx + v01 * lx) * hy + (v10 * hx + v11 * lx) * ly;
     if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c4 * 4);
     if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + c4 * 4);
-    *reinterpret_cast<f32x4*>(dst + (((long long)n * Ho + oy) * Wo + ox) * dst_ld + c4 * 4) = v;
+    st4(dst + (((long long)n * Ho + oy) * Wo + ox) * dst_ld + c4 * 4, v);
 }
 
 __global__ void avgpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, long long total) {
@@ -198,10 +219,11 @@ __device__ __forceinline__ Bil bil_zeros(float px, float py, int H, int W) {
 }
 
 // thread = (pixel, 4-channel chunk); C/4 threads per pixel
+template <typename TC>
 __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const float* __restrict__ f2, int f2_ld,
                                  const float* __restrict__ flow_a, const float* __restrict__ flow_b,
-                                 long long flow_img_stride, float* __restrict__ cond, float* __restrict__ flows, int N,
-                                 int H, int W, int C) {
+                                 long long flow_img_stride, TC* __restrict__ cond, float* __restrict__ flows,
+                                 __bf16* __restrict__ flows8, int N, int H, int W, int C) {
     const int cq = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * H * W * cq) return;
@@ -237,20 +259,25 @@ __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const 
                      *reinterpret_cast<const f32x4*>(s1 + b1.o01 * fp_ld) * b1.w01 +
                      *reinterpret_cast<const f32x4*>(s1 + b1.o10 * fp_ld) * b1.w10 +
                      *reinterpret_cast<const f32x4*>(s1 + b1.o11 * fp_ld) * b1.w11;
-    float* co = cond + pix * (2 * C);
-    *reinterpret_cast<f32x4*>(co + c4 * 4) = c1;
-    *reinterpret_cast<f32x4*>(co + C + c4 * 4) = c2;
+    TC* co = cond + pix * (2 * C);
+    st4(co + c4 * 4, c1);
+    st4(co + C + c4 * 4, c2);
     if (c4 == 0) {
         f32x4 fo = {f1.x, f1.y, fl2.x, fl2.y};
         *reinterpret_cast<f32x4*>(flows + pix * 4) = fo;
+        if (flows8) {                      // the same four values as a bf16 conv source, padded to 8 channels
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            st4(flows8 + pix * 8, fo);
+            st4(flows8 + pix * 8 + 4, z4);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm
 // one wave per row; C = 256 * VPL
-template <int VPL>
+template <int VPL, typename TO>
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* __restrict__ y, long long rows, int C) {
+                                 const float* __restrict__ beta, TO* __restrict__ y, long long rows, int C) {
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -274,18 +301,19 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = 1.f / sqrtf(q / (float)C + 1e-5f);
-    float* yr = y + row * C;
+    TO* yr = y + row * C;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (i * 64 + lane) * 4);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + (i * 64 + lane) * 4);
-        *reinterpret_cast<f32x4*>(yr + (i * 64 + lane) * 4) = v[i] * rstd * g + bb;
+        st4(yr + (i * 64 + lane) * 4, v[i] * rstd * g + bb);
     }
 }
 
 // ------------------------------------------------------------------------------------------ window pooling
-__global__ void window_pool_kernel(const float* __restrict__ x, const float* __restrict__ w45,
-                                   const float* __restrict__ bias1, float* __restrict__ pooled, int BT, int fh, int fw,
+template <typename T>
+__global__ void window_pool_kernel(const T* __restrict__ x, const float* __restrict__ w45,
+                                   const float* __restrict__ bias1, T* __restrict__ pooled, int BT, int fh, int fw,
                                    int C) {
     const int cq = C / 4;
     const int nWw = fw / 9, nWh = fh / 5;
@@ -301,10 +329,10 @@ __global__ void window_pool_kernel(const float* __restrict__ x, const float* __r
     f32x4 acc = {b, b, b, b};
     for (int py = 0; py < 5; ++py)
         for (int px = 0; px < 9; ++px) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((bt * fh + wy * 5 + py) * fw + wx * 9 + px) * C + c4 * 4);
+            const f32x4 v = ld4(x + ((bt * fh + wy * 5 + py) * fw + wx * 9 + px) * C + c4 * 4);
             acc = acc + v * w45[py * 9 + px];
         }
-    *reinterpret_cast<f32x4*>(pooled + idx * 4) = acc;
+    st4(pooled + idx * 4, acc);
 }
 
 // ------------------------------------------------------------------------------------------ fold / unfold (7,3,3)
@@ -317,9 +345,9 @@ __device__ __forceinline__ void fold_range(int Y, int L, int& l_lo, int& l_hi) {
     l_hi = min((Y + 3) / 3, L - 1);
 }
 
-template <bool NORMALISE>
-__global__ void fold_kernel(const float* __restrict__ emb, const float* __restrict__ bias_hwc,
-                            const float* __restrict__ residual, float* __restrict__ dst, int F, int fh, int fw, int H,
+template <bool NORMALISE, typename TE, typename TR, typename TD>
+__global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict__ bias_hwc,
+                            const TR* __restrict__ residual, TD* __restrict__ dst, int F, int fh, int fw, int H,
                             int W, int C) {
     const int cq = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,7 +367,7 @@ __global__ void fold_kernel(const float* __restrict__ emb, const float* __restri
         const int ki = Y + 3 - 3 * ly;
         for (int lx = lx0; lx <= lx1; ++lx) {
             const int kj = X + 3 - 3 * lx;
-            acc = acc + *reinterpret_cast<const f32x4*>(emb + ((f * fh + ly) * fw + lx) * row_len + (ki * 7 + kj) * C + c4 * 4);
+            acc = acc + ld4(emb + ((f * fh + ly) * fw + lx) * row_len + (ki * 7 + kj) * C + c4 * 4);
         }
     }
     if (NORMALISE) {
@@ -348,13 +376,14 @@ __global__ void fold_kernel(const float* __restrict__ emb, const float* __restri
     }
     const long long o = ((f * H + Y) * W + X) * C + c4 * 4;
     if (bias_hwc) acc = acc + *reinterpret_cast<const f32x4*>(bias_hwc + ((long long)Y * W + X) * C + c4 * 4);
-    if (residual) acc = acc + *reinterpret_cast<const f32x4*>(residual + o);
-    *reinterpret_cast<f32x4*>(dst + o) = acc;
+    if (residual) acc = acc + ld4(residual + o);
+    st4(dst + o, acc);
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-__global__ void unfold_gelu_kernel(const float* __restrict__ folded, float* __restrict__ out, int F, int fh, int fw,
+template <typename T>
+__global__ void unfold_gelu_kernel(const T* __restrict__ folded, T* __restrict__ out, int F, int fh, int fw,
                                    int H, int W, int C) {
     const int cq = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,24 +399,41 @@ __global__ void unfold_gelu_kernel(const float* __restrict__ folded, float* __re
     const int Y = 3 * ly - 3 + tap / 7, X = 3 * lx - 3 + tap % 7;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (Y >= 0 && Y < H && X >= 0 && X < W) {
-        v = *reinterpret_cast<const f32x4*>(folded + ((f * H + Y) * W + X) * C + c4 * 4);
+        v = ld4(folded + ((f * H + Y) * W + X) * C + c4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
     }
-    *reinterpret_cast<f32x4*>(out + idx * 4) = v;
+    st4(out + idx * 4, v);
+}
+
+// fp32 <-> bf16 element conversion (4 elements per thread)
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, long long n4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n4) st4(dst + idx * 4, ld4(src + idx * 4));
 }
 
 inline unsigned blocks_for(long long total) { return (unsigned)cdiv64(total, NTH); }
 
 }  // namespace
 
-extern "C" int e2fgvi_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
-                                   float scale, float shift, void* stream) {
-    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, E2FGVI_EINVAL, "nchw_to_nhwc: bad arguments");
+#define E2_DT_OK(dt) ((dt) == E2FGVI_F32 || (dt) == E2FGVI_BF16)
+
+extern "C" int e2fgvi_nchw_to_nhwc_x(const float* src, void* dst, int32_t dst_dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                                     int32_t ld, float scale, float shift, void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C && E2_DT_OK(dst_dtype), E2FGVI_EINVAL,
+               "nchw_to_nhwc: bad arguments");
     dim3 grid(cdiv(H * W, 32), cdiv(ld, 32), N), block(32, 8);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, src, dst, C, H * W, ld, scale, shift);
+    if (dst_dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, src, (__bf16*)dst, C, H * W, ld, scale, shift);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, (hipStream_t)stream, src, (float*)dst, C, H * W, ld, scale, shift);
     E2_LAUNCH_CHECK("nchw_to_nhwc");
     return 0;
+}
+extern "C" int e2fgvi_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld,
+                                   float scale, float shift, void* stream) {
+    return e2fgvi_nchw_to_nhwc_x(src, dst, E2FGVI_F32, N, C, H, W, ld, scale, shift, stream);
 }
 
 extern "C" int e2fgvi_nhwc_to_nchw(const float* src, int32_t ld, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -399,13 +445,7 @@ extern "C" int e2fgvi_nhwc_to_nchw(const float* src, int32_t ld, float* dst, int
     return 0;
 }
 
-extern "C" int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_t src_ld, float* dst, int32_t dst_ld,
-                                      int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                                      int32_t align_corners, const float* scale, const float* shift, void* stream) {
-    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && dst_ld >= C &&
-                   (src_nchw || src_ld >= C),
-               E2FGVI_EINVAL, "resize_bilinear: bad arguments");
-    float sh, sw;
+static void resize_scales(int H, int W, int Ho, int Wo, int align_corners, float& sh, float& sw) {
     if (align_corners) {
         sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
         sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -413,11 +453,21 @@ extern "C" int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_
         sh = (float)H / (float)Ho;
         sw = (float)W / (float)Wo;
     }
+}
+
+extern "C" int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_t src_ld, float* dst, int32_t dst_ld,
+                                      int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                      int32_t align_corners, const float* scale, const float* shift, void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && dst_ld >= C &&
+                   (src_nchw || src_ld >= C),
+               E2FGVI_EINVAL, "resize_bilinear: bad arguments");
+    float sh, sw;
+    resize_scales(H, W, Ho, Wo, align_corners, sh, sw);
     const bool vec = !src_nchw && C % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 &&
                      (!scale || ((uintptr_t)scale & 15) == 0) && (!shift || ((uintptr_t)shift & 15) == 0);
     if (vec) {
         const long long total4 = (long long)N * Ho * Wo * (C / 4);
-        hipLaunchKernelGGL(resize_bilinear_vec4_kernel, dim3(blocks_for(total4)), dim3(NTH), 0, (hipStream_t)stream, src,
+        hipLaunchKernelGGL(resize_bilinear_vec4_kernel<float>, dim3(blocks_for(total4)), dim3(NTH), 0, (hipStream_t)stream, src,
                            src_ld, dst, dst_ld, N, C / 4, H, W, Ho, Wo, align_corners, sh, sw, scale, shift, total4);
         E2_LAUNCH_CHECK("resize_bilinear_vec4");
         return 0;
@@ -426,6 +476,21 @@ extern "C" int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src, src_nchw,
                        src_ld, dst, dst_ld, N, C, H, W, Ho, Wo, align_corners, sh, sw, scale, shift, total);
     E2_LAUNCH_CHECK("resize_bilinear");
+    return 0;
+}
+
+extern "C" int e2fgvi_resize_bilinear_bf16(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int32_t N, int32_t C,
+                                           int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && dst_ld >= C && src_ld >= C && C % 4 == 0 &&
+                   src_ld % 4 == 0 && dst_ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0,
+               E2FGVI_EINVAL, "resize_bilinear_bf16: bad arguments (NHWC bf16, channels in multiples of 4)");
+    float sh, sw;
+    resize_scales(H, W, Ho, Wo, align_corners, sh, sw);
+    const long long total4 = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(resize_bilinear_vec4_kernel<__bf16>, dim3(blocks_for(total4)), dim3(NTH), 0, (hipStream_t)stream,
+                       (const __bf16*)src, src_ld, (__bf16*)dst, dst_ld, N, C / 4, H, W, Ho, Wo, align_corners, sh, sw,
+                       (const float*)nullptr, (const float*)nullptr, total4);
+    E2_LAUNCH_CHECK("resize_bilinear_bf16");
     return 0;
 }
 
@@ -451,45 +516,76 @@ extern "C" int e2fgvi_spynet_level_input(const float* pyr, const int32_t* ref_id
     return 0;
 }
 
-extern "C" int e2fgvi_prop_cond(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,
-                                const float* flow_a, const float* flow_b, int64_t flow_img_stride, float* cond,
-                                float* flows, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
-    E2_REQUIRE(feat_prop && flow_a && cond && flows && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && fp_ld % 4 == 0,
+extern "C" int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,
+                                  const float* flow_a, const float* flow_b, int64_t flow_img_stride, void* cond,
+                                  int32_t cond_dtype, float* flows, void* flows8_bf16, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, void* stream) {
+    E2_REQUIRE(feat_prop && flow_a && cond && flows && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && fp_ld % 4 == 0 &&
+                   E2_DT_OK(cond_dtype),
                E2FGVI_EINVAL, "prop_cond: bad arguments");
     E2_REQUIRE(!flow_b || (feat_n2 && f2_ld % 4 == 0), E2FGVI_EINVAL, "prop_cond: flow_b needs feat_n2");
     const long long total = (long long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(prop_cond_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
-                       feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, cond, flows, N, H, W, C);
+    if (cond_dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL(prop_cond_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
+                           feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, (__bf16*)cond, flows,
+                           (__bf16*)flows8_bf16, N, H, W, C);
+    else
+        hipLaunchKernelGGL(prop_cond_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
+                           feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, (float*)cond, flows,
+                           (__bf16*)flows8_bf16, N, H, W, C);
     E2_LAUNCH_CHECK("prop_cond");
     return 0;
 }
+extern "C" int e2fgvi_prop_cond(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,
+                                const float* flow_a, const float* flow_b, int64_t flow_img_stride, float* cond,
+                                float* flows, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    return e2fgvi_prop_cond_x(feat_prop, fp_ld, feat_n2, f2_ld, flow_a, flow_b, flow_img_stride, cond, E2FGVI_F32, flows,
+                              nullptr, N, H, W, C, stream);
+}
 
-extern "C" int e2fgvi_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t C,
-                                void* stream) {
-    E2_REQUIRE(x && gamma && beta && y && rows > 0, E2FGVI_EINVAL, "layernorm: bad arguments");
-    E2_REQUIRE(C == 256 || C == 512 || C == 768 || C == 1024, E2FGVI_EUNSUP, "layernorm: C must be 256/512/768/1024");
+template <typename TO>
+static int layernorm_launch(const float* x, const float* gamma, const float* beta, TO* y, int64_t rows, int32_t C, hipStream_t st) {
     const int wpb = 4;
     dim3 grid((unsigned)cdiv64(rows, wpb)), block(64 * wpb);
-    hipStream_t st = (hipStream_t)stream;
     switch (C / 256) {
-        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
-        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
-        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
-        default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        case 1: hipLaunchKernelGGL((layernorm_kernel<1, TO>), grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<2, TO>), grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<3, TO>), grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
+        default: hipLaunchKernelGGL((layernorm_kernel<4, TO>), grid, block, 0, st, x, gamma, beta, y, (long long)rows, C); break;
     }
     E2_LAUNCH_CHECK("layernorm");
     return 0;
 }
+extern "C" int e2fgvi_layernorm_x(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype, int64_t rows,
+                                  int32_t C, void* stream) {
+    E2_REQUIRE(x && gamma && beta && y && rows > 0 && E2_DT_OK(y_dtype), E2FGVI_EINVAL, "layernorm: bad arguments");
+    E2_REQUIRE(C == 256 || C == 512 || C == 768 || C == 1024, E2FGVI_EUNSUP, "layernorm: C must be 256/512/768/1024");
+    return y_dtype == E2FGVI_BF16 ? layernorm_launch(x, gamma, beta, (__bf16*)y, rows, C, (hipStream_t)stream)
+                                  : layernorm_launch(x, gamma, beta, (float*)y, rows, C, (hipStream_t)stream);
+}
+extern "C" int e2fgvi_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t C,
+                                void* stream) {
+    return e2fgvi_layernorm_x(x, gamma, beta, y, E2FGVI_F32, rows, C, stream);
+}
 
-extern "C" int e2fgvi_window_pool(const float* x, const float* w45, const float* bias1, float* pooled, int32_t BT,
-                                  int32_t fh, int32_t fw, int32_t C, void* stream) {
-    E2_REQUIRE(x && w45 && bias1 && pooled && BT > 0 && fh > 0 && fw > 0 && fh % 5 == 0 && fw % 9 == 0 && C % 4 == 0,
+extern "C" int e2fgvi_window_pool_x(const void* x, int32_t dtype, const float* w45, const float* bias1, void* pooled,
+                                    int32_t BT, int32_t fh, int32_t fw, int32_t C, void* stream) {
+    E2_REQUIRE(x && w45 && bias1 && pooled && BT > 0 && fh > 0 && fw > 0 && fh % 5 == 0 && fw % 9 == 0 && C % 4 == 0 &&
+                   E2_DT_OK(dtype),
                E2FGVI_EINVAL, "window_pool: bad arguments");
     const long long total = (long long)BT * (fh / 5) * (fw / 9) * (C / 4);
-    hipLaunchKernelGGL(window_pool_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, x, w45, bias1, pooled,
-                       BT, fh, fw, C);
+    if (dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL(window_pool_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const __bf16*)x, w45, bias1, (__bf16*)pooled, BT, fh, fw, C);
+    else
+        hipLaunchKernelGGL(window_pool_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const float*)x, w45, bias1, (float*)pooled, BT, fh, fw, C);
     E2_LAUNCH_CHECK("window_pool");
     return 0;
+}
+extern "C" int e2fgvi_window_pool(const float* x, const float* w45, const float* bias1, float* pooled, int32_t BT,
+                                  int32_t fh, int32_t fw, int32_t C, void* stream) {
+    return e2fgvi_window_pool_x(x, E2FGVI_F32, w45, bias1, pooled, BT, fh, fw, C, stream);
 }
 
 static int check_fold(const char* name, int F, int fh, int fw, int H, int W, int C) {
@@ -499,26 +595,42 @@ static int check_fold(const char* name, int F, int fh, int fw, int H, int W, int
     return 0;
 }
 
-extern "C" int e2fgvi_ffn_fold(const float* hid, float* folded, int32_t F, int32_t fh, int32_t fw, int32_t H, int32_t W,
-                               int32_t C, void* stream) {
-    E2_REQUIRE(hid && folded, E2FGVI_EINVAL, "ffn_fold: null pointer");
+extern "C" int e2fgvi_ffn_fold_x(const void* hid, void* folded, int32_t dtype, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                                 int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(hid && folded && E2_DT_OK(dtype), E2FGVI_EINVAL, "ffn_fold: bad arguments");
     if (int rc = check_fold("ffn_fold", F, fh, fw, H, W, C)) return rc;
     const long long total = (long long)F * H * W * (C / 4);
-    hipLaunchKernelGGL(fold_kernel<true>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, hid,
-                       (const float*)nullptr, (const float*)nullptr, folded, F, fh, fw, H, W, C);
+    if (dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL((fold_kernel<true, __bf16, __bf16, __bf16>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const __bf16*)hid, (const float*)nullptr, (const __bf16*)nullptr, (__bf16*)folded, F, fh, fw, H, W, C);
+    else
+        hipLaunchKernelGGL((fold_kernel<true, float, float, float>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const float*)hid, (const float*)nullptr, (const float*)nullptr, (float*)folded, F, fh, fw, H, W, C);
     E2_LAUNCH_CHECK("ffn_fold");
     return 0;
 }
+extern "C" int e2fgvi_ffn_fold(const float* hid, float* folded, int32_t F, int32_t fh, int32_t fw, int32_t H, int32_t W,
+                               int32_t C, void* stream) {
+    return e2fgvi_ffn_fold_x(hid, folded, E2FGVI_F32, F, fh, fw, H, W, C, stream);
+}
 
-extern "C" int e2fgvi_ffn_unfold_gelu(const float* folded, float* out, int32_t F, int32_t fh, int32_t fw, int32_t H,
-                                      int32_t W, int32_t C, void* stream) {
-    E2_REQUIRE(folded && out, E2FGVI_EINVAL, "ffn_unfold_gelu: null pointer");
+extern "C" int e2fgvi_ffn_unfold_gelu_x(const void* folded, void* out, int32_t dtype, int32_t F, int32_t fh, int32_t fw,
+                                        int32_t H, int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(folded && out && E2_DT_OK(dtype), E2FGVI_EINVAL, "ffn_unfold_gelu: bad arguments");
     if (int rc = check_fold("ffn_unfold_gelu", F, fh, fw, H, W, C)) return rc;
     const long long total = (long long)F * fh * fw * 49 * (C / 4);
-    hipLaunchKernelGGL(unfold_gelu_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, folded, out, F, fh,
-                       fw, H, W, C);
+    if (dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL(unfold_gelu_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const __bf16*)folded, (__bf16*)out, F, fh, fw, H, W, C);
+    else
+        hipLaunchKernelGGL(unfold_gelu_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const float*)folded, (float*)out, F, fh, fw, H, W, C);
     E2_LAUNCH_CHECK("ffn_unfold_gelu");
     return 0;
+}
+extern "C" int e2fgvi_ffn_unfold_gelu(const float* folded, float* out, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                                      int32_t W, int32_t C, void* stream) {
+    return e2fgvi_ffn_unfold_gelu_x(folded, out, E2FGVI_F32, F, fh, fw, H, W, C, stream);
 }
 
 extern "C" int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* residual, float* dst, int32_t F,
@@ -526,8 +638,33 @@ extern "C" int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, con
     E2_REQUIRE(emb && dst, E2FGVI_EINVAL, "softcomp_fold: null pointer");
     if (int rc = check_fold("softcomp_fold", F, fh, fw, H, W, C)) return rc;
     const long long total = (long long)F * H * W * (C / 4);
-    hipLaunchKernelGGL(fold_kernel<false>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, emb, bias_hwc,
-                       residual, dst, F, fh, fw, H, W, C);
+    hipLaunchKernelGGL((fold_kernel<false, float, float, float>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, emb,
+                       bias_hwc, residual, dst, F, fh, fw, H, W, C);
     E2_LAUNCH_CHECK("softcomp_fold");
+    return 0;
+}
+/* bf16 data path: emb, residual and dst are bf16 (bias_hwc stays fp32) */
+extern "C" int e2fgvi_softcomp_fold_bf16(const void* emb, const float* bias_hwc, const void* residual, void* dst, int32_t F,
+                                         int32_t fh, int32_t fw, int32_t H, int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(emb && dst, E2FGVI_EINVAL, "softcomp_fold_bf16: null pointer");
+    if (int rc = check_fold("softcomp_fold_bf16", F, fh, fw, H, W, C)) return rc;
+    const long long total = (long long)F * H * W * (C / 4);
+    hipLaunchKernelGGL((fold_kernel<false, __bf16, __bf16, __bf16>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                       (const __bf16*)emb, bias_hwc, (const __bf16*)residual, (__bf16*)dst, F, fh, fw, H, W, C);
+    E2_LAUNCH_CHECK("softcomp_fold_bf16");
+    return 0;
+}
+
+extern "C" int e2fgvi_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream) {
+    E2_REQUIRE(src && dst && n > 0 && n % 4 == 0 && E2_DT_OK(src_dtype) && E2_DT_OK(dst_dtype) && src_dtype != dst_dtype &&
+                   (((uintptr_t)src | (uintptr_t)dst) & 7) == 0,
+               E2FGVI_EINVAL, "cast: bad arguments (n must be a multiple of 4, dtypes must differ)");
+    if (src_dtype == E2FGVI_F32)
+        hipLaunchKernelGGL((cast_kernel<float, __bf16>), dim3(blocks_for(n / 4)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const float*)src, (__bf16*)dst, (long long)(n / 4));
+    else
+        hipLaunchKernelGGL((cast_kernel<__bf16, float>), dim3(blocks_for(n / 4)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const __bf16*)src, (float*)dst, (long long)(n / 4));
+    E2_LAUNCH_CHECK("cast");
     return 0;
 }

@@ -21,6 +21,7 @@ import os
 import torch
 
 from . import ops
+from .engine_x import BF16Path
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedDcn, PackedLinear
 
 WIN = (5, 9)
@@ -70,12 +71,12 @@ def build_key_table(fh, fw, valid_ind_rolled):
     return tab, nk
 
 
-class Engine:
+class Engine(BF16Path):
     def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32", winograd=True, autotune=True):
         """precision="fp32": every contraction on fp32 MFMA (the default and the parity configuration).
-        precision="bf16": the wide conv / linear layers run on bf16 MFMA with fp32 accumulation (BASELINE.json HQ
-        configurations); SPyNet, the first / last conv, conv_offset's last layer, the deformable conv and the attention
-        stay fp32, all tensors in HBM stay fp32."""
+        precision="bf16": the bf16 data path of engine_x.py (BASELINE.json HQ configurations): bf16 activations in HBM,
+        every conv / linear / attention product on bf16 MFMA with fp32 accumulation; SPyNet, the flows, the DCN offsets
+        and masks, the deformable conv's arithmetic and the token residual stream stay fp32."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         self.precision = precision
@@ -84,9 +85,10 @@ class Engine:
         sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
         self.sd = sd
         f = lambda k: sd[k].float().contiguous()
-        pw = dict(precision=precision)          # layers that follow the precision mode
+        self.bf16 = precision == "bf16"
+        pw = dict(precision="fp32")
         # wide 3x3 / stride-1 layers: fp32 Winograd F(2x2,3x3) whenever the call qualifies (even H, W), else implicit GEMM
-        ww = dict(precision=precision, algo="auto" if (winograd and precision == "fp32") else "igemm")
+        ww = dict(precision="fp32", algo="auto" if winograd else "igemm")
 
         # ---- encoder (e2fgvi.py:75-94)
         w0 = torch.zeros(64, 4, 3, 3, device=self.device)
@@ -204,11 +206,13 @@ class Engine:
                     c.tune = True
             if self.hq:
                 self.sc_bias_conv.tune = True
-        # SPyNet runs on a side stream next to the encoder -- fp32 mode only.  Measured on MI355X (tools/overlap_probe.py,
-        # DESIGN.md "Stream overlap"): with the 2x2-accumulator bf16 conv tiles on the other stream, spynet_level_input
-        # intermittently produced wrong values in lanes 48-63 of a wave; no fp32 kernel ever triggered it, and the bf16
-        # kernels themselves are bit-reproducible on one stream.  bf16 mode therefore stays on a single stream.
-        self.overlap_flows = precision == "fp32"
+        # SPyNet runs on a side stream next to the encoder, in both precision modes.  Round 1 found the side stream's
+        # kernels corrupted beside bf16 MFMA tiles; round 2 traced it to packed-fp32 VALU instructions consuming freshly
+        # loaded registers (tools/probe/overlap_probe.hip, DESIGN.md "Stream overlap"): every kernel that can run on the
+        # side stream is built without them (csrc/misc.hip and the `nopk` build of conv.hip, e2fgvi_amd/build.py).
+        self.overlap_flows = True
+        if self.bf16:
+            self._init_x(f)
         self._side = None
         torch.cuda.synchronize(self.device)
 
@@ -393,6 +397,8 @@ class Engine:
         if not (1 <= l_t <= t):
             raise ValueError("num_local_frames must be in [1, t]")
         frames = ops._chk(frames.float().contiguous(), "masked_frames")
+        if self.bf16:
+            return self.forward_x(frames, l_t, b, t, h, w, fh, fw, trace)
         if l_t == 1:
             # a one-frame local window (test.py on a 1-frame video): the reference's flow tensors are empty
             # [b,0,2,h,w] and each propagation direction is backbone(cat(x, 0)) (feat_prop.py:105,131-137)

@@ -53,7 +53,7 @@ class MdcnDesc(C.Structure):
         ("offset", _fp), ("off_ld", C.c_int32), ("mask", _fp), ("mask_ld", C.c_int32),
         ("flows", _fp), ("max_residue", C.c_float),
         ("wpacked", _fp), ("bias", _fp),
-        ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("tile", C.c_int32),
+        ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("tile", C.c_int32), ("dst_dtype", C.c_int32),
     ]
 
 
@@ -97,6 +97,16 @@ SYMBOLS = {
     "e2fgvi_psnr_ssim_workspace": (_i64, [_i32, _i32, _i32]),
     "e2fgvi_psnr_ssim": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp, _fp, _fp]),
     "e2fgvi_softcomp_fold": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_focal_attention_bf16": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_nchw_to_nhwc_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
+    "e2fgvi_resize_bilinear_bf16": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_prop_cond_x": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i64, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_layernorm_x": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i64, _i32, _fp]),
+    "e2fgvi_window_pool_x": (C.c_int, [_fp, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_ffn_fold_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_ffn_unfold_gelu_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_softcomp_fold_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_cast": (C.c_int, [_fp, _i32, _fp, _i32, _i64, _fp]),
 }
 
 _lib = None

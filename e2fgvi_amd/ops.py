@@ -411,7 +411,8 @@ class PackedDcn:
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
         self.name = "dcn"
 
-    def __call__(self, sources, offset, mask=None, off_cols=None, flows=None, max_residue=10.0, out=None, tile=0):
+    def __call__(self, sources, offset, mask=None, off_cols=None, flows=None, max_residue=10.0, out=None, tile=0,
+                 out_dtype=torch.float32):
         """sources: 1 or 2 NHWC tensors (virtual concat).  offset: [N,Ho,Wo,*] pixel-major; if ``mask`` is None
         the mask words live in the same tensor starting at column dg*2*K (raw conv_offset layout)."""
         lib = _L.load()
@@ -451,9 +452,9 @@ class PackedDcn:
         d.wpacked = self.wpacked.data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         if out is None:
-            out = empty_nhwc(N, Ho, Wo, self.Cout, sources[0].device)
-        _chk(out, "out")
-        d.dst, d.dst_ld, d.dst_coff, d.tile = out.data_ptr(), out.shape[3], 0, tile
+            out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=sources[0].device)
+        _chk_any(out, "out")
+        d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile, _dt(out)
         if _L.TRACE is not None:
             m = N * Ho * Wo * self.Cout * self.C * K
             _L.annotate(layer=self.name, kernel="mdcn", shape="N%d %dx%d %d->%d dg%d" % (N, H, W, self.C, self.Cout, self.dg),
@@ -500,14 +501,48 @@ def focal_attention(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, waves=
     return out
 
 
+def focal_attention_bf16(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None):
+    """bf16 data path: qkv [rows,1536] / kv_pool [B*T*nWin,1536] / out [rows,512] are bf16"""
+    lib = _L.load()
+    _chk(qkv, "qkv", torch.bfloat16); _chk(kv_pool, "kv_pool", torch.bfloat16)
+    _chk(key_tab, "key_tab", torch.int32); _chk(nkeys, "nkeys", torch.int32)
+    rows = B * T * fh * fw
+    nwin = (fh // 5) * (fw // 9)
+    if tuple(qkv.shape) != (rows, 1536) or tuple(kv_pool.shape) != (B * T * nwin, 1536):
+        raise ValueError("qkv must be [%d,1536] and kv_pool [%d,1536]" % (rows, B * T * nwin))
+    if key_tab.shape[0] != nwin or nkeys.shape[0] != nwin:
+        raise ValueError("key table must have %d rows" % nwin)
+    if out is None:
+        out = torch.empty((rows, 512), dtype=torch.bfloat16, device=qkv.device)
+    _chk(out, "out", torch.bfloat16)
+    if _L.TRACE is not None:
+        nkl = nkeys.tolist()
+        alg = B * nwin * 4 * (45 * T) * (210 * T) * 128 * 2
+        qpad = -(-(45 * T) // 32) * 32
+        iss = B * 4 * qpad * 128 * 2 * sum(-(-(T * k) // 32) * 32 for k in nkl)
+        _L.annotate(layer="attention", kernel="focal_attn_bf16", shape="B%d T%d grid %dx%d" % (B, T, fh, fw), macs=alg, issued=iss)
+    _L.check(lib.e2fgvi_focal_attention_bf16(_ptr(qkv), _ptr(kv_pool), _ptr(key_tab), key_tab.shape[1], _ptr(nkeys), _ptr(out),
+                                             B, T, fh, fw, _stream()), "focal_attention_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ small kernels
-def nchw_to_nhwc(x, ld=None, scale=1.0, shift=0.0):
+def nchw_to_nhwc(x, ld=None, scale=1.0, shift=0.0, out_dtype=torch.float32):
     lib = _L.load()
     _chk(x, "x")
     N, Cc, H, W = x.shape
     ld = Cc if ld is None else ld
-    out = empty_nhwc(N, H, W, ld, x.device)
-    _L.check(lib.e2fgvi_nchw_to_nhwc(_ptr(x), _ptr(out), N, Cc, H, W, ld, scale, shift, _stream()), "nchw_to_nhwc")
+    out = torch.empty((N, H, W, ld), dtype=out_dtype, device=x.device)
+    _L.check(lib.e2fgvi_nchw_to_nhwc_x(_ptr(x), _ptr(out), _dt(out), N, Cc, H, W, ld, scale, shift, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def cast(x, dtype):
+    """fp32 <-> bf16 copy of a tensor (round to nearest even); numel must be a multiple of 4"""
+    lib = _L.load()
+    _chk_any(x, "x")
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _L.check(lib.e2fgvi_cast(_ptr(x), _dt(x), _ptr(out), _dt(out), x.numel(), _stream()), "cast")
     return out
 
 
@@ -523,6 +558,15 @@ def nhwc_to_nchw(x, channels=None):
 
 def resize_bilinear(x, out_hw, align_corners, src_nchw=False, channels=None, out_ld=None, scale=None, shift=None):
     lib = _L.load()
+    if isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16:         # bf16 data path: NHWC -> NHWC only
+        _chk(x, "x", torch.bfloat16)
+        if src_nchw or scale is not None or shift is not None or channels is not None or out_ld is not None:
+            raise ValueError("bf16 resize: plain NHWC -> NHWC only")
+        N, H, W, Cc = x.shape
+        out = torch.empty((N, out_hw[0], out_hw[1], Cc), dtype=torch.bfloat16, device=x.device)
+        _L.check(lib.e2fgvi_resize_bilinear_bf16(_ptr(x), Cc, _ptr(out), Cc, N, Cc, H, W, out_hw[0], out_hw[1],
+                                                 int(align_corners), _stream()), "resize_bilinear_bf16")
+        return out
     _chk(x, "x")
     if src_nchw:
         N, Cc, H, W = x.shape
@@ -572,70 +616,87 @@ def spynet_level_input(pyr, ref_idx, supp_idx, flow_prev):
     return out
 
 
-def prop_cond(feat_prop, feat_n2, flow_a, flow_b, flow_img_stride, cond=None, flows=None):
-    """flow_a / flow_b: tensors whose data_ptr is image 0's [H,W,2] flow; image n is at +n*flow_img_stride floats."""
+def prop_cond(feat_prop, feat_n2, flow_a, flow_b, flow_img_stride, cond=None, flows=None, cond_dtype=torch.float32,
+              flows8=False):
+    """flow_a / flow_b: tensors whose data_ptr is image 0's [H,W,2] flow; image n is at +n*flow_img_stride floats.
+    cond_dtype=torch.bfloat16 writes the warped features as bf16 (bf16 data path); flows8=True additionally returns the
+    four flow values as a bf16 [N,H,W,8] conv source (channels 4..7 zero)."""
     lib = _L.load()
     _chk(feat_prop, "feat_prop")
     N, H, W, Cc = feat_prop.shape
     if cond is None:
-        cond = empty_nhwc(N, H, W, 2 * Cc, feat_prop.device)
+        cond = torch.empty((N, H, W, 2 * Cc), dtype=cond_dtype, device=feat_prop.device)
     if flows is None:
         flows = empty_nhwc(N, H, W, 4, feat_prop.device)
+    fl8 = torch.empty((N, H, W, 8), dtype=torch.bfloat16, device=feat_prop.device) if flows8 else None
     f2_ld = 0
     if flow_b is not None:
         _chk(feat_n2, "feat_n2")
         f2_ld = feat_n2.shape[3]
-    _L.check(lib.e2fgvi_prop_cond(_ptr(feat_prop), Cc, _ptr(feat_n2) if flow_b is not None else None, f2_ld,
-                                  C.c_void_p(flow_a.data_ptr()),
-                                  C.c_void_p(flow_b.data_ptr()) if flow_b is not None else None,
-                                  flow_img_stride, _ptr(cond), _ptr(flows), N, H, W, Cc, _stream()), "prop_cond")
-    return cond, flows
+    _L.check(lib.e2fgvi_prop_cond_x(_ptr(feat_prop), Cc, _ptr(feat_n2) if flow_b is not None else None, f2_ld,
+                                    C.c_void_p(flow_a.data_ptr()),
+                                    C.c_void_p(flow_b.data_ptr()) if flow_b is not None else None,
+                                    flow_img_stride, _ptr(cond), _dt(cond), _ptr(flows), _ptr(fl8), N, H, W, Cc, _stream()),
+             "prop_cond")
+    return (cond, flows, fl8) if flows8 else (cond, flows)
 
 
-def layernorm(x, gamma, beta, out=None):
+def layernorm(x, gamma, beta, out=None, out_dtype=torch.float32):
     lib = _L.load()
     _chk(x, "x"); _chk(gamma, "gamma"); _chk(beta, "beta")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     if out is None:
-        out = torch.empty_like(x)
-    _L.check(lib.e2fgvi_layernorm(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, Cc, _stream()), "layernorm")
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _chk_any(out, "out")
+    _L.check(lib.e2fgvi_layernorm_x(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _dt(out), rows, Cc, _stream()), "layernorm")
     return out
 
 
 def window_pool(x, w45, bias1, BT, fh, fw, out=None):
     lib = _L.load()
-    _chk(x, "x"); _chk(w45, "w45"); _chk(bias1, "bias1")
+    _chk_any(x, "x"); _chk(w45, "w45"); _chk(bias1, "bias1")
     Cc = x.shape[-1]
     rows = BT * (fh // 5) * (fw // 9)
     if out is None:
-        out = torch.empty((rows, Cc), dtype=torch.float32, device=x.device)
-    elif tuple(_chk(out, "out").shape) != (rows, Cc):
+        out = torch.empty((rows, Cc), dtype=x.dtype, device=x.device)
+    elif tuple(_chk(out, "out", x.dtype).shape) != (rows, Cc):
         raise ValueError("window_pool out must be [%d,%d]" % (rows, Cc))
-    _L.check(lib.e2fgvi_window_pool(_ptr(x), _ptr(w45), _ptr(bias1), _ptr(out), BT, fh, fw, Cc, _stream()), "window_pool")
+    _L.check(lib.e2fgvi_window_pool_x(_ptr(x), _dt(x), _ptr(w45), _ptr(bias1), _ptr(out), BT, fh, fw, Cc, _stream()), "window_pool")
     return out
 
 
 def ffn_fold(hid, F_, fh, fw, H, W, Cc):
     lib = _L.load()
-    _chk(hid, "hid")
-    out = empty_nhwc(F_, H, W, Cc, hid.device)
-    _L.check(lib.e2fgvi_ffn_fold(_ptr(hid), _ptr(out), F_, fh, fw, H, W, Cc, _stream()), "ffn_fold")
+    _chk_any(hid, "hid")
+    out = torch.empty((F_, H, W, Cc), dtype=hid.dtype, device=hid.device)
+    _L.check(lib.e2fgvi_ffn_fold_x(_ptr(hid), _ptr(out), _dt(hid), F_, fh, fw, H, W, Cc, _stream()), "ffn_fold")
     return out
 
 
 def ffn_unfold_gelu(folded, fh, fw, out=None):
     lib = _L.load()
-    _chk(folded, "folded")
+    _chk_any(folded, "folded")
     F_, H, W, Cc = folded.shape
     if out is None:
-        out = torch.empty((F_ * fh * fw, 49 * Cc), dtype=torch.float32, device=folded.device)
-    _L.check(lib.e2fgvi_ffn_unfold_gelu(_ptr(folded), _ptr(out), F_, fh, fw, H, W, Cc, _stream()), "ffn_unfold_gelu")
+        out = torch.empty((F_ * fh * fw, 49 * Cc), dtype=folded.dtype, device=folded.device)
+    _chk(out, "out", folded.dtype)
+    _L.check(lib.e2fgvi_ffn_unfold_gelu_x(_ptr(folded), _ptr(out), _dt(folded), F_, fh, fw, H, W, Cc, _stream()), "ffn_unfold_gelu")
     return out
 
 
 def softcomp_fold(emb, F_, fh, fw, H, W, Cc, bias_hwc=None, residual=None):
     lib = _L.load()
+    if isinstance(emb, torch.Tensor) and emb.dtype == torch.bfloat16:     # bf16 data path: emb, residual, result bf16
+        _chk(emb, "emb", torch.bfloat16)
+        out = torch.empty((F_, H, W, Cc), dtype=torch.bfloat16, device=emb.device)
+        if bias_hwc is not None:
+            _chk(bias_hwc, "bias_hwc")
+        if residual is not None:
+            _chk(residual, "residual", torch.bfloat16)
+        _L.check(lib.e2fgvi_softcomp_fold_bf16(_ptr(emb), _ptr(bias_hwc), _ptr(residual), _ptr(out), F_, fh, fw, H, W, Cc,
+                                               _stream()), "softcomp_fold_bf16")
+        return out
     _chk(emb, "emb")
     out = empty_nhwc(F_, H, W, Cc, emb.device)
     if bias_hwc is not None:

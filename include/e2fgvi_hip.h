@@ -71,6 +71,10 @@ int e2fgvi_psnr_ssim(const float* img1, const float* img2, int32_t N, int32_t H,
 
 #define E2FGVI_MAX_SRC 4
 
+/* element types of the tensors of the bf16 data path (see the end of this header) */
+#define E2FGVI_F32 0
+#define E2FGVI_BF16 1
+
 const char* e2fgvi_last_error(void);
 int e2fgvi_abi_version(void);
 
@@ -171,6 +175,7 @@ typedef struct {
     const float* bias;
     float* dst; int32_t dst_ld, dst_coff;
     int32_t tile;
+    int32_t dst_dtype;                 /* E2FGVI_F32 (0, default) or E2FGVI_BF16: dst is a bf16 NHWC tensor        */
 } e2fgvi_mdcn_desc;
 
 int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream);
@@ -265,8 +270,6 @@ int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* r
  * bf16, every product runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; bias / residual / activation are applied
  * in fp32 and the result is stored as bf16 and / or fp32.  Same operators and call sites as e2fgvi_conv2d_nhwc.
  * ---------------------------------------------------------------------------------------------- */
-#define E2FGVI_F32 0
-#define E2FGVI_BF16 1
 typedef struct {
     const void* src[E2FGVI_MAX_SRC];   /* bf16 NHWC sources of the virtual concat                          */
     int32_t src_ld[E2FGVI_MAX_SRC];    /* pixel stride, elements (multiple of 8)                           */
@@ -298,6 +301,36 @@ int64_t e2fgvi_packed_conv_weight_bf16x_size(int32_t Cout, int32_t groups, int32
 /* w: fp32 [Cout, sum(cpg), KH, KW] (torch OIHW) */
 int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
                                   int32_t nsrc, const int32_t* src_cpg, void* stream);
+
+/* Fused temporal focal window attention on bf16 MFMA: qkv / kv_pool / out are bf16 with the layouts of
+ * e2fgvi_focal_attention; scores, softmax statistics and accumulation are fp32.  qkv and kv_pool must lie within one
+ * 4 GiB window (the engine allocates them back to back). */
+int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool, const int32_t* key_tab, int32_t tab_ld,
+                                const int32_t* nkeys, void* out, int32_t B, int32_t T, int32_t fh, int32_t fw,
+                                void* stream);
+
+/* Typed variants of the HBM-bound helpers for the bf16 data path: same operators and reference call sites as the fp32
+ * entry points above, tensors marked `void*` are fp32 or bf16 as the dtype argument says; all arithmetic is fp32. */
+int e2fgvi_nchw_to_nhwc_x(const float* src, void* dst, int32_t dst_dtype, int32_t N, int32_t C, int32_t H, int32_t W,
+                          int32_t ld, float scale, float shift, void* stream);
+int e2fgvi_resize_bilinear_bf16(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int32_t N, int32_t C, int32_t H,
+                                int32_t W, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream);
+/* flows8_bf16 (optional): the [P,4] flows again as a bf16 [P,8] conv source (channels 4..7 zero) */
+int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld, const float* flow_a,
+                       const float* flow_b, int64_t flow_img_stride, void* cond, int32_t cond_dtype, float* flows,
+                       void* flows8_bf16, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int e2fgvi_layernorm_x(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype, int64_t rows,
+                       int32_t C, void* stream);
+int e2fgvi_window_pool_x(const void* x, int32_t dtype, const float* w45, const float* bias1, void* pooled, int32_t BT,
+                         int32_t fh, int32_t fw, int32_t C, void* stream);
+int e2fgvi_ffn_fold_x(const void* hid, void* folded, int32_t dtype, int32_t F, int32_t fh, int32_t fw, int32_t H, int32_t W,
+                      int32_t C, void* stream);
+int e2fgvi_ffn_unfold_gelu_x(const void* folded, void* out, int32_t dtype, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                             int32_t W, int32_t C, void* stream);
+int e2fgvi_softcomp_fold_bf16(const void* emb, const float* bias_hwc, const void* residual, void* dst, int32_t F, int32_t fh,
+                              int32_t fw, int32_t H, int32_t W, int32_t C, void* stream);
+/* element-wise fp32 <-> bf16 conversion (round to nearest even), n a multiple of 4 */
+int e2fgvi_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

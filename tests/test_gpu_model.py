@@ -273,42 +273,23 @@ def test_graph_replay_equals_eager(dev):
     assert torch.equal(a, eager) and torch.equal(b, eager) and torch.equal(c, eager)
 
 
-@pytest.mark.parametrize("model,hw,t,lt", [("e2fgvi_hq", (120, 216), 4, 3), ("e2fgvi", (240, 432), 3, 3)])
-def test_bf16_mode_end_to_end(dev, model, hw, t, lt):
-    """optional bf16-MFMA mode (BASELINE.json HQ configs): not the 1e-3 parity configuration -- operands of the wide
-    layers are rounded to bf16 -- but it must stay close to the fp32 oracle: <= 3 % of the output rms, max abs <= 2e-2"""
-    import importlib
-    sd, x, tr, out, flows = _setup(model, "stress", hw, t, lt)
-    net = importlib.import_module("model." + model).InpaintGenerator()
-    net.load_state_dict(sd)
-    net = net.to(dev).eval()
-    net.precision = "bf16"
-    got, (ff, fb) = net(x.to(dev), lt)
-    d, r = err(got, out)
-    print("bf16 mode %s: max abs %.3e (%.2e x rms)" % (model, d, r))
-    assert torch.isfinite(got).all() and d <= 2e-2 and r <= 0.2
-    assert err(ff, flows[0])[0] <= 1e-3 * max(1.0, flows[0].abs().max().item())     # SPyNet stays fp32
-    net.precision = "fp32"                                                          # switching back rebuilds the engine
-    got32, _ = net(x.to(dev), lt)
-    assert err(got32, out)[0] <= 1e-3
-
-
 def test_stream_overlap_is_bit_identical_to_serial(dev):
-    """fp32 mode runs SPyNet on a side stream next to the encoder (Engine.overlap_flows): the two-stream schedule must
-    give exactly the single-stream result, every time (tripwire for cross-stream interference; bf16 mode does not
-    overlap -- see tools/overlap_probe.py)."""
+    """SPyNet runs on a side stream next to the encoder (Engine.overlap_flows), in the fp32 and in the bf16 mode: the
+    two-stream schedule must give exactly the single-stream result, every time.  Tripwire for the cross-stream corruption
+    of round 1 (packed-fp32 VALU of side-stream kernels beside bf16 MFMA tiles, tools/probe/overlap_probe.hip): in the
+    round-1 build 60-70 % of the bf16 forwards differed."""
     from e2fgvi_amd.engine import Engine
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
     sd = synth_state_dict("e2fgvi", "stress", 0)
     x = synth_clip(1, 4, 240, 432, seed=3, moving=True)[0].to(dev)
-    eng = Engine(sd, "e2fgvi", dev)
-    assert eng.overlap_flows
-    eng.overlap_flows = False
-    base, (bf, bb) = eng.forward(x, 3)
-    torch.cuda.synchronize()
-    eng.overlap_flows = True
-    for _ in range(40):
-        got, (ff, fb) = eng.forward(x, 3)
+    for precision, trials in (("fp32", 40), ("bf16", 120)):
+        eng = Engine(sd, "e2fgvi", dev, precision=precision)
+        assert eng.overlap_flows
+        eng.overlap_flows = False
+        base, (bf, bb) = eng.forward(x, 3)
         torch.cuda.synchronize()
-        assert torch.equal(ff, bf) and torch.equal(fb, bb) and torch.equal(got, base)
-    assert not Engine(sd, "e2fgvi", dev, precision="bf16").overlap_flows
+        eng.overlap_flows = True
+        for _ in range(trials):
+            got, (ff, fb) = eng.forward(x, 3)
+            torch.cuda.synchronize()
+            assert torch.equal(ff, bf) and torch.equal(fb, bb) and torch.equal(got, base), precision

@@ -100,13 +100,13 @@ def test_abi_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().e2fgvi_abi_version() == 1
+    assert lib.load().e2fgvi_abi_version() == 2
 
 
 def test_desc_struct_sizes_are_plain_c():
     from e2fgvi_amd import lib
     # pointers 8 bytes, int32 fields: sizes must be multiples of 8 and stable
-    assert ctypes.sizeof(lib.ConvDesc) % 8 == 0 and ctypes.sizeof(lib.MdcnDesc) % 8 == 0
+    assert ctypes.sizeof(lib.ConvDesc) % 8 == 0 and ctypes.sizeof(lib.MdcnDesc) % 8 == 0 and ctypes.sizeof(lib.ConvXDesc) % 8 == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
