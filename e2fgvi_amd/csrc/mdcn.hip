@@ -68,17 +68,21 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // KS K-groups of WGM x WGN waves share one output tile (intra-workgroup split-K, see conv.hip): group kg takes the
 // K-chunks kg, kg+KS, ... .  All loads are raw buffer loads: corners outside the image, rows outside the problem and
 // chunks past the end read as zero through the buffer bounds, so the loop has no branches.
-template <int BM, int BN, int WGM, int WGN, int KS>
+// BF: the sampled slab and the weights are held in LDS as bf16 and multiplied on v_mfma_f32_32x32x16_bf16 (the bf16 data
+// path); the gather, the bilinear blend and the accumulation are fp32 either way.
+//   bf16 LDS images: A [BM rows][32 k (+8 pad)] (80-byte rows: conflict-free b128 reads), B [4 k-octets][BN][8]
+template <int BM, int BN, int WGM, int WGN, int KS, bool BF>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnParams p) {
     constexpr int BK = 32;
     constexpr int NG = 64 * WGM * WGN;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int LDA = BK + 4;
+    constexpr int LDA16 = BK + 8;                     // bf16 elements per A row
     constexpr int A_ITEMS = BM * 8;                   // (row, unit-in-chunk, c4)
     constexpr int A_IT = (A_ITEMS + NG - 1) / NG;
-    constexpr int B_F4 = BK * BN / 4;
+    constexpr int B_F4 = BF ? BK * BN / 8 : BK * BN / 4;      // 16-byte items of a chunk's weight slab
     constexpr int B_IT = (B_F4 + NG - 1) / NG;
-    constexpr int STAGE = BM * LDA + BK * BN;
+    constexpr int STAGE = BF ? (BM * LDA16 + BK * BN) / 2 : BM * LDA + BK * BN;      // floats
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(KS * 2 * STAGE >= (KS - 1) * NG * TM * TN * 16, "reduction scratch must fit in LDS");
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         const bool ok = (B_F4 % NG == 0 || f < B_F4) && (n0 + n) < p.Npad;
         b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
     }
-    const unsigned b_step = (unsigned)(BK / 4) * (unsigned)p.Npad * 16u;
+    const unsigned b_step = (unsigned)(BF ? BK / 8 : BK / 4) * (unsigned)p.Npad * 16u;
 
     // two register sets: the corner fetches / weights of chunk k+2 are issued while those of chunk k+1 (issued one
     // iteration earlier) are blended into LDS -- a whole MFMA block plus another group's turn covers the gather latency
@@ -258,12 +262,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     };
     auto store_tile = [&](int buf, int S) {
         float* sA = sbase + buf * STAGE;
-        float* sB = sA + BM * LDA;
+        float* sB = BF ? sA + BM * LDA16 / 2 : sA + BM * LDA;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             if (A_ITEMS % NG == 0 || (tid + ia * NG) < A_ITEMS) {
                 const f32x4 v = c00[S][ia] * w00[S][ia] + c01[S][ia] * w01[S][ia] + c10[S][ia] * w10[S][ia] + c11[S][ia] * w11[S][ia];
-                *reinterpret_cast<f32x4*>(sA + it_row[ia] * LDA + it_uu[ia] * 16 + it_c4[ia] * 4) = v;
+                if (BF) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 hv = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(sA) + it_row[ia] * LDA16 + it_uu[ia] * 16 + it_c4[ia] * 4) = hv;
+                } else {
+                    *reinterpret_cast<f32x4*>(sA + it_row[ia] * LDA + it_uu[ia] * 16 + it_c4[ia] * 4) = v;
+                }
             }
         }
 #pragma unroll
@@ -311,8 +321,30 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             const int kt = kg + (it + par) * KS;
             issue_corners(kt + 2 * KS, par, par);            // raw words of chunk i+2 from sraw buffer i&1
             load_w(kt + 2 * KS, par);
-            mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
-                                           wn * TN * 32, lane);
+            if (BF) {
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                const __bf16* sA16 = reinterpret_cast<const __bf16*>(sbase + cur * STAGE);
+                const __bf16* sB16 = sA16 + BM * LDA16;
+                const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 a[TM], b[TN];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        a[tm] = *reinterpret_cast<const bf16x8*>(sA16 + ((wm * TM + tm) * 32 + li) * LDA16 + (2 * kk + lh) * 8);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        b[tn] = *reinterpret_cast<const bf16x8*>(sB16 + ((2 * kk + lh) * BN + (wn * TN + tn) * 32 + li) * 8);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                }
+            } else {
+                mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
+                                               wn * TN * 32, lane);
+            }
             store_tile(cur ^ 1, par ^ 1);                    // chunk i+1
             store_offsets(par ^ 1);                          // chunk i+3 (that buffer's readers passed the last barrier)
             load_offsets(kt + 4 * KS);
@@ -387,6 +419,27 @@ __global__ void pack_dcn_weight_kernel(const float* __restrict__ w, float* __res
     wp[idx] = v;
 }
 
+// bf16 weights of the BF variant: [chunk][4 k-octets][Npad][8], k inside a chunk = (unit in chunk) * 16 + channel, like above
+__global__ void pack_dcn_weight_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Cout, int C, int KK,
+                                            int cg, int Npad, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = (int)(idx & 7);
+    long long rem = idx >> 3;
+    const int n = (int)(rem % Npad);
+    const int ko = (int)(rem / Npad);
+    const int k = ko * 8 + e;
+    const int u = k >> 4, c = k & 15;
+    const int cgq = cg / 16;
+    const int g = u / (KK * cgq);
+    const int r2 = u - g * (KK * cgq);
+    const int tap = r2 / cgq, cq = r2 - tap * cgq;
+    const int ch = g * cg + cq * 16 + c;
+    float v = 0.f;
+    if (ch < C && n < Cout && g * cg < C) v = w[((long long)n * C + ch) * KK + tap];
+    wp[idx] = (__bf16)v;
+}
+
 long long dcn_packed_size(int Cout, int C, int KH, int KW) {
     const int units = (C / 16) * KH * KW;
     const int KT = (units + 1) / 2;
@@ -394,10 +447,13 @@ long long dcn_packed_size(int Cout, int C, int KH, int KW) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS>
-int launch_dcn(DcnParams& p, hipStream_t st) {
+int launch_dcn(DcnParams& p, hipStream_t st, bool bf) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout, BN);
-    hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+    if (bf)
+        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+    else
+        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
     E2_LAUNCH_CHECK("mdcn");
     return 0;
 }
@@ -421,6 +477,19 @@ extern "C" int e2fgvi_pack_dcn_weight(const float* w, float* wpacked, int32_t Co
     hipLaunchKernelGGL(pack_dcn_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        wpacked, Cout, C, KH * KW, C / deform_groups, round_up(Cout, 32), total);
     E2_LAUNCH_CHECK("pack_dcn_weight");
+    return 0;
+}
+
+/* bf16 weights for mfma_dtype = E2FGVI_BF16: same element count as the fp32 packing, 2 bytes each */
+extern "C" int e2fgvi_pack_dcn_weight_bf16(const float* w, void* wpacked, int32_t Cout, int32_t C, int32_t KH, int32_t KW,
+                                           int32_t deform_groups, void* stream) {
+    E2_REQUIRE(w && wpacked, E2FGVI_EINVAL, "pack_dcn_weight_bf16: null pointer");
+    E2_REQUIRE(Cout > 0 && C > 0 && deform_groups > 0 && C % deform_groups == 0 && (C / deform_groups) % 16 == 0,
+               E2FGVI_EUNSUP, "pack_dcn_weight_bf16: channels per deform group must be a multiple of 16");
+    const long long total = dcn_packed_size(Cout, C, KH, KW);
+    hipLaunchKernelGGL(pack_dcn_weight_bf16_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (__bf16*)wpacked, Cout, C, KH * KW, C / deform_groups, round_up(Cout, 32), total);
+    E2_LAUNCH_CHECK("pack_dcn_weight_bf16");
     return 0;
 }
 
@@ -468,7 +537,8 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     {
         const long long P = (long long)d->N * d->Ho * d->Wo;
         const long long sb0 = (long long)d->N * d->H * d->W * p.ld[0] * 4, sb1 = (long long)d->N * d->H * d->W * p.ld[1] * 4;
-        const long long ob = P * d->off_ld * 4, mb = P * d->mask_ld * 4, wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * 4;
+        const long long ob = P * d->off_ld * 4, mb = P * d->mask_ld * 4,
+                        wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * (d->mfma_dtype == E2FGVI_BF16 ? 2 : 4);
         E2_REQUIRE(sb0 < 4294967295LL && sb1 < 4294967295LL && ob < 4294967295LL && mb < 4294967295LL && wb < 4294967295LL,
                    E2FGVI_EUNSUP, "mdcn: a tensor spans >= 4 GiB; buffer addressing needs less (split the batch)");
         p.src_bytes[0] = (unsigned)sb0; p.src_bytes[1] = (unsigned)sb1;
@@ -484,12 +554,13 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         const long long b64 = (long long)cdiv(p.M, 64) * cdiv(p.Cout, 128);
         tile = b64 >= 512 ? 1 : (b64 >= 256 ? 2 : 5);
     }
-    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream);
-    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream);
-    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream);
-    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream);
-    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream);
-    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream);
+    const bool bf = d->mfma_dtype == E2FGVI_BF16;
+    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf);
+    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream, bf);
+    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream, bf);
+    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream, bf);
+    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream, bf);
+    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream, bf);
     e2fgvi_set_error("mdcn: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }

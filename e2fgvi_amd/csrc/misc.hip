@@ -149,7 +149,7 @@ __global__ void avgpool2_kernel(const float* __restrict__ src, float* __restrict
 // one thread per (pair, y, x)
 __global__ void spynet_level_input_kernel(const float* __restrict__ pyr, const int* __restrict__ ref_idx,
                                           const int* __restrict__ supp_idx, const float* __restrict__ flow_prev,
-                                          float* __restrict__ out, int Np, int h, int w) {
+                                          float* __restrict__ out, __bf16* __restrict__ out16, int Np, int h, int w) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Np * h * w) return;
     const int x = (int)(idx % w);
@@ -193,6 +193,10 @@ __global__ void spynet_level_input_kernel(const float* __restrict__ pyr, const i
     f32x4 o1 = {sv[1], sv[2], fu, fv};
     *reinterpret_cast<f32x4*>(o) = o0;
     *reinterpret_cast<f32x4*>(o + 4) = o1;
+    if (out16) {                           // the same 8 channels as the bf16 source of the level's conv stack
+        st4(out16 + idx * 8, o0);
+        st4(out16 + idx * 8 + 4, o1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ propagation
@@ -504,16 +508,21 @@ extern "C" int e2fgvi_avgpool2_nhwc(const float* src, float* dst, int32_t N, int
     return 0;
 }
 
-extern "C" int e2fgvi_spynet_level_input(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx,
-                                         const float* flow_prev, float* out, int32_t Np, int32_t h, int32_t w,
-                                         void* stream) {
+extern "C" int e2fgvi_spynet_level_input_x(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx,
+                                           const float* flow_prev, float* out, void* out_bf16, int32_t Np, int32_t h, int32_t w,
+                                           void* stream) {
     E2_REQUIRE(pyr && ref_idx && supp_idx && out && Np > 0 && h > 0 && w > 0, E2FGVI_EINVAL, "spynet_level_input: bad arguments");
     E2_REQUIRE(!flow_prev || (h % 2 == 0 && w % 2 == 0), E2FGVI_EINVAL, "spynet_level_input: odd level size");
     const long long total = (long long)Np * h * w;
     hipLaunchKernelGGL(spynet_level_input_kernel, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, pyr, ref_idx,
-                       supp_idx, flow_prev, out, Np, h, w);
+                       supp_idx, flow_prev, out, (__bf16*)out_bf16, Np, h, w);
     E2_LAUNCH_CHECK("spynet_level_input");
     return 0;
+}
+extern "C" int e2fgvi_spynet_level_input(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx,
+                                         const float* flow_prev, float* out, int32_t Np, int32_t h, int32_t w,
+                                         void* stream) {
+    return e2fgvi_spynet_level_input_x(pyr, ref_idx, supp_idx, flow_prev, out, nullptr, Np, h, w, stream);
 }
 
 extern "C" int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,

@@ -266,6 +266,9 @@ class Engine(BF16Path):
         ref_idx, supp_idx, sc = self._tables[key]
         flow = None
         for lv in range(6):
+            if self.bf16:
+                flow = self.spynet_level_x(lv, pyr[lv], ref_idx, supp_idx, flow)
+                continue
             inp = ops.spynet_level_input(pyr[lv], ref_idx, supp_idx, flow)
             cv = self.spy[lv]
             x = cv[0]([inp], act=ACT_RELU)

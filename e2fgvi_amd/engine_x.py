@@ -52,10 +52,12 @@ class BF16Path:
             b = "feat_prop_module.backbone.%s." % d
             bb = [PackedConvX(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1),
                   PackedConvX(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1)]
+            dcn = ops.PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1, mfma="bf16")
+            dcn.name = "deform_align.%sdcn" % d
             for k, c in enumerate(off):
                 c.name = "deform_align.%sconv_offset.%d" % (d, 2 * k)
             bb[0].name, bb[1].name = "backbone.%s0" % d, "backbone.%s2" % d
-            self.xprop[d] = (off, bb)
+            self.xprop[d] = (off, bb, dcn)
         self.xfusion = PackedConvX(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128])
         self.xss = PackedConvX(f("ss.embedding.weight").view(512, 128, 7, 7), f("ss.embedding.bias"), [128], stride=3, pad=3)
         wsc = f("sc.embedding.weight").view(128, 49, 512).permute(1, 0, 2).reshape(6272, 512).contiguous()
@@ -65,6 +67,17 @@ class BF16Path:
         if self.hq:
             self.xsc_bias_conv = PackedConvX(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1)
             self.xsc_bias_conv.name = "sc.bias_conv"
+        # SPyNet: the conv stacks of the six pyramid levels on bf16 MFMA (they are 15 % of the 720p forward in fp32); the
+        # geometry stays fp32 -- pyramid images, warps, the flow itself and the residual sum flow = up(flow) + net(...)
+        # (the last conv of a level adds the fp32 upsampled flow and stores fp32).
+        self.xspy = []
+        for lv in range(6):
+            convs = []
+            for j, cin in enumerate((8, 32, 64, 32, 16)):
+                p = "update_spynet.basic_module.%d.basic_module.%d.conv." % (lv, j)
+                convs.append(PackedConvX(f(p + "weight"), f(p + "bias"), [cin], pad=3))
+                convs[-1].name = "spynet.%d.%d" % (lv, j)
+            self.xspy.append(convs)
         self.xblocks = []
         for i in range(8):
             p = "transformer.%d." % i
@@ -83,6 +96,17 @@ class BF16Path:
         if key not in self._zeros:
             self._zeros[key] = torch.zeros(tuple(shape), dtype=BF16, device=self.device)
         return self._zeros[key]
+
+    # ------------------------------------------------------------------ flows (e2fgvi.py:210-234, flow_comp.py:84-169)
+    def spynet_level_x(self, lv, pyr_lv, ref_idx, supp_idx, flow):
+        from .ops import ACT_RELU
+        inp, inp16 = ops.spynet_level_input(pyr_lv, ref_idx, supp_idx, flow, bf16_copy=True)
+        cv = self.xspy[lv]
+        x = cv[0]([inp16], act=ACT_RELU)
+        x = cv[1]([x], act=ACT_RELU)
+        x = cv[2]([x], act=ACT_RELU)
+        x = cv[3]([x], act=ACT_RELU)
+        return cv[4]([x], out_dtype=torch.float32, residual=inp, res_coff=6)          # + fp32 upsampled flow
 
     # ------------------------------------------------------------------ encoder (e2fgvi.py:96-109)
     def encode_x(self, frames):
@@ -109,8 +133,7 @@ class BF16Path:
         zero16 = self._zero16((b, h, w, ch))
         lk = dict(act=ACT_LRELU, slope=0.1)
         for name, flows in (("backward_", flows_a), ("forward_", flows_b)):
-            off, bb = self.xprop[name]
-            dcn = self.prop[name][1]
+            off, bb, dcn = self.xprop[name]
             store16 = torch.empty((l_t, b, h, w, ch), dtype=BF16, device=dev)
             order = list(range(l_t))
             if name == "backward_":

@@ -54,6 +54,7 @@ class MdcnDesc(C.Structure):
         ("flows", _fp), ("max_residue", C.c_float),
         ("wpacked", _fp), ("bias", _fp),
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("tile", C.c_int32), ("dst_dtype", C.c_int32),
+        ("mfma_dtype", C.c_int32),
     ]
 
 
@@ -78,6 +79,7 @@ SYMBOLS = {
     "e2fgvi_mdcn_nhwc": (C.c_int, [C.POINTER(MdcnDesc), _fp]),
     "e2fgvi_packed_dcn_weight_size": (_i64, [_i32, _i32, _i32, _i32]),
     "e2fgvi_pack_dcn_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_pack_dcn_weight_bf16": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_focal_attention": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_nchw_to_nhwc": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
     "e2fgvi_nhwc_to_nchw": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _fp]),
@@ -101,6 +103,7 @@ SYMBOLS = {
     "e2fgvi_nchw_to_nhwc_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
     "e2fgvi_resize_bilinear_bf16": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_prop_cond_x": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i64, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_spynet_level_input_x": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "e2fgvi_layernorm_x": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i64, _i32, _fp]),
     "e2fgvi_window_pool_x": (C.c_int, [_fp, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_ffn_fold_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),

@@ -397,17 +397,25 @@ class PackedLinear(PackedConv):
 
 # ------------------------------------------------------------------------------------------ deformable conv
 class PackedDcn:
-    def __init__(self, weight, bias, deform_groups, stride=1, pad=0, dil=1):
+    def __init__(self, weight, bias, deform_groups, stride=1, pad=0, dil=1, mfma="fp32"):
+        """mfma="bf16": the sampled columns and the weights are rounded to bf16 for the MFMA (bf16 data path); the gather,
+        the bilinear blend and the accumulation stay fp32."""
         lib = _L.load()
+        self.mfma_bf16 = mfma == "bf16"
         w = _chk(weight.detach().float().contiguous(), "weight")
         self.Cout, self.C, self.KH, self.KW = w.shape
         self.dg, self.stride, self.pad, self.dil = deform_groups, stride, pad, dil
         n = lib.e2fgvi_packed_dcn_weight_size(self.Cout, self.C, self.KH, self.KW)
         if n < 0:
             _L.check(int(n), "packed_dcn_weight_size")
-        self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
-        _L.check(lib.e2fgvi_pack_dcn_weight(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
-                                            deform_groups, _stream()), "pack_dcn_weight")
+        if self.mfma_bf16:
+            self.wpacked = torch.empty(int(n), dtype=torch.bfloat16, device=w.device)
+            _L.check(lib.e2fgvi_pack_dcn_weight_bf16(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
+                                                     deform_groups, _stream()), "pack_dcn_weight_bf16")
+        else:
+            self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
+            _L.check(lib.e2fgvi_pack_dcn_weight(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
+                                                deform_groups, _stream()), "pack_dcn_weight")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
         self.name = "dcn"
 
@@ -455,9 +463,10 @@ class PackedDcn:
             out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=sources[0].device)
         _chk_any(out, "out")
         d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile, _dt(out)
+        d.mfma_dtype = _L.DT_BF16 if self.mfma_bf16 else _L.DT_F32
         if _L.TRACE is not None:
             m = N * Ho * Wo * self.Cout * self.C * K
-            _L.annotate(layer=self.name, kernel="mdcn", shape="N%d %dx%d %d->%d dg%d" % (N, H, W, self.C, self.Cout, self.dg),
+            _L.annotate(layer=self.name, kernel="mdcn_bf16" if self.mfma_bf16 else "mdcn", shape="N%d %dx%d %d->%d dg%d" % (N, H, W, self.C, self.Cout, self.dg),
                         macs=m, issued=m)
         _L.check(lib.e2fgvi_mdcn_nhwc(C.byref(d), _stream()), "mdcn_nhwc")
         return out
@@ -599,7 +608,7 @@ def avgpool2(x):
     return out
 
 
-def spynet_level_input(pyr, ref_idx, supp_idx, flow_prev):
+def spynet_level_input(pyr, ref_idx, supp_idx, flow_prev, bf16_copy=False):
     lib = _L.load()
     _chk(pyr, "pyr"); _chk(ref_idx, "ref_idx", torch.int32); _chk(supp_idx, "supp_idx", torch.int32)
     F_, h, w, c = pyr.shape
@@ -611,9 +620,10 @@ def spynet_level_input(pyr, ref_idx, supp_idx, flow_prev):
         if tuple(flow_prev.shape) != (Np, h // 2, w // 2, 2):
             raise ValueError("flow_prev must be [%d,%d,%d,2], got %s" % (Np, h // 2, w // 2, tuple(flow_prev.shape)))
     out = empty_nhwc(Np, h, w, 8, pyr.device)
-    _L.check(lib.e2fgvi_spynet_level_input(_ptr(pyr), _ptr(ref_idx), _ptr(supp_idx), _ptr(flow_prev), _ptr(out), Np, h, w,
-                                           _stream()), "spynet_level_input")
-    return out
+    out16 = torch.empty((Np, h, w, 8), dtype=torch.bfloat16, device=pyr.device) if bf16_copy else None
+    _L.check(lib.e2fgvi_spynet_level_input_x(_ptr(pyr), _ptr(ref_idx), _ptr(supp_idx), _ptr(flow_prev), _ptr(out), _ptr(out16),
+                                             Np, h, w, _stream()), "spynet_level_input")
+    return (out, out16) if bf16_copy else out
 
 
 def prop_cond(feat_prop, feat_n2, flow_a, flow_b, flow_img_stride, cond=None, flows=None, cond_dtype=torch.float32,

@@ -176,6 +176,9 @@ typedef struct {
     float* dst; int32_t dst_ld, dst_coff;
     int32_t tile;
     int32_t dst_dtype;                 /* E2FGVI_F32 (0, default) or E2FGVI_BF16: dst is a bf16 NHWC tensor        */
+    int32_t mfma_dtype;                /* E2FGVI_F32 (0, default): fp32 MFMA, wpacked from e2fgvi_pack_dcn_weight;
+                                          E2FGVI_BF16: the sampled slab is rounded to bf16 and multiplied on bf16 MFMA
+                                          (fp32 gather / blend / accumulation), wpacked from e2fgvi_pack_dcn_weight_bf16 */
 } e2fgvi_mdcn_desc;
 
 int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream);
@@ -183,6 +186,9 @@ int64_t e2fgvi_packed_dcn_weight_size(int32_t Cout, int32_t C, int32_t KH, int32
 /* w: [Cout, C, KH, KW] */
 int e2fgvi_pack_dcn_weight(const float* w, float* wpacked, int32_t Cout, int32_t C, int32_t KH,
                            int32_t KW, int32_t deform_groups, void* stream);
+/* bf16 packing (e2fgvi_packed_dcn_weight_size elements of 2 bytes) for mfma_dtype = E2FGVI_BF16 */
+int e2fgvi_pack_dcn_weight_bf16(const float* w, void* wpacked, int32_t Cout, int32_t C, int32_t KH,
+                                int32_t KW, int32_t deform_groups, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal focal window attention, fused (flash-style, fp32 MFMA, online softmax).
@@ -319,6 +325,9 @@ int e2fgvi_resize_bilinear_bf16(const void* src, int32_t src_ld, void* dst, int3
 int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld, const float* flow_a,
                        const float* flow_b, int64_t flow_img_stride, void* cond, int32_t cond_dtype, float* flows,
                        void* flows8_bf16, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* out_bf16 (optional): the 8 input channels again as bf16 [Np,h,w,8], the source of the level's bf16 conv stack */
+int e2fgvi_spynet_level_input_x(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx, const float* flow_prev,
+                                float* out, void* out_bf16, int32_t Np, int32_t h, int32_t w, void* stream);
 int e2fgvi_layernorm_x(const float* x, const float* gamma, const float* beta, void* y, int32_t y_dtype, int64_t rows,
                        int32_t C, void* stream);
 int e2fgvi_window_pool_x(const void* x, int32_t dtype, const float* w45, const float* bias1, void* pooled, int32_t BT,

@@ -26,3 +26,16 @@ def assert_close(got, ref, rel, what=""):
     assert torch.isfinite(got.detach().float().cpu()).all(), what + ": non-finite output"
     assert r <= rel, "%s: max abs err %.3e = %.3e x rms(ref) (allowed %.1e)" % (what, d, r, rel)
     return d, r
+
+
+def assert_close_bf16(got, ref, what="", ulps=1.0, abs_rms=4e-3):
+    """for results stored as bf16: |got - ref| <= ulps * 2^-8 * |ref| + abs_rms * rms(ref), element by element (one bf16
+    rounding is 2^-9 relative; the default allows it twice) -- a max-abs bound relative to the rms alone would be set by the
+    few largest elements."""
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert tuple(got.shape) == tuple(ref.shape), (what, tuple(got.shape), tuple(ref.shape))
+    assert torch.isfinite(got).all(), what + ": non-finite output"
+    rms = ref.pow(2).mean().sqrt().item()
+    excess = ((got - ref).abs() - (ulps * 2.0 ** -8) * ref.abs() - abs_rms * rms).max().item()
+    assert excess <= 0, "%s: error exceeds %.1f x 2^-8 relative + %.1e x rms by %.3e" % (what, ulps, abs_rms, excess)
