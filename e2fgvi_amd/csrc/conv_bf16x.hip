@@ -43,7 +43,7 @@ struct ConvXParams {
     const void* res;
     int res_ld, res_coff, res_bf16;
     void* dst;
-    int dst_ld, dst_coff, dst_bf16;
+    int dst_ld, dst_coff, dst_bf16, dst_nchw;
     __bf16* dst2;
     int dst2_ld, dst2_coff;
     int act;
@@ -275,7 +275,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 #pragma unroll
             for (int c = 0; c < 8; ++c) hv[c] = (__bf16)v[c];
             const long long dof = (long long)m * p.dst_ld + p.dst_coff + co;
-            if (p.dst_bf16) {
+            if (p.dst_nchw) {                      // plain fp32 NCHW [N,Cout,Ho,Wo] (the decoder's last layer: 3 channels)
+                const int img = m / HoWo, rem = m - img * HoWo;
+                float* o = reinterpret_cast<float*>(p.dst) + ((long long)img * p.Cout + co) * HoWo + rem;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) o[(long long)c * HoWo] = v[c];
+            } else if (p.dst_bf16) {
                 __bf16* o = reinterpret_cast<__bf16*>(p.dst) + dof;
                 if (vec_d) *reinterpret_cast<bf16x8*>(o) = hv;
                 else {
@@ -414,7 +419,10 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
     }
     E2_REQUIRE(q.wgroup_elems * 2 < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: packed weight group >= 4 GiB");
     E2_REQUIRE(((uintptr_t)d->wpacked & 15) == 0, E2FGVI_EINVAL, "conv2d_bf16x: packed weight not 16-byte aligned");
-    E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst slice exceeds dst_ld");
+    if (d->dst_nchw)
+        E2_REQUIRE(d->dst_dtype == E2FGVI_F32 && !d->dst2, E2FGVI_EINVAL, "conv2d_bf16x: the NCHW destination is fp32, without a second copy");
+    else
+        E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst slice exceeds dst_ld");
     E2_REQUIRE(((uintptr_t)d->dst & 15) == 0 && (!d->dst2 || ((uintptr_t)d->dst2 & 15) == 0) &&
                (!d->residual || ((uintptr_t)d->residual & 15) == 0), E2FGVI_EINVAL, "conv2d_bf16x: dst / dst2 / residual not 16-byte aligned");
     if (d->dst2) E2_REQUIRE(d->dst2_coff >= 0 && d->dst2_coff + d->Cout <= d->dst2_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst2 slice exceeds dst2_ld");
@@ -431,6 +439,7 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
     p.w = (const __bf16*)d->wpacked; p.bias = d->bias;
     p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff; p.res_bf16 = d->res_dtype == E2FGVI_BF16;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_bf16 = d->dst_dtype == E2FGVI_BF16;
+    p.dst_nchw = d->dst_nchw;
     p.dst2 = (__bf16*)d->dst2; p.dst2_ld = d->dst2_ld; p.dst2_coff = d->dst2_coff;
     p.act = d->act; p.slope = d->slope;
     hipStream_t st = (hipStream_t)stream;

@@ -37,8 +37,9 @@ class BF16Path:
             enc[k].name = "encoder.layers.%d" % i
         self.xdec = [PackedConvX(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1),
                      PackedConvX(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1),
-                     PackedConvX(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1)]
-        for k, n in enumerate(("decoder.0.conv", "decoder.2", "decoder.4.conv")):
+                     PackedConvX(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1),
+                     PackedConvX(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
+        for k, n in enumerate(("decoder.0.conv", "decoder.2", "decoder.4.conv", "decoder.6")):
             self.xdec[k].name = n
         self.xprop = {}
         for d, nparts in (("backward_", 2), ("forward_", 3)):
@@ -199,8 +200,8 @@ class BF16Path:
         x = d[0]([x], **lr)
         x = d[1]([x], **lr)
         x = ops.resize_bilinear(x, (4 * h, 4 * w), True)
-        x = d[2]([x], out_dtype=torch.float32, **lr)             # fp32 for the 64 -> 3 conv + tanh (fp32 kernel, NCHW store)
-        return self.dec[3]([x], act=ACT_TANH, out_nchw=True)
+        x = d[2]([x], **lr)
+        return d[3]([x], act=ACT_TANH, out_nchw=True)             # 64 -> 3, tanh, fp32 NCHW frames
 
     # ------------------------------------------------------------------ whole forward (e2fgvi_hq.py:235-263)
     def forward_x(self, frames, l_t, b, t, h, w, fh, fw, trace=None):

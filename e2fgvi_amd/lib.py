@@ -40,7 +40,7 @@ class ConvXDesc(C.Structure):
         ("res_dtype", C.c_int32),
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("dst_dtype", C.c_int32),
         ("dst2", _fp), ("dst2_ld", C.c_int32), ("dst2_coff", C.c_int32),
-        ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32), ("dst_nchw", C.c_int32),
     ]
 
 

@@ -7,6 +7,7 @@ and raises on error -- there is no eager fallback.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -44,6 +45,23 @@ TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
+# E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
+# exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
+_TUNE_FILE = os.environ.get("E2FGVI_TUNE_FILE")
+if _TUNE_FILE and os.path.exists(_TUNE_FILE):
+    import ast
+    for _line in open(_TUNE_FILE):
+        if _line.strip():
+            _k, _v = ast.literal_eval(_line)
+            _TUNED[_k] = _v
+
+
+def _remember(key, tile):
+    _TUNED[key] = tile
+    if _TUNE_FILE:
+        with open(_TUNE_FILE, "a") as fh:
+            fh.write(repr((key, tile)) + "\n")
+    return tile
 
 
 class PackedConv:
@@ -242,7 +260,7 @@ class PackedConv:
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
-                best = _TUNED[key] = self._autotune(lib, d, use_wino)
+                best = _remember(key, self._autotune(lib, d, use_wino))
             d.tile = best or 0
         if _L.TRACE is not None:
             _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile))
@@ -303,7 +321,7 @@ class PackedConvX:
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
 
     def __call__(self, sources, out=None, out_dtype=torch.bfloat16, out_coff=0, residual=None, res_coff=0, act=ACT_NONE,
-                 slope=0.0, out2=None, tile=0):
+                 slope=0.0, out2=None, tile=0, out_nchw=False):
         lib = _L.load()
         d = _L.ConvXDesc()
         srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
@@ -313,7 +331,8 @@ class PackedConvX:
         Ho, Wo = self.out_hw(H, W)
         dev = srcs[0][0].device
         if out is None:
-            out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=dev)
+            out = (torch.empty((N, self.Cout, Ho, Wo), dtype=torch.float32, device=dev) if out_nchw else
+                   torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=dev))
         per_img = max(H * W * t.shape[3] * 2 for t, _ in srcs)
         if N > 1 and N * per_img >= (1 << 32) - 1:                 # 32-bit buffer resources: image chunks
             step = max(1, ((1 << 32) - 2) // per_img)
@@ -321,7 +340,7 @@ class PackedConvX:
                 n1 = min(N, n0 + step)
                 self([(t[n0:n1], c) for t, c in srcs], out=out[n0:n1], out_coff=out_coff,
                      residual=None if residual is None else residual[n0:n1], res_coff=res_coff, act=act, slope=slope,
-                     out2=None if out2 is None else out2[n0:n1], tile=tile)
+                     out2=None if out2 is None else out2[n0:n1], tile=tile, out_nchw=out_nchw)
             return out
         for i, (t, coff) in enumerate(srcs):
             _chk(t, "source %d" % i, torch.bfloat16)
@@ -335,9 +354,14 @@ class PackedConvX:
         d.wpacked = self.wpacked.data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         _chk_any(out, "out")
-        if out.dim() != 4 or tuple(out.shape[:3]) != (N, Ho, Wo):
-            raise ValueError("out shape %s != [%d,%d,%d,*]" % (tuple(out.shape), N, Ho, Wo))
-        d.dst, d.dst_ld, d.dst_coff, d.dst_dtype = out.data_ptr(), out.shape[3], out_coff, _dt(out)
+        if out_nchw:
+            if tuple(out.shape) != (N, self.Cout, Ho, Wo) or out.dtype != torch.float32:
+                raise ValueError("NCHW out must be fp32 %s" % ((N, self.Cout, Ho, Wo),))
+            d.dst, d.dst_ld, d.dst_coff, d.dst_dtype, d.dst_nchw = out.data_ptr(), 0, 0, _L.DT_F32, 1
+        else:
+            if out.dim() != 4 or tuple(out.shape[:3]) != (N, Ho, Wo):
+                raise ValueError("out shape %s != [%d,%d,%d,*]" % (tuple(out.shape), N, Ho, Wo))
+            d.dst, d.dst_ld, d.dst_coff, d.dst_dtype = out.data_ptr(), out.shape[3], out_coff, _dt(out)
         if out2 is not None:
             _chk(out2, "out2", torch.bfloat16)
             if out2.dim() != 4 or tuple(out2.shape[:3]) != (N, Ho, Wo):

@@ -297,6 +297,7 @@ typedef struct {
     int32_t act;
     float slope;
     int32_t tile;                      /* 0 = auto                                                          */
+    int32_t dst_nchw;                  /* 1: dst is plain fp32 NCHW [N,Cout,Ho,Wo] (dst_ld / dst_coff ignored)  */
 } e2fgvi_convx_desc;
 
 int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream);

@@ -42,6 +42,7 @@ CASES = [
     ("7x7 stride 3 pad 3, 128 -> 512 (soft split)", 2, 30, 54, [128], 1, 512, 7, 3, 3, (0, 1)),
     ("1x1 256 -> 128 two sources (fusion)", 3, 9, 11, [128, 128], 1, 128, 1, 1, 0, (0, 1, 5)),
     ("3x3 64 -> 24 (narrow N)", 1, 16, 16, [64], 1, 24, 3, 1, 1, (0, 3)),
+    ("3x3 64 -> 3 (decoder.6)", 2, 24, 36, [64], 1, 3, 3, 1, 1, (0, 3)),
 ]
 
 
@@ -79,6 +80,9 @@ def test_conv_bf16x(dev, case):
     out = layer(src_d, residual=res16.to(dev), act=ops.ACT_RELU)
     assert out.dtype == torch.bfloat16
     assert_close_bf16(nchw(out.float().cpu()), F.relu(ref0 + nchw(res16.float())), name + " bf16 out, bf16 residual", abs_rms=1e-4)
+    if groups == 1:                                     # fp32 NCHW store (the decoder's last layer)
+        outn = layer(src_d, act=ops.ACT_TANH, out_nchw=True)
+        assert_close(outn.cpu(), torch.tanh(ref0), 3e-5, name + " NCHW fp32 out")
     # into a channel slice of a wider destination
     wide = torch.zeros(N, ref0.shape[2], ref0.shape[3], Cout + 24, dtype=torch.bfloat16, device=dev)
     layer(src_d, out=wide, out_coff=8)
@@ -195,7 +199,7 @@ def test_typed_helper_kernels(dev):
     s32 = ops.softcomp_fold(emb.float(), BT, fh, fw, H, W, 128, bias_hwc=bias, residual=res.float())
     assert torch.equal(s16, s32.bfloat16())
     r16, r32 = ops.resize_bilinear(res, (2 * H, 2 * W), True), ops.resize_bilinear(res.float(), (2 * H, 2 * W), True)
-    assert torch.equal(r16, r32.bfloat16())
+    assert_close_bf16(r16, r32, "x2 upsample", ulps=1.0, abs_rms=1e-6)      # two instantiations, two fp32 contraction orders
     # NCHW fp32 -> NHWC bf16 with channel padding
     fr = torch.rand(2, 3, 24, 40, generator=g).to(dev)
     n16 = ops.nchw_to_nhwc(fr, ld=8, out_dtype=torch.bfloat16)
