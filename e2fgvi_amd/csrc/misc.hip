@@ -20,6 +20,34 @@ template <> __device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
                __builtin_bit_cast(float, q[1] << 16), __builtin_bit_cast(float, q[1] & 0xFFFF0000u)};
     return v;
 }
+// channels per thread: 4 for fp32 tensors, 8 for bf16 tensors -- a 16-byte access either way.  ldv / stv move VT<T>::N
+// consecutive channels as VT<T>::Q fp32 quads; ldf loads the same channel count from an fp32 tensor.
+typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+template <typename T> struct VT;
+template <> struct VT<float> { static constexpr int N = 4, Q = 1; };
+template <> struct VT<__bf16> { static constexpr int N = 8, Q = 2; };
+template <typename T> __device__ __forceinline__ void ldv(const T* p, f32x4 (&v)[VT<T>::Q]);
+template <> __device__ __forceinline__ void ldv<float>(const float* p, f32x4 (&v)[1]) { v[0] = *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ void ldv<__bf16>(const __bf16* p, f32x4 (&v)[2]) {
+    const u32x4m q = *reinterpret_cast<const u32x4m*>(p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        v[i][0] = __builtin_bit_cast(float, q[2 * i] << 16);     v[i][1] = __builtin_bit_cast(float, q[2 * i] & 0xFFFF0000u);
+        v[i][2] = __builtin_bit_cast(float, q[2 * i + 1] << 16); v[i][3] = __builtin_bit_cast(float, q[2 * i + 1] & 0xFFFF0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ void stv(T* p, const f32x4 (&v)[VT<T>::Q]);
+template <> __device__ __forceinline__ void stv<float>(float* p, const f32x4 (&v)[1]) { *reinterpret_cast<f32x4*>(p) = v[0]; }
+template <> __device__ __forceinline__ void stv<__bf16>(__bf16* p, const f32x4 (&v)[2]) {
+    typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
+    bf16x8m h = {(__bf16)v[0][0], (__bf16)v[0][1], (__bf16)v[0][2], (__bf16)v[0][3],
+                 (__bf16)v[1][0], (__bf16)v[1][1], (__bf16)v[1][2], (__bf16)v[1][3]};
+    *reinterpret_cast<bf16x8m*>(p) = h;
+}
+template <int Q> __device__ __forceinline__ void ldf(const float* p, f32x4 (&v)[Q]) {
+#pragma unroll
+    for (int i = 0; i < Q; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + 4 * i);
+}
 template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
@@ -43,6 +71,24 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, TO* __restric
         const int p = p0 + r, c = c0 + threadIdx.x;
         if (p < HW && c < ld) dst[((long long)n * HW + p) * ld + c] = (TO)((c < C) ? tile[threadIdx.x][r] : 0.f);
     }
+}
+
+// frames with few channels (C <= 8) -> NHWC pixels of exactly 8 channels (zeros beyond C): one thread per pixel, every
+// plane read is coalesced across the lanes and the pixel leaves as one 16-byte (bf16) / two 16-byte (fp32) stores.  The
+// tiled transpose above moves 32 B per 32-lane row for such tensors (358 us for ten 720x1296 frames; this: ~35 us).
+template <typename TO>
+__global__ void nchw_small_to_nhwc8_kernel(const float* __restrict__ src, TO* __restrict__ dst, int C, int HW, float scale,
+                                           float shift, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long n = idx / HW;
+    const int p = (int)(idx - n * HW);
+    f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < C) v[c >> 2][c & 3] = src[(n * C + c) * HW + p] * scale + shift;
+    st4(dst + idx * 8, v[0]);
+    st4(dst + idx * 8 + 4, v[1]);
 }
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int C, int HW) {
@@ -104,13 +150,14 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ src, int src_nc
 // NHWC -> NHWC, 4 channels per thread (16-byte loads/stores): the decoder's x2 upsample moves 130-400 MB per call
 template <typename T>
 __global__ void resize_bilinear_vec4_kernel(const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld,
-                                            int N, int C4, int H, int W, int Ho, int Wo, int align, float sh, float sw,
+                                            int N, int CV, int H, int W, int Ho, int Wo, int align, float sh, float sw,
                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                             long long total) {
+    constexpr int NV = VT<T>::N, Q = VT<T>::Q;          // CV = C / NV channel vectors per pixel
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c4 = (int)(idx % C4);
-    long long r = idx / C4;
+    const int cv = (int)(idx % CV);
+    long long r = idx / CV;
     const int ox = (int)(r % Wo);
     r /= Wo;
     const int oy = (int)(r % Ho);
@@ -120,15 +167,19 @@ __global__ void resize_bilinear_vec4_kernel(const T* __restrict__ src, int src_l
     src_index(oy, sh, align, H, y0, y1, ly);
     src_index(ox, sw, align, W, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const T* b = src + (long long)n * H * W * src_ld + c4 * 4;
-    const f32x4 v00 = ld4(b + ((long long)y0 * W + x0) * src_ld);
-    const f32x4 v01 = ld4(b + ((long long)y0 * W + x1) * src_ld);
-    const f32x4 v10 = ld4(b + ((long long)y1 * W + x0) * src_ld);
-    const f32x4 v11 = ld4(b + ((long long)y1 * W + x1) * src_ld);
-    f32x4 v = (v00 * hx + v01 * lx) * hy + (v10 * hx + v11 * lx) * ly;
-    if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c4 * 4);
-    if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + c4 * 4);
-    st4(dst + (((long long)n * Ho + oy) * Wo + ox) * dst_ld + c4 * 4, v);
+    const T* b = src + (long long)n * H * W * src_ld + cv * NV;
+    f32x4 v00[Q], v01[Q], v10[Q], v11[Q], v[Q];
+    ldv(b + ((long long)y0 * W + x0) * src_ld, v00);
+    ldv(b + ((long long)y0 * W + x1) * src_ld, v01);
+    ldv(b + ((long long)y1 * W + x0) * src_ld, v10);
+    ldv(b + ((long long)y1 * W + x1) * src_ld, v11);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        v[q] = (v00[q] * hx + v01[q] * lx) * hy + (v10[q] * hx + v11[q] * lx) * ly;
+        if (scale) v[q] = v[q] * *reinterpret_cast<const f32x4*>(scale + cv * NV + 4 * q);
+        if (shift) v[q] = v[q] + *reinterpret_cast<const f32x4*>(shift + cv * NV + 4 * q);
+    }
+    stv(dst + (((long long)n * Ho + oy) * Wo + ox) * dst_ld + cv * NV, v);
 }
 
 __global__ void avgpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, long long total) {
@@ -228,10 +279,11 @@ __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const 
                                  const float* __restrict__ flow_a, const float* __restrict__ flow_b,
                                  long long flow_img_stride, TC* __restrict__ cond, float* __restrict__ flows,
                                  __bf16* __restrict__ flows8, int N, int H, int W, int C) {
-    const int cq = C / 4;
+    constexpr int NV = VT<TC>::N, Q = VT<TC>::Q;
+    const int cq = C / NV;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * H * W * cq) return;
-    const int c4 = (int)(idx % cq);
+    const int c4 = (int)(idx % cq);                    // channel vector index
     const long long pix = idx / cq;
     const int x = (int)(pix % W);
     const int y = (int)((pix / W) % H);
@@ -241,8 +293,9 @@ __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const 
     const float2 f1 = *reinterpret_cast<const float2*>(fa + ip * 2);
     const Bil b1 = bil_zeros((float)x + f1.x, (float)y + f1.y, H, W);
     float2 fl2 = make_float2(0.f, 0.f);
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 c2 = z;
+    f32x4 c1[Q], c2[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) c2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (flow_b) {
         const float* fb = flow_b + n * flow_img_stride;
         const float2 a00 = *reinterpret_cast<const float2*>(fb + b1.o00 * 2);
@@ -252,20 +305,22 @@ __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const 
         fl2.x = f1.x + (a00.x * b1.w00 + a01.x * b1.w01 + a10.x * b1.w10 + a11.x * b1.w11);
         fl2.y = f1.y + (a00.y * b1.w00 + a01.y * b1.w01 + a10.y * b1.w10 + a11.y * b1.w11);
         const Bil b2 = bil_zeros((float)x + fl2.x, (float)y + fl2.y, H, W);
-        const float* s2 = f2 + (long long)n * H * W * f2_ld + c4 * 4;
-        c2 = *reinterpret_cast<const f32x4*>(s2 + b2.o00 * f2_ld) * b2.w00 +
-             *reinterpret_cast<const f32x4*>(s2 + b2.o01 * f2_ld) * b2.w01 +
-             *reinterpret_cast<const f32x4*>(s2 + b2.o10 * f2_ld) * b2.w10 +
-             *reinterpret_cast<const f32x4*>(s2 + b2.o11 * f2_ld) * b2.w11;
+        const float* s2 = f2 + (long long)n * H * W * f2_ld + c4 * NV;
+        f32x4 a[Q], bq[Q], cc[Q], dd[Q];
+        ldf<Q>(s2 + b2.o00 * f2_ld, a); ldf<Q>(s2 + b2.o01 * f2_ld, bq); ldf<Q>(s2 + b2.o10 * f2_ld, cc); ldf<Q>(s2 + b2.o11 * f2_ld, dd);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c2[q] = a[q] * b2.w00 + bq[q] * b2.w01 + cc[q] * b2.w10 + dd[q] * b2.w11;
     }
-    const float* s1 = fp + (long long)n * H * W * fp_ld + c4 * 4;
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(s1 + b1.o00 * fp_ld) * b1.w00 +
-                     *reinterpret_cast<const f32x4*>(s1 + b1.o01 * fp_ld) * b1.w01 +
-                     *reinterpret_cast<const f32x4*>(s1 + b1.o10 * fp_ld) * b1.w10 +
-                     *reinterpret_cast<const f32x4*>(s1 + b1.o11 * fp_ld) * b1.w11;
+    {
+        const float* s1 = fp + (long long)n * H * W * fp_ld + c4 * NV;
+        f32x4 a[Q], bq[Q], cc[Q], dd[Q];
+        ldf<Q>(s1 + b1.o00 * fp_ld, a); ldf<Q>(s1 + b1.o01 * fp_ld, bq); ldf<Q>(s1 + b1.o10 * fp_ld, cc); ldf<Q>(s1 + b1.o11 * fp_ld, dd);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c1[q] = a[q] * b1.w00 + bq[q] * b1.w01 + cc[q] * b1.w10 + dd[q] * b1.w11;
+    }
     TC* co = cond + pix * (2 * C);
-    st4(co + c4 * 4, c1);
-    st4(co + C + c4 * 4, c2);
+    stv(co + c4 * NV, c1);
+    stv(co + C + c4 * NV, c2);
     if (c4 == 0) {
         f32x4 fo = {f1.x, f1.y, fl2.x, fl2.y};
         *reinterpret_cast<f32x4*>(flows + pix * 4) = fo;
@@ -319,7 +374,8 @@ template <typename T>
 __global__ void window_pool_kernel(const T* __restrict__ x, const float* __restrict__ w45,
                                    const float* __restrict__ bias1, T* __restrict__ pooled, int BT, int fh, int fw,
                                    int C) {
-    const int cq = C / 4;
+    constexpr int NV = VT<T>::N, Q = VT<T>::Q;
+    const int cq = C / NV;
     const int nWw = fw / 9, nWh = fh / 5;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)BT * nWh * nWw * cq) return;
@@ -330,13 +386,17 @@ __global__ void window_pool_kernel(const T* __restrict__ x, const float* __restr
     const int wy = (int)(r % nWh);
     const long long bt = r / nWh;
     const float b = bias1[0];
-    f32x4 acc = {b, b, b, b};
+    f32x4 acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = f32x4{b, b, b, b};
     for (int py = 0; py < 5; ++py)
         for (int px = 0; px < 9; ++px) {
-            const f32x4 v = ld4(x + ((bt * fh + wy * 5 + py) * fw + wx * 9 + px) * C + c4 * 4);
-            acc = acc + v * w45[py * 9 + px];
+            f32x4 v[Q];
+            ldv(x + ((bt * fh + wy * 5 + py) * fw + wx * 9 + px) * C + c4 * NV, v);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = acc[q] + v[q] * w45[py * 9 + px];
         }
-    st4(pooled + idx * 4, acc);
+    stv(pooled + idx * NV, acc);
 }
 
 // ------------------------------------------------------------------------------------------ fold / unfold (7,3,3)
@@ -353,7 +413,9 @@ template <bool NORMALISE, typename TE, typename TR, typename TD>
 __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict__ bias_hwc,
                             const TR* __restrict__ residual, TD* __restrict__ dst, int F, int fh, int fw, int H,
                             int W, int C) {
-    const int cq = C / 4;
+    static_assert(VT<TE>::N == VT<TD>::N && VT<TR>::N == VT<TD>::N, "fold: one element class per instantiation");
+    constexpr int NV = VT<TD>::N, Q = VT<TD>::Q;
+    const int cq = C / NV;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)F * H * W * cq) return;
     const int c4 = (int)(idx % cq);
@@ -365,23 +427,39 @@ __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict_
     int ly0, ly1, lx0, lx1;
     fold_range(Y, fh, ly0, ly1);
     fold_range(X, fw, lx0, lx1);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int row_len = 49 * C;
     for (int ly = ly0; ly <= ly1; ++ly) {
         const int ki = Y + 3 - 3 * ly;
         for (int lx = lx0; lx <= lx1; ++lx) {
             const int kj = X + 3 - 3 * lx;
-            acc = acc + ld4(emb + ((f * fh + ly) * fw + lx) * row_len + (ki * 7 + kj) * C + c4 * 4);
+            f32x4 v[Q];
+            ldv(emb + ((f * fh + ly) * fw + lx) * row_len + (ki * 7 + kj) * C + c4 * NV, v);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = acc[q] + v[q];
         }
     }
     if (NORMALISE) {
         const float cnt = (float)((ly1 - ly0 + 1) * (lx1 - lx0 + 1));
-        acc = acc / cnt;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = acc[q] / cnt;
     }
-    const long long o = ((f * H + Y) * W + X) * C + c4 * 4;
-    if (bias_hwc) acc = acc + *reinterpret_cast<const f32x4*>(bias_hwc + ((long long)Y * W + X) * C + c4 * 4);
-    if (residual) acc = acc + ld4(residual + o);
-    st4(dst + o, acc);
+    const long long o = ((f * H + Y) * W + X) * C + c4 * NV;
+    if (bias_hwc) {
+        f32x4 bq[Q];
+        ldf<Q>(bias_hwc + ((long long)Y * W + X) * C + c4 * NV, bq);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = acc[q] + bq[q];
+    }
+    if (residual) {
+        f32x4 rq[Q];
+        ldv(residual + o, rq);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] = acc[q] + rq[q];
+    }
+    stv(dst + o, acc);
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -389,7 +467,8 @@ __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + 
 template <typename T>
 __global__ void unfold_gelu_kernel(const T* __restrict__ folded, T* __restrict__ out, int F, int fh, int fw,
                                    int H, int W, int C) {
-    const int cq = C / 4;
+    constexpr int NV = VT<T>::N, Q = VT<T>::Q;
+    const int cq = C / NV;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)F * fh * fw * 49 * cq) return;
     const int c4 = (int)(idx % cq);
@@ -401,13 +480,17 @@ __global__ void unfold_gelu_kernel(const T* __restrict__ folded, T* __restrict__
     const int ly = (int)(r % fh);
     const long long f = r / fh;
     const int Y = 3 * ly - 3 + tap / 7, X = 3 * lx - 3 + tap % 7;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (Y >= 0 && Y < H && X >= 0 && X < W) {
-        v = ld4(folded + ((f * H + Y) * W + X) * C + c4 * 4);
+    f32x4 v[Q];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+    for (int q = 0; q < Q; ++q) v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        ldv(folded + ((f * H + Y) * W + X) * C + c4 * NV, v);
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q][e] = gelu_exact(v[q][e]);
     }
-    st4(out + idx * 4, v);
+    stv(out + idx * NV, v);
 }
 
 // fp32 <-> bf16 element conversion (4 elements per thread)
@@ -427,6 +510,17 @@ extern "C" int e2fgvi_nchw_to_nhwc_x(const float* src, void* dst, int32_t dst_dt
                                      int32_t ld, float scale, float shift, void* stream) {
     E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C && E2_DT_OK(dst_dtype), E2FGVI_EINVAL,
                "nchw_to_nhwc: bad arguments");
+    if (ld == 8 && C <= 8 && ((uintptr_t)dst & 15) == 0) {
+        const long long total = (long long)N * H * W;
+        if (dst_dtype == E2FGVI_BF16)
+            hipLaunchKernelGGL(nchw_small_to_nhwc8_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src,
+                               (__bf16*)dst, C, H * W, scale, shift, total);
+        else
+            hipLaunchKernelGGL(nchw_small_to_nhwc8_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src,
+                               (float*)dst, C, H * W, scale, shift, total);
+        E2_LAUNCH_CHECK("nchw_to_nhwc8");
+        return 0;
+    }
     dim3 grid(cdiv(H * W, 32), cdiv(ld, 32), N), block(32, 8);
     if (dst_dtype == E2FGVI_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, src, (__bf16*)dst, C, H * W, ld, scale, shift);
@@ -485,14 +579,14 @@ extern "C" int e2fgvi_resize_bilinear(const float* src, int32_t src_nchw, int32_
 
 extern "C" int e2fgvi_resize_bilinear_bf16(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int32_t N, int32_t C,
                                            int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t align_corners, void* stream) {
-    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && dst_ld >= C && src_ld >= C && C % 4 == 0 &&
-                   src_ld % 4 == 0 && dst_ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 7) == 0,
-               E2FGVI_EINVAL, "resize_bilinear_bf16: bad arguments (NHWC bf16, channels in multiples of 4)");
+    E2_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && dst_ld >= C && src_ld >= C && C % 8 == 0 &&
+                   src_ld % 8 == 0 && dst_ld % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+               E2FGVI_EINVAL, "resize_bilinear_bf16: bad arguments (NHWC bf16, channels in multiples of 8)");
     float sh, sw;
     resize_scales(H, W, Ho, Wo, align_corners, sh, sw);
-    const long long total4 = (long long)N * Ho * Wo * (C / 4);
+    const long long total4 = (long long)N * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(resize_bilinear_vec4_kernel<__bf16>, dim3(blocks_for(total4)), dim3(NTH), 0, (hipStream_t)stream,
-                       (const __bf16*)src, src_ld, (__bf16*)dst, dst_ld, N, C / 4, H, W, Ho, Wo, align_corners, sh, sw,
+                       (const __bf16*)src, src_ld, (__bf16*)dst, dst_ld, N, C / 8, H, W, Ho, Wo, align_corners, sh, sw,
                        (const float*)nullptr, (const float*)nullptr, total4);
     E2_LAUNCH_CHECK("resize_bilinear_bf16");
     return 0;
@@ -533,7 +627,9 @@ extern "C" int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const f
                    E2_DT_OK(cond_dtype),
                E2FGVI_EINVAL, "prop_cond: bad arguments");
     E2_REQUIRE(!flow_b || (feat_n2 && f2_ld % 4 == 0), E2FGVI_EINVAL, "prop_cond: flow_b needs feat_n2");
-    const long long total = (long long)N * H * W * (C / 4);
+    const int nv = cond_dtype == E2FGVI_BF16 ? 8 : 4;             // channels per thread
+    E2_REQUIRE(C % nv == 0, E2FGVI_EINVAL, "prop_cond: C must be a multiple of %d", nv);
+    const long long total = (long long)N * H * W * (C / nv);
     if (cond_dtype == E2FGVI_BF16)
         hipLaunchKernelGGL(prop_cond_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
                            feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, (__bf16*)cond, flows,
@@ -582,7 +678,8 @@ extern "C" int e2fgvi_window_pool_x(const void* x, int32_t dtype, const float* w
     E2_REQUIRE(x && w45 && bias1 && pooled && BT > 0 && fh > 0 && fw > 0 && fh % 5 == 0 && fw % 9 == 0 && C % 4 == 0 &&
                    E2_DT_OK(dtype),
                E2FGVI_EINVAL, "window_pool: bad arguments");
-    const long long total = (long long)BT * (fh / 5) * (fw / 9) * (C / 4);
+    E2_REQUIRE(dtype == E2FGVI_F32 || C % 8 == 0, E2FGVI_EINVAL, "window_pool: bf16 needs C %% 8 == 0");
+    const long long total = (long long)BT * (fh / 5) * (fw / 9) * (C / (dtype == E2FGVI_BF16 ? 8 : 4));
     if (dtype == E2FGVI_BF16)
         hipLaunchKernelGGL(window_pool_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
                            (const __bf16*)x, w45, bias1, (__bf16*)pooled, BT, fh, fw, C);
@@ -608,7 +705,8 @@ extern "C" int e2fgvi_ffn_fold_x(const void* hid, void* folded, int32_t dtype, i
                                  int32_t W, int32_t C, void* stream) {
     E2_REQUIRE(hid && folded && E2_DT_OK(dtype), E2FGVI_EINVAL, "ffn_fold: bad arguments");
     if (int rc = check_fold("ffn_fold", F, fh, fw, H, W, C)) return rc;
-    const long long total = (long long)F * H * W * (C / 4);
+    E2_REQUIRE(dtype == E2FGVI_F32 || C % 8 == 0, E2FGVI_EINVAL, "ffn_fold: bf16 needs C %% 8 == 0");
+    const long long total = (long long)F * H * W * (C / (dtype == E2FGVI_BF16 ? 8 : 4));
     if (dtype == E2FGVI_BF16)
         hipLaunchKernelGGL((fold_kernel<true, __bf16, __bf16, __bf16>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
                            (const __bf16*)hid, (const float*)nullptr, (const __bf16*)nullptr, (__bf16*)folded, F, fh, fw, H, W, C);
@@ -627,7 +725,8 @@ extern "C" int e2fgvi_ffn_unfold_gelu_x(const void* folded, void* out, int32_t d
                                         int32_t H, int32_t W, int32_t C, void* stream) {
     E2_REQUIRE(folded && out && E2_DT_OK(dtype), E2FGVI_EINVAL, "ffn_unfold_gelu: bad arguments");
     if (int rc = check_fold("ffn_unfold_gelu", F, fh, fw, H, W, C)) return rc;
-    const long long total = (long long)F * fh * fw * 49 * (C / 4);
+    E2_REQUIRE(dtype == E2FGVI_F32 || C % 8 == 0, E2FGVI_EINVAL, "ffn_unfold_gelu: bf16 needs C %% 8 == 0");
+    const long long total = (long long)F * fh * fw * 49 * (C / (dtype == E2FGVI_BF16 ? 8 : 4));
     if (dtype == E2FGVI_BF16)
         hipLaunchKernelGGL(unfold_gelu_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
                            (const __bf16*)folded, (__bf16*)out, F, fh, fw, H, W, C);
@@ -657,7 +756,8 @@ extern "C" int e2fgvi_softcomp_fold_bf16(const void* emb, const float* bias_hwc,
                                          int32_t fh, int32_t fw, int32_t H, int32_t W, int32_t C, void* stream) {
     E2_REQUIRE(emb && dst, E2FGVI_EINVAL, "softcomp_fold_bf16: null pointer");
     if (int rc = check_fold("softcomp_fold_bf16", F, fh, fw, H, W, C)) return rc;
-    const long long total = (long long)F * H * W * (C / 4);
+    E2_REQUIRE(C % 8 == 0, E2FGVI_EINVAL, "softcomp_fold_bf16: C %% 8 != 0");
+    const long long total = (long long)F * H * W * (C / 8);
     hipLaunchKernelGGL((fold_kernel<false, __bf16, __bf16, __bf16>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
                        (const __bf16*)emb, bias_hwc, (const __bf16*)residual, (__bf16*)dst, F, fh, fw, H, W, C);
     E2_LAUNCH_CHECK("softcomp_fold_bf16");

@@ -199,19 +199,16 @@ class Engine(BF16Path):
                 for k in ("qkv", "proj", "fc1", "fc2"):
                     blk[k].tune = True
             self.ss.tune = self.sc.tune = self.fusion.tune = True
-            # Winograd layers: the best block shape (16x16 / 8x16 pixels x 32 / 64 couts) depends on how many blocks the
-            # call has -- one 60x108 frame per propagation step vs 10 frames in the encoder
-            for c in self.enc + self.dec + [q for off, _, bb in self.prop.values() for q in off + bb]:
-                if c.algo == "auto":
-                    c.tune = True
-            if self.hq:
-                self.sc_bias_conv.tune = True
+            # (Winograd block shapes are NOT tuned at run time: measured in round 2, the timing-based choice between the
+            # 16x16 / 8x16-pixel blocks moved the forward by -1 ... -2 % and added run-to-run variance; the static rule of
+            # e2fgvi_conv3x3_winograd stays.)
         # SPyNet runs on a side stream next to the encoder, in both precision modes.  Round 1 found the side stream's
         # kernels corrupted beside bf16 MFMA tiles; round 2 traced it to packed-fp32 VALU instructions consuming freshly
         # loaded registers (tools/probe/overlap_probe.hip, DESIGN.md "Stream overlap"): every kernel that can run on the
         # side stream is built without them (csrc/misc.hip and the `nopk` build of conv.hip, e2fgvi_amd/build.py).
         self.overlap_flows = True
         if self.bf16:
+            self.autotune_x = autotune and os.environ.get("E2FGVI_AUTOTUNE", "1") != "0"
             self._init_x(f)
         self._side = None
         torch.cuda.synchronize(self.device)

@@ -92,6 +92,19 @@ class BF16Path:
                 blk[k].name = "transformer.%d.%s" % (i, k)
             self.xblocks.append(blk)
 
+        if self.autotune_x:
+            # the best tile of conv_bf16x depends on the layer's M x N x K and on how many tiles that makes for 256 CUs:
+            # timed on the first (eager) call of each size class, never under graph capture
+            layers = self.xenc + self.xdec + [self.xfusion, self.xss, self.xsc] + [c for cv in self.xspy for c in cv]
+            for off, bb, _ in self.xprop.values():
+                layers += off + bb
+            for blk in self.xblocks:
+                layers += [blk[k] for k in ("qkv", "proj", "fc1", "fc2")]
+            if self.hq:
+                layers.append(self.xsc_bias_conv)
+            for c in layers:
+                c.tune = True
+
     def _zero16(self, shape):
         key = ("bf16",) + tuple(shape)
         if key not in self._zeros:

@@ -44,6 +44,8 @@ def empty_nhwc(n, h, w, c, device):
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
+# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 (8 waves), 128x64, 64x64, 128x32 tiles
+XTUNE_CANDIDATES = (1, 4, 6, 2, 5, 3)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
 # exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
@@ -308,6 +310,7 @@ class PackedConvX:
             raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
         self.groups, self.stride, self.pad = groups, stride, pad
         self.name = "conv"
+        self.tune = False          # time XTUNE_CANDIDATES on the first call of every new size class and keep the fastest
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         n = lib.e2fgvi_packed_conv_weight_bf16x_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
         if n < 0:
@@ -373,6 +376,14 @@ class PackedConvX:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff, d.res_dtype = residual.data_ptr(), residual.shape[3], res_coff, _dt(residual)
         d.act, d.slope, d.tile = act, slope, tile
+        if tile == 0 and self.tune and N * Ho * Wo >= 2048:
+            key = ("x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
+                   int(4.0 * math.log2(N * Ho * Wo)), _dt(out), out_nchw)
+            best = _TUNED.get(key)
+            if best is None and not torch.cuda.is_current_stream_capturing() and (
+                    residual is None or residual.data_ptr() != out.data_ptr()):
+                best = _remember(key, self._autotune(lib, d))
+            d.tile = tile = best or 0
         if _L.TRACE is not None:
             cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
             cin_p = sum(-(-c // 64) * 64 for c in self.cpg)
@@ -382,6 +393,32 @@ class PackedConvX:
                 issued=N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2)
         _L.check(lib.e2fgvi_conv2d_bf16x(C.byref(d), _stream()), "conv2d_bf16x")
         return out
+
+
+    def _autotune(self, lib, d):
+        """device time of every tile shape on this exact call (the launches rewrite the same output)"""
+        best, best_ms = 0, float("inf")
+        st = _stream()
+        d.tile = 0
+        for _ in range(2):
+            lib.e2fgvi_conv2d_bf16x(C.byref(d), st)
+        for code in XTUNE_CANDIDATES:
+            if code == 3 and self.Cout // self.groups > 64:       # 32-wide tiles only make sense for narrow layers
+                continue
+            d.tile = code
+            if lib.e2fgvi_conv2d_bf16x(C.byref(d), st) != 0:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                lib.e2fgvi_conv2d_bf16x(C.byref(d), st)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if ms < best_ms:
+                best, best_ms = code, ms
+        d.tile = 0
+        return best
 
 
 class PackedLinearX(PackedConvX):

@@ -15,7 +15,11 @@ LAYERS = [("encoder.10", 10, 180, 324, [128, 192], 2, 512, 3, 1, 1), ("encoder.8
           ("qkv", 64800 + 1440, 1, 1, [512], 1, 1536, 1, 1, 0), ("proj", 64800, 1, 1, [512], 1, 512, 1, 1, 0),
           ("fc1", 64800, 1, 1, [512], 1, 1960, 1, 1, 0), ("fc2", 64800, 1, 1, [1960], 1, 512, 1, 1, 0),
           ("sc", 64800, 1, 1, [512], 1, 6272, 1, 1, 0)]
+only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None
+tiles = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 5, 6]
 for name, N, H, W, cpg, groups, Cout, k, s, p in LAYERS:
+    if only and name not in only:
+        continue
     w = torch.randn(Cout, sum(cpg), k, k, device=dev) * 0.02
     layer = ops.PackedConvX(w, torch.zeros(Cout, device=dev), cpg, groups=groups, stride=s, pad=p)
     srcs = [torch.randn(N, H, W, c * groups, device=dev).bfloat16() for c in cpg]
@@ -23,7 +27,7 @@ for name, N, H, W, cpg, groups, Cout, k, s, p in LAYERS:
     out = torch.empty(N, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
     gflop = 2e-9 * N * Ho * Wo * Cout * sum(cpg) * k * k
     res = {}
-    for tile in (1, 2, 4, 5, 6):
+    for tile in tiles:
         try:
             layer(srcs, out=out, act=ops.ACT_LRELU, slope=0.2, tile=tile)
         except Exception as e:
