@@ -63,7 +63,16 @@ __device__ __forceinline__ float dcn_post(float v, int co, int C, const f32x4& f
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    // counted wait: the N most recent LDS-DMA loads (the stage after next) stay in flight across the barrier; a plain
+    // __syncthreads() would drain them (hipcc emits vmcnt(0) in front of it while an LDS-DMA is outstanding)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// STAGES = 2: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.
+// STAGES = 3: the DMA runs TWO steps ahead; the barrier that ends step s waits only for step s+1's loads (counted vmcnt).
+template <int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
     constexpr int NT = 64 * WGM * WGN;
@@ -73,7 +82,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte DMA items per thread
     constexpr int R = TM * 32, CN = TN * 32, LDE = CN + 4;      // a wave's epilogue region: R rows of LDE floats
     constexpr int EPI = WGM * WGN * R * LDE * 4;
-    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    constexpr int SMEM = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
+    constexpr int NLOADS = A_IT + B_IT;                         // LDS-DMA instructions per thread and step
+    static_assert(STAGES == 2 || STAGES == 3, "stages");
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile");
 
@@ -177,13 +188,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) b_rd[tn] = A_BYTES + ((wn * TN + tn) * 32 + i) * 16;
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int step = 0; step < p.nsteps; ++step) {
-        const int cur = step & 1;
-        if (step + 1 < p.nsteps) issue(cur ^ 1, step + 1);
-        const unsigned char* st = smem + cur * STAGE;
+    auto compute = [&](const unsigned char* st) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 a[TM], b[TN];
@@ -199,8 +204,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed (this wave's share)
-        __syncthreads();                                        // ... everybody's, and this stage's readers are done
+    };
+    if (STAGES == 2) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int step = 0; step < p.nsteps; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < p.nsteps) issue(cur ^ 1, step + 1);
+            compute(smem + cur * STAGE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed (this wave's share)
+            __syncthreads();                                        // ... everybody's, and this stage's readers are done
+        }
+    } else {
+        issue(0, 0);
+        if (p.nsteps > 1) {
+            issue(1, 1);
+            wait_vm_and_barrier<NLOADS>();                          // stage 0 landed, stage 1 in flight
+        } else {
+            wait_vm_and_barrier<0>();
+        }
+        int cur = 0;                                                // step % 3
+        for (int step = 0; step < p.nsteps; ++step) {
+            // stage (step + 2) % 3 was read during step - 1: its readers passed the barrier that ended that step
+            if (step + 2 < p.nsteps) issue(cur == 0 ? 2 : cur - 1, step + 2);
+            compute(smem + cur * STAGE);
+            if (step + 2 < p.nsteps) wait_vm_and_barrier<NLOADS>();  // step + 1 landed; step + 2 stays in flight
+            else wait_vm_and_barrier<0>();
+            cur = cur == 2 ? 0 : cur + 1;
+        }
     }
 
     // ---- epilogue through LDS
@@ -359,11 +391,11 @@ __global__ void pack_conv_weight_bf16x_kernel(const float* __restrict__ w, __bf1
     wp[idx] = (__bf16)v;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int STAGES>
 int launch_x(ConvXParams& p, int groups, hipStream_t st) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout_g, BN);
-    hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+    hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, STAGES>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
     E2_LAUNCH_CHECK("conv2d_bf16x");
     return 0;
 }
@@ -450,12 +482,19 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
         else tile = ((long long)cdiv(p.M, 128) * cdiv(p.Cout_g, 128) * d->groups >= 384) ? 1 : 4;
     }
     switch (tile) {
-        case 1: return launch_x<128, 128, 2, 2>(p, d->groups, st);
-        case 2: return launch_x<128, 64, 2, 2>(p, d->groups, st);
-        case 3: return launch_x<128, 32, 4, 1>(p, d->groups, st);
-        case 4: return launch_x<64, 128, 2, 2>(p, d->groups, st);
-        case 5: return launch_x<64, 64, 2, 2>(p, d->groups, st);
-        case 6: return launch_x<256, 128, 4, 2>(p, d->groups, st);
+        case 1: return launch_x<128, 128, 2, 2, 2>(p, d->groups, st);
+        case 2: return launch_x<128, 64, 2, 2, 2>(p, d->groups, st);
+        case 3: return launch_x<128, 32, 4, 1, 2>(p, d->groups, st);
+        case 4: return launch_x<64, 128, 2, 2, 2>(p, d->groups, st);
+        case 5: return launch_x<64, 64, 2, 2, 2>(p, d->groups, st);
+        case 6: return launch_x<256, 128, 4, 2, 2>(p, d->groups, st);
+        // the same tiles with the LDS-DMA two steps ahead (3 LDS stages)
+        case 11: return launch_x<128, 128, 2, 2, 3>(p, d->groups, st);
+        case 12: return launch_x<128, 64, 2, 2, 3>(p, d->groups, st);
+        case 13: return launch_x<128, 32, 4, 1, 3>(p, d->groups, st);
+        case 14: return launch_x<64, 128, 2, 2, 3>(p, d->groups, st);
+        case 15: return launch_x<64, 64, 2, 2, 3>(p, d->groups, st);
+        case 16: return launch_x<256, 128, 4, 2, 3>(p, d->groups, st);
         default: break;
     }
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);

@@ -44,8 +44,9 @@ def empty_nhwc(n, h, w, c, device):
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
-# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 (8 waves), 128x64, 64x64, 128x32 tiles
-XTUNE_CANDIDATES = (1, 4, 6, 2, 5, 3)
+# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 (8 waves), 128x64, 64x64, 128x32 tiles; +10 = the same tile with
+# three LDS stages (LDS-DMA two K-steps ahead)
+XTUNE_CANDIDATES = (1, 4, 6, 2, 5, 3, 11, 14, 16, 12, 15, 13)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
 # exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
@@ -403,7 +404,7 @@ class PackedConvX:
         for _ in range(2):
             lib.e2fgvi_conv2d_bf16x(C.byref(d), st)
         for code in XTUNE_CANDIDATES:
-            if code == 3 and self.Cout // self.groups > 64:       # 32-wide tiles only make sense for narrow layers
+            if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
                 continue
             d.tile = code
             if lib.e2fgvi_conv2d_bf16x(C.byref(d), st) != 0:
