@@ -35,10 +35,10 @@ struct ConvXParams {
     int Cout, Cout_g, Npad;
     int M;
     int tilesM, tilesN;
-    int nsteps;                           // KH * KW * (64-channel blocks per tap)
+    int nsteps;                           // KH * KW * (K-step blocks per tap); a K-step = 64 bf16 / 32 fp32 channels
     unsigned wgroup_bytes;
     long long wgroup_elems;
-    const __bf16* w;
+    const void* w;
     const float* bias;
     const void* res;
     int res_ld, res_coff, res_bf16;
@@ -72,12 +72,18 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
 
 // STAGES = 2: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.
 // STAGES = 3: the DMA runs TWO steps ahead; the barrier that ends step s waits only for step s+1's loads (counted vmcnt).
-template <int BM, int BN, int WGM, int WGN, int STAGES>
+// F32 = true: the same kernel on fp32 operands (fp32 NHWC sources, fp32 packed weights, v_mfma_f32_32x32x2_f32 -- exact fp32):
+// a K-step is then 32 channels (the same 128-byte rows, 16-byte chunks of 4 channels), everything else -- DMA, swizzle,
+// stages, epilogue -- is shared.  Used by the fp32 path for its GEMM-shaped layers (token Linears, SoftSplit / SoftComp).
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool F32>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
     constexpr int NT = 64 * WGM * WGN;
+    constexpr int ESZ = F32 ? 4 : 2;                            // operand element size
+    constexpr int CH = 16 / ESZ;                                // channels per 16-byte chunk
+    constexpr int KC = 8 * CH;                                  // channels per K-step (128-byte rows)
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one 64-deep stage of each operand
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one K-step stage of each operand
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte DMA items per thread
     constexpr int R = TM * 32, CN = TN * 32, LDE = CN + 4;      // a wave's epilogue region: R rows of LDE floats
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         const int koct = item / BN, n = item - koct * BN;
         b_off[it] = (n0 + n) < p.Npad ? (unsigned)((koct * p.Npad + n0 + n) * 16) : OOB;
     }
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w + (long long)g * p.wgroup_elems, p.wgroup_bytes);
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_elems * ESZ, p.wgroup_bytes);
     const unsigned b_step = 8u * (unsigned)p.Npad * 16u;          // packed-weight bytes per K-step
 
     // walk of the K-steps: tap (ky, kx) -> source s -> 64-channel block c0; the parameters of the source being walked
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     int ky = 0, kx = 0, s = 0, c0 = 0;
     const void* cur_src = p.src[0];
     unsigned cur_bytes = p.src_bytes[0];
-    unsigned cur_ld2 = (unsigned)p.ld[0] * 2u;
-    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 2u;
+    unsigned cur_ld2 = (unsigned)p.ld[0] * (unsigned)ESZ;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * (unsigned)ESZ;
     int cur_cpg = p.cpg[0];
 
     auto issue = [&](int stage, int step) {
@@ -142,9 +148,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         const int tap = ky * p.W + kx;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int c = c0 + a_chunk[it] * 8;
+            const int c = c0 + a_chunk[it] * CH;
             const bool ok = c < cur_cpg && (unsigned)(a_by[it] + ky) < (unsigned)p.H && (unsigned)(a_bx[it] + kx) < (unsigned)p.W;
-            const unsigned off = (unsigned)(a_pix[it] + tap) * cur_ld2 + cur_chan + (unsigned)c * 2u;
+            const unsigned off = (unsigned)(a_pix[it] + tap) * cur_ld2 + cur_chan + (unsigned)c * (unsigned)ESZ;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + (it * NT + wave * 64) * 16), 16, ok ? off : OOB, 0, 0, 0);
         }
 #pragma unroll
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(sb + (it * NT + wave * 64) * 16), 16,
                                                      b_off[it] == OOB ? OOB : b_off[it] + (unsigned)step * b_step, 0, 0, 0);
         // advance the walk
-        c0 += 64;
+        c0 += KC;
         if (c0 >= cur_cpg) {
             c0 = 0;
             ++s;
@@ -162,8 +168,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                 if (kx == p.KW) { kx = 0; ++ky; }
             }
             if (p.nsrc > 1) {
-                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld2 = (unsigned)p.ld[s] * 2u;
-                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 2u; cur_cpg = p.cpg[s];
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld2 = (unsigned)p.ld[s] * (unsigned)ESZ;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * (unsigned)ESZ; cur_cpg = p.cpg[s];
             }
         }
     };
@@ -191,18 +197,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     auto compute = [&](const unsigned char* st) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[TM], b[TN];
+            if constexpr (F32) {
+                // chunk 2 kk + h holds 4 consecutive k of the row / column: MFMA #e multiplies k = 4 (2 kk + h) + e of both halves
+                f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                a[tm] = *reinterpret_cast<const bf16x8*>(st + a_rd[tm] + (((2 * kk + h) ^ a_key[tm]) << 4));
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                b[tn] = *reinterpret_cast<const bf16x8*>(st + b_rd[tn] + (2 * kk + h) * (BN * 16));
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
+                    a[tm] = *reinterpret_cast<const f32x4*>(st + a_rd[tm] + (((2 * kk + h) ^ a_key[tm]) << 4));
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+                    b[tn] = *reinterpret_cast<const f32x4*>(st + b_rd[tn] + (2 * kk + h) * (BN * 16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][e], b[tn][e], acc[tm][tn], 0, 0, 0);
+            } else {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    a[tm] = *reinterpret_cast<const bf16x8*>(st + a_rd[tm] + (((2 * kk + h) ^ a_key[tm]) << 4));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    b[tn] = *reinterpret_cast<const bf16x8*>(st + b_rd[tn] + (2 * kk + h) * (BN * 16));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
         }
     };
     if (STAGES == 2) {
@@ -347,10 +371,13 @@ struct PackX {
     int Cout, groups, KH, KW, nsrc;
     int cpg[E2FGVI_MAX_SRC];
     int Cout_g, Npad, Cin_g, steps_per_tap;
-    long long total, wgroup_elems;        // bf16 elements
+    int kc, ch;                           // channels per K-step (64 bf16 / 32 fp32) and per 16-byte chunk (8 / 4)
+    long long total, wgroup_elems;        // elements
 };
 
-bool geometry_x(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* cpg, PackX* q) {
+bool geometry_x(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* cpg, PackX* q, bool f32 = false) {
+    q->kc = f32 ? 32 : 64;
+    q->ch = f32 ? 4 : 8;
     if (Cout <= 0 || groups <= 0 || Cout % groups || KH <= 0 || KW <= 0 || nsrc < 1 || nsrc > E2FGVI_MAX_SRC) return false;
     q->Cout = Cout; q->groups = groups; q->KH = KH; q->KW = KW; q->nsrc = nsrc;
     q->Cout_g = Cout / groups;
@@ -359,23 +386,25 @@ bool geometry_x(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* c
     q->steps_per_tap = 0;
     for (int s = 0; s < E2FGVI_MAX_SRC; ++s) q->cpg[s] = 0;
     for (int s = 0; s < nsrc; ++s) {
-        if (cpg[s] <= 0 || cpg[s] % 8) return false;
+        if (cpg[s] <= 0 || cpg[s] % q->ch) return false;
         q->cpg[s] = cpg[s];
         q->Cin_g += cpg[s];
-        q->steps_per_tap += cdiv(cpg[s], 64);
+        q->steps_per_tap += cdiv(cpg[s], q->kc);
     }
-    q->wgroup_elems = (long long)KH * KW * q->steps_per_tap * 64 * q->Npad;
+    q->wgroup_elems = (long long)KH * KW * q->steps_per_tap * q->kc * q->Npad;
     q->total = q->wgroup_elems * groups;
     return true;
 }
 
-__global__ void pack_conv_weight_bf16x_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const PackX p) {
+// packed layout [group][K-step][8 chunks][Npad][ch elements]
+template <typename T>
+__global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __restrict__ wp, const PackX p) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.total) return;
     const int g = (int)(idx / p.wgroup_elems);
     long long rem = idx - (long long)g * p.wgroup_elems;
-    const int e = (int)(rem & 7);
-    rem >>= 3;
+    const int e = (int)(rem % p.ch);
+    rem /= p.ch;
     const int n = (int)(rem % p.Npad);
     rem /= p.Npad;
     const int koct = (int)(rem & 7);
@@ -383,20 +412,27 @@ __global__ void pack_conv_weight_bf16x_kernel(const float* __restrict__ w, __bf1
     const int tap = step / p.steps_per_tap;
     int blk = step - tap * p.steps_per_tap;
     int s = 0, prefix = 0;
-    while (blk >= (p.cpg[s] + 63) / 64) { blk -= (p.cpg[s] + 63) / 64; prefix += p.cpg[s]; ++s; }
-    const int c = blk * 64 + koct * 8 + e;
+    while (blk >= (p.cpg[s] + p.kc - 1) / p.kc) { blk -= (p.cpg[s] + p.kc - 1) / p.kc; prefix += p.cpg[s]; ++s; }
+    const int c = blk * p.kc + koct * p.ch + e;
     float v = 0.f;
     if (c < p.cpg[s] && n < p.Cout_g)
         v = w[((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + c) * (p.KH * p.KW) + tap];
-    wp[idx] = (__bf16)v;
+    wp[idx] = (T)v;
 }
 
 template <int BM, int BN, int WGM, int WGN, int STAGES>
-int launch_x(ConvXParams& p, int groups, hipStream_t st) {
+int launch_x(ConvXParams& p, int groups, hipStream_t st, bool f32 = false) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout_g, BN);
-    hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, STAGES>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
-    E2_LAUNCH_CHECK("conv2d_bf16x");
+    if (f32) {
+        if constexpr (STAGES == 2)
+            hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, 2, true>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+        else
+            return E2FGVI_EUNSUP;
+    } else {
+        hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, STAGES, false>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+    }
+    E2_LAUNCH_CHECK("conv2d_x");
     return 0;
 }
 
@@ -417,17 +453,39 @@ extern "C" int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int3
     PackX q;
     E2_REQUIRE(w && wpacked && src_cpg, E2FGVI_EINVAL, "pack_conv_weight_bf16x: null pointer");
     E2_REQUIRE(geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q), E2FGVI_EINVAL, "pack_conv_weight_bf16x: bad geometry");
-    hipLaunchKernelGGL(pack_conv_weight_bf16x_kernel, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_conv_weight_x_kernel<__bf16>, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
                        w, (__bf16*)wpacked, q);
     E2_LAUNCH_CHECK("pack_conv_weight_bf16x");
     return 0;
 }
 
-extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
+extern "C" int64_t e2fgvi_packed_conv_weight_f32x_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW, int32_t nsrc,
+                                                       const int32_t* src_cpg) {
+    PackX q;
+    if (!src_cpg || !geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q, true)) {
+        e2fgvi_set_error("packed_conv_weight_f32x_size: bad geometry (channels per source must be multiples of 4)");
+        return E2FGVI_EINVAL;
+    }
+    return q.total;
+}
+
+extern "C" int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int32_t Cout, int32_t groups, int32_t KH,
+                                            int32_t KW, int32_t nsrc, const int32_t* src_cpg, void* stream) {
+    PackX q;
+    E2_REQUIRE(w && wpacked && src_cpg, E2FGVI_EINVAL, "pack_conv_weight_f32x: null pointer");
+    E2_REQUIRE(geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q, true), E2FGVI_EINVAL, "pack_conv_weight_f32x: bad geometry");
+    hipLaunchKernelGGL(pack_conv_weight_x_kernel<float>, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, wpacked, q);
+    E2_LAUNCH_CHECK("pack_conv_weight_f32x");
+    return 0;
+}
+
+static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv2d_bf16x: null descriptor");
     PackX q;
-    E2_REQUIRE(geometry_x(d->Cout, d->groups, d->KH, d->KW, d->nsrc, d->src_cpg, &q), E2FGVI_EINVAL,
-               "conv2d_bf16x: bad geometry (channels per source must be multiples of 8)");
+    const int esz = f32 ? 4 : 2;
+    E2_REQUIRE(geometry_x(d->Cout, d->groups, d->KH, d->KW, d->nsrc, d->src_cpg, &q, f32), E2FGVI_EINVAL,
+               "conv2d_bf16x: bad geometry (channels per source must be multiples of 8 bf16 / 4 fp32)");
     E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->stride > 0 && d->pad >= 0, E2FGVI_EINVAL,
                "conv2d_bf16x: bad sizes");
     E2_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
@@ -440,16 +498,16 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
     for (int s = 0; s < E2FGVI_MAX_SRC; ++s) { p.src[s] = nullptr; p.ld[s] = 0; p.coff[s] = 0; p.cpg[s] = 0; p.src_bytes[s] = 0; }
     for (int s = 0; s < d->nsrc; ++s) {
         E2_REQUIRE(d->src[s], E2FGVI_EINVAL, "conv2d_bf16x: null source %d", s);
-        E2_REQUIRE(d->src_ld[s] % 8 == 0 && d->src_coff[s] % 8 == 0 && ((uintptr_t)d->src[s] & 15) == 0, E2FGVI_EINVAL,
-                   "conv2d_bf16x: source %d not 16-byte addressable (ld / coff multiples of 8 bf16)", s);
+        E2_REQUIRE(d->src_ld[s] % q.ch == 0 && d->src_coff[s] % q.ch == 0 && ((uintptr_t)d->src[s] & 15) == 0, E2FGVI_EINVAL,
+                   "conv2d_bf16x: source %d not 16-byte addressable (ld / coff multiples of 8 bf16 / 4 fp32)", s);
         E2_REQUIRE(d->src_coff[s] + d->groups * d->src_cpg[s] <= d->src_ld[s], E2FGVI_EINVAL,
                    "conv2d_bf16x: source %d channel range exceeds its pixel stride", s);
-        const long long bytes = (long long)d->N * d->H * d->W * d->src_ld[s] * 2;
+        const long long bytes = (long long)d->N * d->H * d->W * d->src_ld[s] * esz;
         E2_REQUIRE(bytes < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: source %d spans >= 4 GiB (split the batch)", s);
         p.src[s] = d->src[s]; p.ld[s] = d->src_ld[s]; p.coff[s] = d->src_coff[s]; p.cpg[s] = d->src_cpg[s];
         p.src_bytes[s] = (unsigned)bytes;
     }
-    E2_REQUIRE(q.wgroup_elems * 2 < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: packed weight group >= 4 GiB");
+    E2_REQUIRE(q.wgroup_elems * esz < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: packed weight group >= 4 GiB");
     E2_REQUIRE(((uintptr_t)d->wpacked & 15) == 0, E2FGVI_EINVAL, "conv2d_bf16x: packed weight not 16-byte aligned");
     if (d->dst_nchw)
         E2_REQUIRE(d->dst_dtype == E2FGVI_F32 && !d->dst2, E2FGVI_EINVAL, "conv2d_bf16x: the NCHW destination is fp32, without a second copy");
@@ -467,8 +525,8 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
     p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
     p.M = d->N * d->Ho * d->Wo;
     p.nsteps = d->KH * d->KW * q.steps_per_tap;
-    p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * 2);
-    p.w = (const __bf16*)d->wpacked; p.bias = d->bias;
+    p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * esz);
+    p.w = d->wpacked; p.bias = d->bias;
     p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff; p.res_bf16 = d->res_dtype == E2FGVI_BF16;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_bf16 = d->dst_dtype == E2FGVI_BF16;
     p.dst_nchw = d->dst_nchw;
@@ -482,12 +540,12 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
         else tile = ((long long)cdiv(p.M, 128) * cdiv(p.Cout_g, 128) * d->groups >= 384) ? 1 : 4;
     }
     switch (tile) {
-        case 1: return launch_x<128, 128, 2, 2, 2>(p, d->groups, st);
-        case 2: return launch_x<128, 64, 2, 2, 2>(p, d->groups, st);
-        case 3: return launch_x<128, 32, 4, 1, 2>(p, d->groups, st);
-        case 4: return launch_x<64, 128, 2, 2, 2>(p, d->groups, st);
-        case 5: return launch_x<64, 64, 2, 2, 2>(p, d->groups, st);
-        case 6: return launch_x<256, 128, 4, 2, 2>(p, d->groups, st);
+        case 1: return launch_x<128, 128, 2, 2, 2>(p, d->groups, st, f32);
+        case 2: return launch_x<128, 64, 2, 2, 2>(p, d->groups, st, f32);
+        case 3: return launch_x<128, 32, 4, 1, 2>(p, d->groups, st, f32);
+        case 4: return launch_x<64, 128, 2, 2, 2>(p, d->groups, st, f32);
+        case 5: return launch_x<64, 64, 2, 2, 2>(p, d->groups, st, f32);
+        case 6: return launch_x<256, 128, 4, 2, 2>(p, d->groups, st, f32);
         // the same tiles with the LDS-DMA two steps ahead (3 LDS stages)
         case 11: return launch_x<128, 128, 2, 2, 3>(p, d->groups, st);
         case 12: return launch_x<128, 64, 2, 2, 3>(p, d->groups, st);
@@ -500,3 +558,7 @@ extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) {
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }
+
+extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, false); }
+/* the same kernel on fp32 operands (fp32 NHWC sources, e2fgvi_pack_conv_weight_f32x weights, exact fp32 MFMA) */
+extern "C" int e2fgvi_conv2d_f32x(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, true); }

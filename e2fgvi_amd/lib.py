@@ -73,6 +73,9 @@ SYMBOLS = {
     "e2fgvi_conv2d_bf16x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
     "e2fgvi_packed_conv_weight_bf16x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_bf16x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
+    "e2fgvi_conv2d_f32x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
+    "e2fgvi_packed_conv_weight_f32x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    "e2fgvi_pack_conv_weight_f32x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_packed_winograd_weight_size": (_i64, [_i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_winograd_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_conv3x3_winograd": (C.c_int, [C.POINTER(ConvDesc), _fp]),

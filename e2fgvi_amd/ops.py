@@ -142,6 +142,17 @@ class PackedConv:
         _L.check(lib.e2fgvi_pack_conv_weight(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
                                              len(self.cpg), arr, bk, _stream()), "pack_conv_weight")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        self._w_raw = w            # for the alternative LDS-DMA kernel (built on the first tuned call)
+        self.alt = None
+
+    def _alt(self):
+        """the LDS-DMA fp32 kernel (conv_bf16x.hip, F32 variant) as a tuning alternative of the implicit GEMM"""
+        if self.alt is None and getattr(self, "_w_raw", None) is not None:
+            self.alt = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
+                                   dtype=torch.float32)
+            self.alt.name = self.name
+            self._w_raw = None
+        return self.alt
 
     def _autotune(self, lib, d, wino=False):
         """Device time of every candidate tile code on this exact call (2 launches each, hip events); the launches
@@ -264,7 +275,24 @@ class PackedConv:
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
-                best = _remember(key, self._autotune(lib, d, use_wino))
+                best = self._autotune(lib, d, use_wino)
+                if not use_wino and not self.nopk and self._alt() is not None:
+                    # the LDS-DMA fp32 kernel on the very same call: codes 2000 + its tile
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    d.tile = best
+                    e0.record()
+                    for _ in range(3):
+                        lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream())
+                    e1.record()
+                    e1.synchronize()
+                    mine = e0.elapsed_time(e1) / 3
+                    res = self.alt._time_tiles(self.alt._desc(srcs, out, out_coff, residual, res_coff, act, slope, None, out_nchw))
+                    if res and min(res.values()) < mine:
+                        best = 2000 + min(res, key=res.get)
+                best = _remember(key, best)
+            if best and best >= 2000:
+                return self._alt()(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
+                                   tile=best - 2000, out_nchw=out_nchw)
             d.tile = best or 0
         if _L.TRACE is not None:
             _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile))
@@ -297,11 +325,16 @@ def _chk_any(t, name):
 
 
 class PackedConvX:
-    """Conv / linear layer of the bf16 data path: bf16 NHWC sources (virtual concat, channels per source in multiples of
-    8), bf16 packed weights, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 epilogue (bias, fp32 / bf16 residual,
-    activation or the DCN offset post-processing), bf16 or fp32 result and an optional second bf16 copy (`out2`)."""
+    """Conv / linear layer on the LDS-DMA implicit-GEMM kernel (csrc/conv_bf16x.hip).
 
-    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0):
+    dtype=torch.bfloat16 (default): the bf16 data path -- bf16 NHWC sources (virtual concat, channels per source in
+    multiples of 8), bf16 packed weights, v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    dtype=torch.float32: the same kernel on fp32 operands (channels in multiples of 4, exact fp32 MFMA) -- the fp32 path's
+    tuning alternative to PackedConv's register-staged implicit GEMM.
+    Either way: fp32 epilogue (bias, fp32 / bf16 residual, activation or the DCN offset post-processing), bf16 or fp32
+    result (NHWC, or fp32 NCHW), optional second bf16 copy (`out2`)."""
+
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, dtype=torch.bfloat16):
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -311,44 +344,32 @@ class PackedConvX:
         if sum(self.cpg) != cin_g:
             raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
         self.groups, self.stride, self.pad = groups, stride, pad
+        self.dtype = dtype
+        self.f32 = dtype == torch.float32
+        self._fn = lib.e2fgvi_conv2d_f32x if self.f32 else lib.e2fgvi_conv2d_bf16x
         self.name = "conv"
         self.tune = False          # time XTUNE_CANDIDATES on the first call of every new size class and keep the fastest
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
-        n = lib.e2fgvi_packed_conv_weight_bf16x_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
+        size_fn = lib.e2fgvi_packed_conv_weight_f32x_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size
+        pack_fn = lib.e2fgvi_pack_conv_weight_f32x if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x
+        n = size_fn(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
         if n < 0:
-            _L.check(int(n), "packed_conv_weight_bf16x_size")
-        self.wpacked = torch.empty(int(n), dtype=torch.bfloat16, device=w.device)
-        _L.check(lib.e2fgvi_pack_conv_weight_bf16x(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
-                                                   len(self.cpg), arr, _stream()), "pack_conv_weight_bf16x")
+            _L.check(int(n), "packed_conv_weight_x_size")
+        self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
+        _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, _stream()),
+                 "pack_conv_weight_x")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
 
     def out_hw(self, H, W):
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
 
-    def __call__(self, sources, out=None, out_dtype=torch.bfloat16, out_coff=0, residual=None, res_coff=0, act=ACT_NONE,
-                 slope=0.0, out2=None, tile=0, out_nchw=False):
-        lib = _L.load()
+    def _desc(self, srcs, out, out_coff, residual, res_coff, act, slope, out2, out_nchw):
+        """the C descriptor of one call (srcs: list of (tensor, channel offset))"""
         d = _L.ConvXDesc()
-        srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
-        if len(srcs) != len(self.cpg):
-            raise ValueError("expected %d sources, got %d" % (len(self.cpg), len(srcs)))
         N, H, W, _ = srcs[0][0].shape
         Ho, Wo = self.out_hw(H, W)
-        dev = srcs[0][0].device
-        if out is None:
-            out = (torch.empty((N, self.Cout, Ho, Wo), dtype=torch.float32, device=dev) if out_nchw else
-                   torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=dev))
-        per_img = max(H * W * t.shape[3] * 2 for t, _ in srcs)
-        if N > 1 and N * per_img >= (1 << 32) - 1:                 # 32-bit buffer resources: image chunks
-            step = max(1, ((1 << 32) - 2) // per_img)
-            for n0 in range(0, N, step):
-                n1 = min(N, n0 + step)
-                self([(t[n0:n1], c) for t, c in srcs], out=out[n0:n1], out_coff=out_coff,
-                     residual=None if residual is None else residual[n0:n1], res_coff=res_coff, act=act, slope=slope,
-                     out2=None if out2 is None else out2[n0:n1], tile=tile, out_nchw=out_nchw)
-            return out
         for i, (t, coff) in enumerate(srcs):
-            _chk(t, "source %d" % i, torch.bfloat16)
+            _chk(t, "source %d" % i, self.dtype)
             if t.dim() != 4 or tuple(t.shape[:3]) != (N, H, W):
                 raise ValueError("source %d shape %s does not match [%d,%d,%d,*]" % (i, tuple(t.shape), N, H, W))
             d.src[i], d.src_ld[i], d.src_coff[i], d.src_cpg[i] = t.data_ptr(), t.shape[3], coff, self.cpg[i]
@@ -377,62 +398,89 @@ class PackedConvX:
             if residual.dim() != 4 or tuple(residual.shape[:3]) != (N, Ho, Wo):
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff, d.res_dtype = residual.data_ptr(), residual.shape[3], res_coff, _dt(residual)
-        d.act, d.slope, d.tile = act, slope, tile
+        d.act, d.slope, d.tile = act, slope, 0
+        return d
+
+    def __call__(self, sources, out=None, out_dtype=None, out_coff=0, residual=None, res_coff=0, act=ACT_NONE,
+                 slope=0.0, out2=None, tile=0, out_nchw=False):
+        if out_dtype is None:
+            out_dtype = self.dtype
+        srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
+        if len(srcs) != len(self.cpg):
+            raise ValueError("expected %d sources, got %d" % (len(self.cpg), len(srcs)))
+        N, H, W, _ = srcs[0][0].shape
+        Ho, Wo = self.out_hw(H, W)
+        dev = srcs[0][0].device
+        if out is None:
+            out = (torch.empty((N, self.Cout, Ho, Wo), dtype=torch.float32, device=dev) if out_nchw else
+                   torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=dev))
+        per_img = max(H * W * t.shape[3] * (4 if self.f32 else 2) for t, _ in srcs)
+        if N > 1 and N * per_img >= (1 << 32) - 1:                 # 32-bit buffer resources: image chunks
+            step = max(1, ((1 << 32) - 2) // per_img)
+            for n0 in range(0, N, step):
+                n1 = min(N, n0 + step)
+                self([(t[n0:n1], c) for t, c in srcs], out=out[n0:n1], out_coff=out_coff,
+                     residual=None if residual is None else residual[n0:n1], res_coff=res_coff, act=act, slope=slope,
+                     out2=None if out2 is None else out2[n0:n1], tile=tile, out_nchw=out_nchw)
+            return out
+        d = self._desc(srcs, out, out_coff, residual, res_coff, act, slope, out2, out_nchw)
+        d.tile = tile
         if tile == 0 and self.tune and N * Ho * Wo >= 2048:
-            key = ("x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
+            key = ("x32" if self.f32 else "x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
                    int(4.0 * math.log2(N * Ho * Wo)), _dt(out), out_nchw)
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
-                best = _remember(key, self._autotune(lib, d))
+                res = self._time_tiles(d)
+                best = _remember(key, min(res, key=res.get) if res else 0)
             d.tile = tile = best or 0
         if _L.TRACE is not None:
             cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
-            cin_p = sum(-(-c // 64) * 64 for c in self.cpg)
-            _L.annotate(layer=self.name, kernel="conv_bf16x tile=%d" % tile, shape="N%d %dx%d %d->%d k%d s%d g%d" % (
-                N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
-                macs=N * Ho * Wo * self.Cout * cin_g * K2,
-                issued=N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2)
-        _L.check(lib.e2fgvi_conv2d_bf16x(C.byref(d), _stream()), "conv2d_bf16x")
+            kc = 32 if self.f32 else 64
+            cin_p = sum(-(-c // kc) * kc for c in self.cpg)
+            _L.annotate(layer=self.name, kernel="conv_%s tile=%d" % ("f32x" if self.f32 else "bf16x", tile),
+                        shape="N%d %dx%d %d->%d k%d s%d g%d" % (N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
+                        macs=N * Ho * Wo * self.Cout * cin_g * K2,
+                        issued=N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2)
+        _L.check(self._fn(C.byref(d), _stream()), "conv2d_x")
         return out
 
-
-    def _autotune(self, lib, d):
-        """device time of every tile shape on this exact call (the launches rewrite the same output)"""
-        best, best_ms = 0, float("inf")
+    def _time_tiles(self, d, reps=3, rounds=2):
+        """{tile code: best device time in ms} of every tile shape on this exact call (the launches rewrite the same
+        output); best of `rounds` measurements of `reps` launches each"""
         st = _stream()
+        res = {}
         d.tile = 0
         for _ in range(2):
-            lib.e2fgvi_conv2d_bf16x(C.byref(d), st)
-        for code in XTUNE_CANDIDATES:
-            if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
-                continue
-            d.tile = code
-            if lib.e2fgvi_conv2d_bf16x(C.byref(d), st) != 0:
-                continue
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                lib.e2fgvi_conv2d_bf16x(C.byref(d), st)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if ms < best_ms:
-                best, best_ms = code, ms
+            self._fn(C.byref(d), st)
+        for _ in range(rounds):
+            for code in XTUNE_CANDIDATES:
+                if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
+                    continue
+                d.tile = code
+                if self._fn(C.byref(d), st) != 0:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    self._fn(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                res[code] = min(res.get(code, float("inf")), e0.elapsed_time(e1) / reps)
         d.tile = 0
-        return best
+        return res
 
 
 class PackedLinearX(PackedConvX):
     """y[rows, Cout] = x[rows, Cin] @ W^T + b (+ residual) on the bf16 data path, rows treated as 1x1 images."""
 
-    def __init__(self, weight, bias):
-        super().__init__(weight, bias, [weight.shape[1]])
+    def __init__(self, weight, bias, dtype=torch.bfloat16):
+        super().__init__(weight, bias, [weight.shape[1]], dtype=dtype)
 
-    def __call__(self, x, out=None, out_dtype=torch.bfloat16, residual=None, act=ACT_NONE, slope=0.0, out2=None, tile=0):
+    def __call__(self, x, out=None, out_dtype=None, residual=None, act=ACT_NONE, slope=0.0, out2=None, tile=0):
         rows = x.numel() // x.shape[-1]
         if out is None:
-            out = torch.empty((rows, self.Cout), dtype=out_dtype, device=x.device)
+            out = torch.empty((rows, self.Cout), dtype=out_dtype or self.dtype, device=x.device)
         r4 = None if residual is None else residual.view(rows, 1, 1, residual.shape[-1])
         o2 = None if out2 is None else out2.view(rows, 1, 1, out2.shape[-1])
         super().__call__([x.view(rows, 1, 1, x.shape[-1])], out=out.view(rows, 1, 1, out.shape[-1]), residual=r4, act=act,

@@ -277,7 +277,7 @@ int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* r
  * in fp32 and the result is stored as bf16 and / or fp32.  Same operators and call sites as e2fgvi_conv2d_nhwc.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-    const void* src[E2FGVI_MAX_SRC];   /* bf16 NHWC sources of the virtual concat                          */
+    const void* src[E2FGVI_MAX_SRC];   /* bf16 NHWC sources of the virtual concat (fp32 for e2fgvi_conv2d_f32x) */
     int32_t src_ld[E2FGVI_MAX_SRC];    /* pixel stride, elements (multiple of 8)                           */
     int32_t src_coff[E2FGVI_MAX_SRC];  /* first channel used by group 0 (multiple of 8)                    */
     int32_t src_cpg[E2FGVI_MAX_SRC];   /* channels per group taken from this source (multiple of 8)        */
@@ -308,6 +308,15 @@ int64_t e2fgvi_packed_conv_weight_bf16x_size(int32_t Cout, int32_t groups, int32
 /* w: fp32 [Cout, sum(cpg), KH, KW] (torch OIHW) */
 int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
                                   int32_t nsrc, const int32_t* src_cpg, void* stream);
+
+/* The same LDS-DMA kernel on fp32 operands: fp32 NHWC sources (channels per source in multiples of 4), fp32 packed weights,
+ * v_mfma_f32_32x32x2_f32 (exact fp32, a K-step = 32 channels).  Same descriptor; used by the fp32 path for its GEMM-shaped
+ * layers (token Linears, SoftSplit / SoftComp) where it beats e2fgvi_conv2d_nhwc's register-staged pipeline. */
+int e2fgvi_conv2d_f32x(const e2fgvi_convx_desc* d, void* stream);
+int64_t e2fgvi_packed_conv_weight_f32x_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW, int32_t nsrc,
+                                            const int32_t* src_cpg);
+int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
+                                 int32_t nsrc, const int32_t* src_cpg, void* stream);
 
 /* Fused temporal focal window attention on bf16 MFMA: qkv / kv_pool / out are bf16 with the layouts of
  * e2fgvi_focal_attention; scores, softmax statistics and accumulation are fp32.  qkv and kv_pool must lie within one

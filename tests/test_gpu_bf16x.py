@@ -262,3 +262,46 @@ def test_mdcn_bf16_mfma(dev, tile):
     assert_close(nchw(out.cpu()), ref, 1.5e-2, "mdcn bf16 mfma tile %d" % tile)
     out16 = layer(xs, nhwc(off).to(dev), mask=nhwc(msk).to(dev), tile=tile, out_dtype=torch.bfloat16)
     assert torch.equal(out16, out.bfloat16())
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_f32x(dev, case):
+    """the same LDS-DMA kernel on fp32 operands (exact fp32 MFMA; the fp32 path's tuning alternative for its GEMM-shaped
+    layers) against torch fp32 conv2d: fp32 tolerance."""
+    from e2fgvi_amd import ops
+    name, N, H, W, cpg, groups, Cout, k, stride, pad, tiles = case
+    g = _gen(abs(hash(name)) % 1000 + 7)
+    w = torch.randn(Cout, sum(cpg), k, k, generator=g) / math.sqrt(sum(cpg) * k * k)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    srcs, parts = [], []
+    for c in cpg:
+        t = torch.randn(N, H, W, c * groups + 8, generator=g)
+        srcs.append(t)
+        parts.append(t[..., 4:4 + c * groups])
+    x = torch.cat([torch.cat([p_[..., gi * c:(gi + 1) * c] for p_, c in zip(parts, cpg)], -1) for gi in range(groups)], -1)
+    ref0 = F.conv2d(nchw(x), w, bias, stride=stride, padding=pad, groups=groups)
+    layer = ops.PackedConvX(w.to(dev), bias.to(dev), cpg, groups=groups, stride=stride, pad=pad, dtype=torch.float32)
+    src_d = [(s.to(dev), 4) for s in srcs]
+    res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
+    for tile in [t for t in tiles if t < 10]:
+        out = layer(src_d, residual=res.to(dev), act=ops.ACT_LRELU, slope=0.1, tile=tile)
+        assert out.dtype == torch.float32
+        assert_close(nchw(out.cpu()), F.leaky_relu(ref0 + nchw(res), 0.1), 2e-5, "%s f32x tile %d" % (name, tile))
+
+
+def test_fp32_layers_may_pick_the_lds_dma_kernel(dev):
+    """PackedConv / PackedLinear with tune=True time the register-staged implicit GEMM AND the LDS-DMA kernel on the first
+    call and keep the faster; whatever is chosen, the result is the fp32 one"""
+    from e2fgvi_amd import ops
+    g = _gen(3)
+    w = torch.randn(1536, 512, generator=g) / math.sqrt(512)
+    b = torch.randn(1536, generator=g) * 0.1
+    x = torch.randn(7360, 512, generator=g)
+    lin = ops.PackedLinear(w.to(dev), b.to(dev))
+    lin.tune = True
+    ref = F.linear(x, w, b)
+    for _ in range(2):                        # first call tunes, second replays the decision
+        assert_close(lin(x.to(dev)).cpu(), ref, 2e-5, "tuned linear")
+    key = [k for k in ops._TUNED if k[0] == 1536 and k[1] == (512,)]
+    assert key, "no tuning decision recorded"
+    print("qkv-shaped fp32 linear: tile code", ops._TUNED[key[0]])
