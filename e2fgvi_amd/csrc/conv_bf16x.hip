@@ -48,6 +48,7 @@ struct ConvXParams {
     int dst2_ld, dst2_coff;
     int act;
     float slope;
+    int dbg_noload;                       // tools only (tile codes 21 / 26): skip every DMA after the first stage -> the MFMA + LDS ceiling
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         __syncthreads();
         for (int step = 0; step < p.nsteps; ++step) {
             const int cur = step & 1;
-            if (step + 1 < p.nsteps) issue(cur ^ 1, step + 1);
+            if (step + 1 < p.nsteps && !(p.dbg_noload & 1)) issue(cur ^ 1, step + 1);
             compute(smem + cur * STAGE);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed (this wave's share)
             __syncthreads();                                        // ... everybody's, and this stage's readers are done
@@ -259,6 +260,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         }
     }
 
+    if (p.dbg_noload & 2) {                // measurement aid: no epilogue (keeps the accumulators alive through one store)
+        float sacc = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[tm][tn][r];
+        if (sacc == 123.456f) reinterpret_cast<float*>(p.dst)[0] = sacc;
+        return;
+    }
     // ---- epilogue through LDS
     float* E = reinterpret_cast<float*>(smem) + wave * (R * LDE);
 #pragma unroll
@@ -273,6 +285,56 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr int RPP = 64 / LPR;          // rows per pass
     const int col0 = (lane % LPR) * 8;
     const int n = n0 + wn * CN + col0;     // first of this lane's 8 channels inside the group
+    // Fast path, decided per wave (every term is wave-uniform): the wave's whole R x CN block lies inside the problem, the
+    // activation is none / ReLU / LeakyReLU and every tensor is 16-byte addressable per 8 channels.  Straight-line code, no
+    // per-lane predicates: the general path below masks every element (channel tails, row tails, scalar stores) and costs
+    // ~3x the instructions -- on a 512-deep token GEMM that was as much as the K loop (profiles/r02_bf16x_ablation.txt).
+    const bool fast = n0 + wn * CN + CN <= p.Cout_g && m0 + wm * R + R <= p.M && p.act <= E2FGVI_ACT_LRELU && !p.dst_nchw &&
+                      ((p.dst_ld | p.dst_coff | (g * p.Cout_g)) & 7) == 0 && (!p.res || ((p.res_ld | p.res_coff) & 7) == 0) &&
+                      (!p.dst2 || ((p.dst2_ld | p.dst2_coff) & 7) == 0) && !(p.dbg_noload & 8);
+    if (fast) {
+        const int co = g * p.Cout_g + n;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + co); b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4); }
+        const float neg = p.act == E2FGVI_ACT_RELU ? 0.f : (p.act == E2FGVI_ACT_LRELU ? p.slope : 1.f);
+#pragma unroll 1
+        for (int ps = 0; ps < R / RPP; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const long long m = m0 + wm * R + row;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0) + b0;
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0 + 4) + b1;
+            if (p.res) {
+                const long long ro = m * p.res_ld + p.res_coff + co;
+                if (p.res_bf16) {
+                    const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.res) + ro);
+                    v0[0] += __builtin_bit_cast(float, q[0] << 16); v0[1] += __builtin_bit_cast(float, q[0] & 0xFFFF0000u);
+                    v0[2] += __builtin_bit_cast(float, q[1] << 16); v0[3] += __builtin_bit_cast(float, q[1] & 0xFFFF0000u);
+                    v1[0] += __builtin_bit_cast(float, q[2] << 16); v1[1] += __builtin_bit_cast(float, q[2] & 0xFFFF0000u);
+                    v1[2] += __builtin_bit_cast(float, q[3] << 16); v1[3] += __builtin_bit_cast(float, q[3] & 0xFFFF0000u);
+                } else {
+                    const float* rp = reinterpret_cast<const float*>(p.res) + ro;
+                    v0 = v0 + *reinterpret_cast<const f32x4*>(rp);
+                    v1 = v1 + *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {              // none (neg = 1), ReLU (0), LeakyReLU (slope)
+                v0[c] = v0[c] > 0.f ? v0[c] : v0[c] * neg;
+                v1[c] = v1[c] > 0.f ? v1[c] : v1[c] * neg;
+            }
+            bf16x8 hv = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+            const long long dof = m * p.dst_ld + p.dst_coff + co;
+            if (p.dst_bf16) {
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.dst) + dof) = hv;
+            } else {
+                float* o = reinterpret_cast<float*>(p.dst) + dof;
+                *reinterpret_cast<f32x4*>(o) = v0;
+                *reinterpret_cast<f32x4*>(o + 4) = v1;
+            }
+            if (p.dst2) *reinterpret_cast<bf16x8*>(p.dst2 + m * p.dst2_ld + p.dst2_coff + co) = hv;
+        }
+        return;
+    }
     if (n < p.Cout_g) {
         const int co = g * p.Cout_g + n;
         const bool full = n + 7 < p.Cout_g;
@@ -282,7 +344,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         const bool vec_d = full && ((p.dst_ld | p.dst_coff | co) & 7) == 0;
         const bool vec_r = full && p.res && ((p.res_ld | p.res_coff | co) & 7) == 0;
         const bool vec_2 = full && p.dst2 && ((p.dst2_ld | p.dst2_coff | co) & 7) == 0;
-#pragma unroll
+        // NOT unrolled: the pass body is a few hundred instructions with run-time variants (dtypes, residual, activation);
+        // unrolled eight times the epilogue was tens of KB of cold straight-line code per workgroup and cost as much as a
+        // 512-deep K loop (instruction fetch), profiles/r02_bf16x_ablation.txt
+#pragma unroll 1
         for (int ps = 0; ps < R / RPP; ++ps) {
             const int row = ps * RPP + lane / LPR;
             const int m = m0 + wm * R + row;
@@ -331,6 +396,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 #pragma unroll
             for (int c = 0; c < 8; ++c) hv[c] = (__bf16)v[c];
             const long long dof = (long long)m * p.dst_ld + p.dst_coff + co;
+            if ((p.dbg_noload & 8) && v[0] != 123.456f) continue;          // measurement aid: everything but the global stores
             if (p.dst_nchw) {                      // plain fp32 NCHW [N,Cout,Ho,Wo] (the decoder's last layer: 3 channels)
                 const int img = m / HoWo, rem = m - img * HoWo;
                 float* o = reinterpret_cast<float*>(p.dst) + ((long long)img * p.Cout + co) * HoWo + rem;
@@ -534,6 +600,11 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     p.act = d->act; p.slope = d->slope;
     hipStream_t st = (hipStream_t)stream;
     int tile = d->tile;
+    p.dbg_noload = 0;
+    if (tile == 21 || tile == 26) { p.dbg_noload = 1; tile -= 20; }        // measurement aids: results are garbage
+    if (tile == 31 || tile == 36) { p.dbg_noload = 2; tile -= 30; }        //   no epilogue
+    if (tile == 41 || tile == 46) { p.dbg_noload = 3; tile -= 40; }        //   neither
+    if (tile == 61 || tile == 66) { p.dbg_noload = 8; tile -= 60; }        //   epilogue without its global stores
     if (!tile) {
         if (p.Cout_g <= 32) tile = 3;
         else if (p.Cout_g <= 64) tile = 2;

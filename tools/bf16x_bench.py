@@ -16,7 +16,7 @@ LAYERS = [("encoder.10", 10, 180, 324, [128, 192], 2, 512, 3, 1, 1), ("encoder.8
           ("fc1", 64800, 1, 1, [512], 1, 1960, 1, 1, 0), ("fc2", 64800, 1, 1, [1960], 1, 512, 1, 1, 0),
           ("sc", 64800, 1, 1, [512], 1, 6272, 1, 1, 0)]
 only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None
-tiles = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 5, 6, 11, 12, 14, 15, 16]
+tiles = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 6, 21, 26]
 for name, N, H, W, cpg, groups, Cout, k, s, p in LAYERS:
     if only and name not in only:
         continue
