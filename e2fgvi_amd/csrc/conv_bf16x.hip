@@ -87,8 +87,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one K-step stage of each operand
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte DMA items per thread
-    constexpr int R = TM * 32, CN = TN * 32, LDE = CN + 4;      // a wave's epilogue region: R rows of LDE floats
+    constexpr int R = TM * 32, CN = TN * 32;                    // a wave's output block
+    // the epilogue parks the accumulators in LDS, the whole block at once or (256x256 tile) in two column halves
+    constexpr int ES = (WGM * WGN * R * (CN + 4) * 4 > 150 * 1024) ? 2 : 1;
+    constexpr int TNH = TN / ES, CNH = CN / ES, LDE = CNH + 4;  // a wave's epilogue region: R rows of LDE floats
     constexpr int EPI = WGM * WGN * R * LDE * 4;
+    static_assert(TN % ES == 0 && EPI <= 160 * 1024, "epilogue region");
     constexpr int SMEM = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
     constexpr int NLOADS = A_IT + B_IT;                         // LDS-DMA instructions per thread and step
     static_assert(STAGES == 2 || STAGES == 3, "stages");
@@ -273,23 +277,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     }
     // ---- epilogue through LDS
     float* E = reinterpret_cast<float*>(smem) + wave * (R * LDE);
+    constexpr int LPR = CNH / 8;           // lanes per row (8 channels each)
+    constexpr int RPP = 64 / LPR;          // rows per pass
+    const int col0 = (lane % LPR) * 8;
+#pragma unroll
+    for (int eh = 0; eh < ES; ++eh) {
+    if (eh) __syncthreads();               // the previous half has been read out
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TNH; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + i] = acc[tm][tn][r];
+                E[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + tn * 32 + i] = acc[tm][eh * TNH + tn][r];
     __syncthreads();
-    constexpr int LPR = CN / 8;            // lanes per row (8 channels each)
-    constexpr int RPP = 64 / LPR;          // rows per pass
-    const int col0 = (lane % LPR) * 8;
-    const int n = n0 + wn * CN + col0;     // first of this lane's 8 channels inside the group
+    const int n = n0 + wn * CN + eh * CNH + col0;     // first of this lane's 8 channels inside the group
     // Fast path, decided per wave (every term is wave-uniform): the wave's whole R x CN block lies inside the problem, the
     // activation is none / ReLU / LeakyReLU and every tensor is 16-byte addressable per 8 channels.  Straight-line code, no
     // per-lane predicates: the general path below masks every element (channel tails, row tails, scalar stores) and costs
     // ~3x the instructions -- on a 512-deep token GEMM that was as much as the K loop (profiles/r02_bf16x_ablation.txt).
-    const bool fast = n0 + wn * CN + CN <= p.Cout_g && m0 + wm * R + R <= p.M && p.act <= E2FGVI_ACT_LRELU && !p.dst_nchw &&
+    const bool fast = n0 + wn * CN + (eh + 1) * CNH <= p.Cout_g && m0 + wm * R + R <= p.M && p.act <= E2FGVI_ACT_LRELU && !p.dst_nchw &&
                       ((p.dst_ld | p.dst_coff | (g * p.Cout_g)) & 7) == 0 && (!p.res || ((p.res_ld | p.res_coff) & 7) == 0) &&
                       (!p.dst2 || ((p.dst2_ld | p.dst2_coff) & 7) == 0) && !(p.dbg_noload & 8);
     if (fast) {
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             }
             if (p.dst2) *reinterpret_cast<bf16x8*>(p.dst2 + m * p.dst2_ld + p.dst2_coff + co) = hv;
         }
-        return;
+        continue;
     }
     if (n < p.Cout_g) {
         const int co = g * p.Cout_g + n;
@@ -430,6 +437,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             }
         }
     }
+    }   // eh
 #endif
 }
 
@@ -617,6 +625,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
         case 4: return launch_x<64, 128, 2, 2, 2>(p, d->groups, st, f32);
         case 5: return launch_x<64, 64, 2, 2, 2>(p, d->groups, st, f32);
         case 6: return launch_x<256, 128, 4, 2, 2>(p, d->groups, st, f32);
+        case 7: return launch_x<256, 256, 4, 2, 2>(p, d->groups, st, f32);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
         // the same tiles with the LDS-DMA two steps ahead (3 LDS stages)
         case 11: return launch_x<128, 128, 2, 2, 3>(p, d->groups, st);
         case 12: return launch_x<128, 64, 2, 2, 3>(p, d->groups, st);

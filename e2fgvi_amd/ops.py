@@ -44,10 +44,10 @@ def empty_nhwc(n, h, w, c, device):
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
-# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 (8 waves), 128x64, 64x64, 128x32 tiles.  (Tile codes +10 select the
+# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles.  (Tile codes +10 select the
 # same tiles with three LDS stages, the LDS-DMA two K-steps ahead: measured slower on every layer shape of the 720p forward,
 # profiles/r02_bf16x_conv_microbench.txt -- the second resident workgroup per CU hides more than the deeper pipeline.)
-XTUNE_CANDIDATES = (1, 4, 6, 2, 5, 3)
+XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
 # exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
