@@ -64,19 +64,19 @@ __device__ __forceinline__ float dcn_post(float v, int co, int C, const f32x4& f
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-template <int N>
-__device__ __forceinline__ void wait_vm_and_barrier() {
-    // counted wait: the N most recent LDS-DMA loads (the stage after next) stay in flight across the barrier; a plain
-    // __syncthreads() would drain them (hipcc emits vmcnt(0) in front of it while an LDS-DMA is outstanding)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-
-// STAGES = 2: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.
-// STAGES = 3: the DMA runs TWO steps ahead; the barrier that ends step s waits only for step s+1's loads (counted vmcnt).
+// Two LDS stages: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.
+// (A third stage with counted vmcnt waits was measured slower on every layer -- it costs the second resident workgroup --
+// and was removed, profiles/r02_bf16x_conv_microbench.txt.)
+// S3 = true (3x3, stride 1, pad 1 only): the three horizontal taps of a kernel row share ONE A stage.  Output pixels are
+// linear in (image, y, x), so the input pixel of tap kx is the input pixel of the centre tap of the linear neighbour
+// m + kx - 1 whenever that neighbour is in the same image row: the stage holds BM + 2 rows (virtual pixels m0 - 1 ..
+// m0 + BM, vertical offset ky - 1 applied), tap kx reads rows r + kx, and the two lanes whose neighbour would wrap into
+// another image row (x = 0 with kx = 0, x = W - 1 with kx = 2) zero their operand instead.  A DMA per 9 taps: 3 stages of
+// BM + 2 rows instead of 9 of BM; the weights are fetched per tap as before.  K walk: ky -> source -> block -> kx.
 // F32 = true: the same kernel on fp32 operands (fp32 NHWC sources, fp32 packed weights, v_mfma_f32_32x32x2_f32 -- exact fp32):
 // a K-step is then 32 channels (the same 128-byte rows, 16-byte chunks of 4 channels), everything else -- DMA, swizzle,
 // stages, epilogue -- is shared.  Used by the fp32 path for its GEMM-shaped layers (token Linears, SoftSplit / SoftComp).
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool F32>
+template <int BM, int BN, int WGM, int WGN, bool S3, bool F32>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
     constexpr int NT = 64 * WGM * WGN;
@@ -84,25 +84,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr int CH = 16 / ESZ;                                // channels per 16-byte chunk
     constexpr int KC = 8 * CH;                                  // channels per K-step (128-byte rows)
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one K-step stage of each operand
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte DMA items per thread
+    constexpr int AR = S3 ? BM + 2 : BM;                        // rows of an A stage
+    constexpr int A_BYTES = AR * 128, B_BYTES = BN * 128;       // one K-step stage of each operand
+    constexpr int A_IT = (AR * 8 + NT - 1) / NT, B_IT = BN * 8 / NT;   // 16-byte DMA items per thread
+    constexpr bool A_PART = (AR * 8) % NT != 0;                 // the last A iteration is partial (S3: 16 extra items)
     constexpr int R = TM * 32, CN = TN * 32;                    // a wave's output block
     // the epilogue parks the accumulators in LDS, the whole block at once or (256x256 tile) in two column halves
     constexpr int ES = (WGM * WGN * R * (CN + 4) * 4 > 150 * 1024) ? 2 : 1;
     constexpr int TNH = TN / ES, CNH = CN / ES, LDE = CNH + 4;  // a wave's epilogue region: R rows of LDE floats
     constexpr int EPI = WGM * WGN * R * LDE * 4;
     static_assert(TN % ES == 0 && EPI <= 160 * 1024, "epilogue region");
-    constexpr int SMEM = STAGES * STAGE > EPI ? STAGES * STAGE : EPI;
-    constexpr int NLOADS = A_IT + B_IT;                         // LDS-DMA instructions per thread and step
-    static_assert(STAGES == 2 || STAGES == 3, "stages");
+    constexpr int SMEM = 2 * (A_BYTES + B_BYTES) > EPI ? 2 * (A_BYTES + B_BYTES) : EPI;   // A stages first, then B stages
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: the LDS-DMA base (M0) is SALU work
     const int wm = wave / WGN, wn = wave % WGN;
     const int g = blockIdx.y;
     const int logical = xcd_remap(blockIdx.x, p.tilesM * p.tilesN);
@@ -110,22 +109,33 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HoWo = p.Ho * p.Wo;
 
-    // ---- DMA bookkeeping of this thread's A items (step invariant): item = tid + it * NT -> (row, 16-byte slot)
-    int a_pix[A_IT], a_by[A_IT], a_bx[A_IT], a_chunk[A_IT];
+    // ---- DMA bookkeeping.  The K loop must stay almost free of VALU / SALU work: every LDS-DMA piece that needs a dozen
+    // address instructions costs as much issue time as the MFMAs it feeds (SQ_INSTS_VALU was 4.5 per MFMA with per-step
+    // address arithmetic, profiles/r02_bf16x_pmc_raw.txt).  So a thread keeps ONE ready-made byte offset per A item, valid
+    // for the current (tap, source) -- or the out-of-range sentinel for halo / tail rows, which the buffer bounds check
+    // turns into zeros -- and the channel block inside the source advances through the instruction's SCALAR offset; the
+    // weight offsets are constant and the K-step advances through the scalar offset as well.
+    int a_pix[A_IT];                       // input pixel (linear) of tap (0, 0)
+    unsigned a_msk[A_IT];                  // bit ky: row by + ky inside the image; bit 8 + kx: column bx + kx inside
+    unsigned a_ch16[A_IT];                 // byte offset of the item's (swizzled) chunk inside a K-step
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int item = tid + it * NT;
         const int row = item >> 3, slot = item & 7;
-        a_chunk[it] = slot ^ ((row >> 1) & 7);
-        const int m = m0 + row;
-        const bool ok = m < p.M;
+        a_ch16[it] = (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+        const int m = S3 ? m0 + row - 1 : m0 + row;             // S3: the stage row's virtual pixel
+        const bool ok = m >= 0 && m < p.M;
         const int mm = ok ? m : 0;
         const int img = mm / HoWo;
         const int rem = mm - img * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_by[it] = ok ? oy * p.stride - p.pad : -(1 << 28);
-        a_bx[it] = ox * p.stride - p.pad;
-        a_pix[it] = (img * p.H + oy * p.stride - p.pad) * p.W + ox * p.stride - p.pad;
+        const int by = oy * p.stride - p.pad;
+        const int bx = S3 ? ox : ox * p.stride - p.pad;         // S3 stages the centre column; the tap shifts the READ
+        unsigned msk = 0;
+        for (int k = 0; k < p.KH; ++k) msk |= ((unsigned)(by + k) < (unsigned)p.H ? 1u : 0u) << k;
+        for (int k = 0; k < (S3 ? 1 : p.KW); ++k) msk |= ((unsigned)(bx + k) < (unsigned)p.W ? 1u : 0u) << (8 + k);
+        a_msk[it] = ok ? msk : 0u;
+        a_pix[it] = (img * p.H + by) * p.W + bx;
     }
     unsigned b_off[B_IT];
 #pragma unroll
@@ -137,46 +147,81 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_elems * ESZ, p.wgroup_bytes);
     const unsigned b_step = 8u * (unsigned)p.Npad * 16u;          // packed-weight bytes per K-step
 
-    // walk of the K-steps: tap (ky, kx) -> source s -> 64-channel block c0; the parameters of the source being walked
-    // live in scalar registers (indexing the kernel-argument arrays per step costs two dependent scalar loads)
+    // walk of the K-steps: tap (ky, kx) -> source s -> 64-channel block c0.  The per-source parameters are read from the
+    // kernel arguments ONCE (indexing the argument arrays per step costs dependent scalar loads and a wait in the loop).
+    const void* const sp0 = p.src[0]; const void* const sp1 = p.src[1]; const void* const sp2 = p.src[2]; const void* const sp3 = p.src[3];
+    const unsigned sb0 = p.src_bytes[0], sb1 = p.src_bytes[1], sb2 = p.src_bytes[2], sb3 = p.src_bytes[3];
+    const unsigned sl0 = (unsigned)p.ld[0] * ESZ, sl1 = (unsigned)p.ld[1] * ESZ, sl2 = (unsigned)p.ld[2] * ESZ, sl3 = (unsigned)p.ld[3] * ESZ;
+    const unsigned sc0 = (unsigned)(p.coff[0] + g * p.cpg[0]) * ESZ, sc1 = (unsigned)(p.coff[1] + g * p.cpg[1]) * ESZ,
+                   sc2 = (unsigned)(p.coff[2] + g * p.cpg[2]) * ESZ, sc3 = (unsigned)(p.coff[3] + g * p.cpg[3]) * ESZ;
+    const int sg0 = p.cpg[0], sg1 = p.cpg[1], sg2 = p.cpg[2], sg3 = p.cpg[3];
     int ky = 0, kx = 0, s = 0, c0 = 0;
-    const void* cur_src = p.src[0];
-    unsigned cur_bytes = p.src_bytes[0];
-    unsigned cur_ld2 = (unsigned)p.ld[0] * (unsigned)ESZ;
-    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * (unsigned)ESZ;
-    int cur_cpg = p.cpg[0];
-
-    auto issue = [&](int stage, int step) {
-        unsigned char* sa = smem + stage * STAGE;
-        unsigned char* sb = sa + A_BYTES;
-        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
-        const int tap = ky * p.W + kx;
+    int blk = 0;                                                  // S3: block index inside the kernel row's tap
+    const void* cur_src = sp0;
+    unsigned cur_bytes = sb0;
+    unsigned cur_ld2 = sl0, cur_chan = sc0;
+    int cur_cpg = sg0;
+    unsigned a_off[A_IT];                                         // this (tap, source)'s byte offsets (block 0) or OOB
+    auto retarget = [&]() {                                       // after ky / kx / s changed
+        if (p.nsrc > 1) {
+            cur_src = s == 0 ? sp0 : s == 1 ? sp1 : s == 2 ? sp2 : sp3;
+            cur_bytes = s == 0 ? sb0 : s == 1 ? sb1 : s == 2 ? sb2 : sb3;
+            cur_ld2 = s == 0 ? sl0 : s == 1 ? sl1 : s == 2 ? sl2 : sl3;
+            cur_chan = s == 0 ? sc0 : s == 1 ? sc1 : s == 2 ? sc2 : sc3;
+            cur_cpg = s == 0 ? sg0 : s == 1 ? sg1 : s == 2 ? sg2 : sg3;
+        }
+        const int kxe = S3 ? 0 : kx;
+        const int tap = ky * p.W + kxe;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int c = c0 + a_chunk[it] * CH;
-            const bool ok = c < cur_cpg && (unsigned)(a_by[it] + ky) < (unsigned)p.H && (unsigned)(a_bx[it] + kx) < (unsigned)p.W;
-            const unsigned off = (unsigned)(a_pix[it] + tap) * cur_ld2 + cur_chan + (unsigned)c * (unsigned)ESZ;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + (it * NT + wave * 64) * 16), 16, ok ? off : OOB, 0, 0, 0);
+            const bool ok = ((a_msk[it] >> ky) & (a_msk[it] >> (8 + kxe)) & 1u) != 0;
+            a_off[it] = ok ? (unsigned)(a_pix[it] + tap) * cur_ld2 + cur_chan + a_ch16[it] : OOB;
         }
+    };
+    retarget();
+    unsigned char* const smem_b = smem + 2 * A_BYTES;
+    // The whole next stage is issued BEFORE the MFMAs of the current one.  Spreading the pieces between the four MFMA groups
+    // of the step (a quarter after each group's operand reads) was measured 5-10 % slower on every layer: the loads are
+    // latency-exposed, the earliest possible issue wins (profiles/r02_bf16x_conv_microbench.txt).
+    auto issue_a = [&](int stage) {
+        if (p.dbg_noload & 16) return;
+        unsigned char* sa = smem + stage * A_BYTES + wave * 1024;
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const unsigned soff = (unsigned)c0 * (unsigned)ESZ;       // the channel block: scalar offset of the instruction
+        if (c0 + KC <= cur_cpg) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                if (!A_PART || it + 1 < A_IT || tid + it * NT < AR * 8)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + it * NT * 16), 16, a_off[it], soff, 0, 0);
+        } else {                                                  // the source's last, partial block: chunks past its channels are zeros
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                if (!A_PART || it + 1 < A_IT || tid + it * NT < AR * 8)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + it * NT * 16), 16,
+                                                             (c0 + (int)(a_ch16[it] / ESZ) < cur_cpg) ? a_off[it] : OOB, soff, 0, 0);
+        }
+    };
+    auto issue_b = [&](int stage, int step) {
+        if (p.dbg_noload & 32) return;
+        unsigned char* sb = smem_b + stage * B_BYTES + wave * 1024;
+        const unsigned soff = (unsigned)step * b_step;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(sb + (it * NT + wave * 64) * 16), 16,
-                                                     b_off[it] == OOB ? OOB : b_off[it] + (unsigned)step * b_step, 0, 0, 0);
-        // advance the walk
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(sb + it * NT * 16), 16, b_off[it], soff, 0, 0);
+    };
+    auto advance = [&]() -> bool {                                // next (source, block); past the last one: next tap / kernel row
         c0 += KC;
-        if (c0 >= cur_cpg) {
-            c0 = 0;
-            ++s;
-            if (s == p.nsrc) {
-                s = 0;
-                ++kx;
-                if (kx == p.KW) { kx = 0; ++ky; }
-            }
-            if (p.nsrc > 1) {
-                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld2 = (unsigned)p.ld[s] * (unsigned)ESZ;
-                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * (unsigned)ESZ; cur_cpg = p.cpg[s];
-            }
+        ++blk;
+        if (c0 < cur_cpg) return false;
+        c0 = 0;
+        ++s;
+        if (s == p.nsrc) {
+            s = 0;
+            blk = 0;
+            if (S3) ++ky;
+            else { ++kx; if (kx == p.KW) { kx = 0; ++ky; } }
         }
+        return true;                                              // the caller re-targets the A offsets
     };
 
     f32x16 acc[TM][TN];
@@ -189,17 +234,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 
     const int i = lane & 31, h = lane >> 5;
     // LDS byte offsets of this lane's operand reads inside a stage (kk = 0); kk advances the chunk by 2
-    int a_rd[TM], a_key[TM], b_rd[TN];
+    int a_row[TM], b_rd[TN];
+    bool okl[TM], okr[TM];                 // S3: this lane's output pixel has a left / right neighbour in its image row
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int row = (wm * TM + tm) * 32 + i;
-        a_rd[tm] = row * 128;
-        a_key[tm] = (row >> 1) & 7;
+        a_row[tm] = (wm * TM + tm) * 32 + i;
+        const int ox = (m0 + a_row[tm]) % p.Wo;
+        okl[tm] = ox != 0;
+        okr[tm] = ox != p.Wo - 1;
     }
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b_rd[tn] = A_BYTES + ((wn * TN + tn) * 32 + i) * 16;
+    for (int tn = 0; tn < TN; ++tn) b_rd[tn] = ((wn * TN + tn) * 32 + i) * 16;
 
-    auto compute = [&](const unsigned char* st) {
+    auto compute = [&](const unsigned char* st, const unsigned char* stb, int kxs) {
+        int a_rd[TM], a_key[TM];
+        bool zero[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = a_row[tm] + (S3 ? kxs : 0);
+            a_rd[tm] = row * 128;
+            a_key[tm] = (row >> 1) & 7;
+            zero[tm] = S3 && ((kxs == 0 && !okl[tm]) || (kxs == 2 && !okr[tm]));
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if constexpr (F32) {
@@ -210,7 +266,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                     a[tm] = *reinterpret_cast<const f32x4*>(st + a_rd[tm] + (((2 * kk + h) ^ a_key[tm]) << 4));
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    b[tn] = *reinterpret_cast<const f32x4*>(st + b_rd[tn] + (2 * kk + h) * (BN * 16));
+                    b[tn] = *reinterpret_cast<const f32x4*>(stb + b_rd[tn] + (2 * kk + h) * (BN * 16));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -221,11 +277,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             } else {
                 bf16x8 a[TM], b[TN];
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm) {
                     a[tm] = *reinterpret_cast<const bf16x8*>(st + a_rd[tm] + (((2 * kk + h) ^ a_key[tm]) << 4));
+                    if (S3) {
+                        u32x4 q = __builtin_bit_cast(u32x4, a[tm]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = zero[tm] ? 0u : q[e];
+                        a[tm] = __builtin_bit_cast(bf16x8, q);
+                    }
+                }
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    b[tn] = *reinterpret_cast<const bf16x8*>(st + b_rd[tn] + (2 * kk + h) * (BN * 16));
+                    b[tn] = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + (2 * kk + h) * (BN * 16));
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -234,33 +297,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             }
         }
     };
-    if (STAGES == 2) {
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    issue_a(0);
+    issue_b(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (!S3) {
         for (int step = 0; step < p.nsteps; ++step) {
             const int cur = step & 1;
-            if (step + 1 < p.nsteps && !(p.dbg_noload & 1)) issue(cur ^ 1, step + 1);
-            compute(smem + cur * STAGE);
+            const bool more = step + 1 < p.nsteps && !(p.dbg_noload & 1);
+            if (more) {
+                if (advance()) retarget();
+                issue_a(cur ^ 1);
+                issue_b(cur ^ 1, step + 1);
+            }
+            compute(smem + cur * A_BYTES, smem_b + cur * B_BYTES, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed (this wave's share)
             __syncthreads();                                        // ... everybody's, and this stage's readers are done
         }
     } else {
-        issue(0, 0);
-        if (p.nsteps > 1) {
-            issue(1, 1);
-            wait_vm_and_barrier<NLOADS>();                          // stage 0 landed, stage 1 in flight
-        } else {
-            wait_vm_and_barrier<0>();
-        }
-        int cur = 0;                                                // step % 3
+        const int spt = p.nsteps / 9;                               // blocks per tap
+        int acur = 0, kxs = 0;
         for (int step = 0; step < p.nsteps; ++step) {
-            // stage (step + 2) % 3 was read during step - 1: its readers passed the barrier that ended that step
-            if (step + 2 < p.nsteps) issue(cur == 0 ? 2 : cur - 1, step + 2);
-            compute(smem + cur * STAGE);
-            if (step + 2 < p.nsteps) wait_vm_and_barrier<NLOADS>();  // step + 1 landed; step + 2 stays in flight
-            else wait_vm_and_barrier<0>();
-            cur = cur == 2 ? 0 : cur + 1;
+            const bool more = step + 1 < p.nsteps && !(p.dbg_noload & 1);
+            int kxn = kxs + 1;
+            bool newblk = false;                                    // the next sub-step opens a new (kernel row, block): new A stage
+            if (kxn == 3) {
+                kxn = 0;
+                if (more) { if (advance()) retarget(); newblk = true; }
+            }
+            if (more) {
+                if (newblk) issue_a(acur ^ 1);
+                issue_b((step + 1) & 1, (ky * 3 + kxn) * spt + blk);
+            }
+            compute(smem + acur * A_BYTES, smem_b + (step & 1) * B_BYTES, kxs);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kxn == 0) acur ^= 1;
+            kxs = kxn;
         }
     }
 
@@ -494,17 +567,21 @@ __global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __rest
     wp[idx] = (T)v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES>
+template <int BM, int BN, int WGM, int WGN, bool S3>
 int launch_x(ConvXParams& p, int groups, hipStream_t st, bool f32 = false) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout_g, BN);
+    if (S3 && !(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1)) {
+        e2fgvi_set_error("conv2d_bf16x: the row-shift tiles (11..17) are for 3x3 stride-1 pad-1 layers");
+        return E2FGVI_EINVAL;
+    }
     if (f32) {
-        if constexpr (STAGES == 2)
-            hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, 2, true>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+        if constexpr (!S3)
+            hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, true>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
         else
             return E2FGVI_EUNSUP;
     } else {
-        hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, STAGES, false>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+        hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, S3, false>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
     }
     E2_LAUNCH_CHECK("conv2d_x");
     return 0;
@@ -565,6 +642,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     E2_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
                E2FGVI_EINVAL, "conv2d_bf16x: Ho/Wo inconsistent with H/W/k/stride/pad");
     E2_REQUIRE((long long)d->N * d->Ho * d->Wo < 2147483647LL, E2FGVI_EUNSUP, "conv2d_bf16x: more than 2^31 output pixels");
+    E2_REQUIRE(d->KH <= 8 && d->KW <= 8, E2FGVI_EUNSUP, "conv2d_bf16x: kernels larger than 8x8 are not supported");
     E2_REQUIRE(d->wpacked && d->dst, E2FGVI_EINVAL, "conv2d_bf16x: null weight/dst");
     E2_REQUIRE((d->dst_dtype == E2FGVI_F32 || d->dst_dtype == E2FGVI_BF16) && (d->res_dtype == E2FGVI_F32 || d->res_dtype == E2FGVI_BF16),
                E2FGVI_EINVAL, "conv2d_bf16x: dtype must be E2FGVI_F32 or E2FGVI_BF16");
@@ -609,30 +687,31 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     hipStream_t st = (hipStream_t)stream;
     int tile = d->tile;
     p.dbg_noload = 0;
-    if (tile == 21 || tile == 26) { p.dbg_noload = 1; tile -= 20; }        // measurement aids: results are garbage
+    if (tile == 21 || tile == 26 || tile == 27) { p.dbg_noload = 1; tile -= 20; }        // measurement aids: results are garbage
     if (tile == 31 || tile == 36) { p.dbg_noload = 2; tile -= 30; }        //   no epilogue
     if (tile == 41 || tile == 46) { p.dbg_noload = 3; tile -= 40; }        //   neither
     if (tile == 61 || tile == 66) { p.dbg_noload = 8; tile -= 60; }        //   epilogue without its global stores
+    if (tile == 71 || tile == 76 || tile == 77) { p.dbg_noload = 16; tile -= 70; }   //   no A (activation) DMA
+    if (tile == 81 || tile == 86 || tile == 87) { p.dbg_noload = 32; tile -= 80; }   //   no B (weight) DMA
     if (!tile) {
         if (p.Cout_g <= 32) tile = 3;
         else if (p.Cout_g <= 64) tile = 2;
         else tile = ((long long)cdiv(p.M, 128) * cdiv(p.Cout_g, 128) * d->groups >= 384) ? 1 : 4;
     }
     switch (tile) {
-        case 1: return launch_x<128, 128, 2, 2, 2>(p, d->groups, st, f32);
-        case 2: return launch_x<128, 64, 2, 2, 2>(p, d->groups, st, f32);
-        case 3: return launch_x<128, 32, 4, 1, 2>(p, d->groups, st, f32);
-        case 4: return launch_x<64, 128, 2, 2, 2>(p, d->groups, st, f32);
-        case 5: return launch_x<64, 64, 2, 2, 2>(p, d->groups, st, f32);
-        case 6: return launch_x<256, 128, 4, 2, 2>(p, d->groups, st, f32);
-        case 7: return launch_x<256, 256, 4, 2, 2>(p, d->groups, st, f32);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
-        // the same tiles with the LDS-DMA two steps ahead (3 LDS stages)
-        case 11: return launch_x<128, 128, 2, 2, 3>(p, d->groups, st);
-        case 12: return launch_x<128, 64, 2, 2, 3>(p, d->groups, st);
-        case 13: return launch_x<128, 32, 4, 1, 3>(p, d->groups, st);
-        case 14: return launch_x<64, 128, 2, 2, 3>(p, d->groups, st);
-        case 15: return launch_x<64, 64, 2, 2, 3>(p, d->groups, st);
-        case 16: return launch_x<256, 128, 4, 2, 3>(p, d->groups, st);
+        case 1: return launch_x<128, 128, 2, 2, false>(p, d->groups, st, f32);
+        case 2: return launch_x<128, 64, 2, 2, false>(p, d->groups, st, f32);
+        case 3: return launch_x<128, 32, 4, 1, false>(p, d->groups, st, f32);
+        case 4: return launch_x<64, 128, 2, 2, false>(p, d->groups, st, f32);
+        case 5: return launch_x<64, 64, 2, 2, false>(p, d->groups, st, f32);
+        case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, f32);
+        case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, f32);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
+        // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
+        case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, f32);
+        case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, f32);
+        case 14: return launch_x<64, 128, 2, 2, true>(p, d->groups, st, f32);
+        case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, f32);
+        case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, f32);
         default: break;
     }
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);

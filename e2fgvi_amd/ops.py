@@ -44,10 +44,10 @@ def empty_nhwc(n, h, w, c, device):
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
-# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles.  (Tile codes +10 select the
-# same tiles with three LDS stages, the LDS-DMA two K-steps ahead: measured slower on every layer shape of the 720p forward,
-# profiles/r02_bf16x_conv_microbench.txt -- the second resident workgroup per CU hides more than the deeper pipeline.)
+# bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles; tile codes +10
+# are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
 XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
+XTUNE_ROWSHIFT = (11, 16, 17)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
 # exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
@@ -454,8 +454,11 @@ class PackedConvX:
         for _ in range(2):
             self._fn(C.byref(d), st)
         for _ in range(rounds):
-            for code in XTUNE_CANDIDATES:
+            rowshift = (self.KH, self.KW, self.stride, self.pad) == (3, 3, 1, 1) and not self.f32
+            for code in XTUNE_CANDIDATES + (XTUNE_ROWSHIFT if rowshift else ()):
                 if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
+                    continue
+                if code % 10 == 2 and self.Cout // self.groups > 64 and code > 10:
                     continue
                 d.tile = code
                 if self._fn(C.byref(d), st) != 0:

@@ -13,7 +13,7 @@ export E2FGVI_TUNE_FILE=$OUT/tune.txt
 rm -f $E2FGVI_TUNE_FILE
 python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/tune_run.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > $OUT/$C.log 2>&1 || true
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > $OUT/$C.log 2>&1 || true
 done
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections

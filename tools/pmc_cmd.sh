@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p -o pmc -- "$@" > $OUT/run.log 2>&1 || true
+timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p -o pmc -- "$@" > $OUT/run.log 2>&1 || true
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -11,7 +11,7 @@ export E2FGVI_TUNE_FILE=$OUT/tune.txt
 rm -f $E2FGVI_TUNE_FILE
 python $REPO/bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" > $OUT/bench_graph.log 2>&1
 tail -1 $OUT/bench_graph.log > $OUT/bench_line.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 5 --warmup 2 "$@" > $OUT/bench.log 2>&1 || true
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 5 --warmup 2 "$@" > $OUT/bench.log 2>&1 || true
 tail -1 $OUT/bench.log | cut -c1-300
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 find $OUT -name "*kernel_trace.csv" -size +20M -delete || true

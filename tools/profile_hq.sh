@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python $REPO/tools/hq_run.py $HW $T 1 > $OUT/run.log 2>&1 || true
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python $REPO/tools/hq_run.py $HW $T 1 > $OUT/run.log 2>&1 || true
 tail -1 $OUT/run.log
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 find $OUT -name "*kernel_trace.csv" -size +20M -delete || true
