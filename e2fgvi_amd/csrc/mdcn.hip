@@ -21,7 +21,7 @@ namespace {
 constexpr int MAX_UNITS = 320;      // (C / 16) * KH * KW entries of the unit table (144 for the 256-channel 3x3 DCN)
 
 struct DcnParams {
-    const float* src[2];
+    const void* src[2];                // fp32 NHWC, or bf16 NHWC in the S16 instantiation
     int ld[2];
     int c[2];
     int N, H, W, Ho, Wo, KH, KW, stride, pad, dil;
@@ -71,14 +71,20 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // BF: the sampled slab and the weights are held in LDS as bf16 and multiplied on v_mfma_f32_32x32x16_bf16 (the bf16 data
 // path); the gather, the bilinear blend and the accumulation are fp32 either way.
 //   bf16 LDS images: A [BM rows][32 k (+8 pad)] (80-byte rows: conflict-free b128 reads), B [4 k-octets][BN][8]
-template <int BM, int BN, int WGM, int WGN, int KS, bool BF>
+// S16 (with BF): the sources are bf16 NHWC.  A 16-byte corner fetch then carries 8 channels instead of 4, so an item is
+// (row, unit, 8-channel half): half the items, half the fetches and half the per-item offset arithmetic (the bilinear
+// weights, tanh / sigmoid and address math are computed once per item) for the same slab.
+template <int BM, int BN, int WGM, int WGN, int KS, bool BF, bool S16>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnParams p) {
+    static_assert(BF || !S16, "bf16 sources only with the bf16 MFMA slab");
+    constexpr int SB = S16 ? 2 : 4;                   // source element size
+    constexpr int CQ = S16 ? 2 : 4;                   // 16-byte corner fetches per (row, unit): 16 channels
     constexpr int BK = 32;
     constexpr int NG = 64 * WGM * WGN;
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int LDA = BK + 4;
     constexpr int LDA16 = BK + 8;                     // bf16 elements per A row
-    constexpr int A_ITEMS = BM * 8;                   // (row, unit-in-chunk, c4)
+    constexpr int A_ITEMS = BM * 2 * CQ;              // (row, unit-in-chunk, 16-byte channel part)
     constexpr int A_IT = (A_ITEMS + NG - 1) / NG;
     constexpr int B_F4 = BF ? BK * BN / 8 : BK * BN / 4;      // 16-byte items of a chunk's weight slab
     constexpr int B_IT = (B_F4 + NG - 1) / NG;
@@ -120,10 +126,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
 #pragma unroll
     for (int ia = 0; ia < A_IT; ++ia) {
         const int f = tid + ia * NG;
-        const int row = f >> 3;
+        const int row = f / (2 * CQ);
         it_row[ia] = row;
-        it_uu[ia] = (f >> 2) & 1;
-        it_c4[ia] = f & 3;
+        it_uu[ia] = (f / CQ) & 1;
+        it_c4[ia] = f & (CQ - 1);
         const int m = m0 + row;
         const bool ok = (A_ITEMS % NG == 0 || f < A_ITEMS) && m < p.M;
         const int mm = ok ? m : 0;
@@ -212,15 +218,15 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         // both units of a chunk read the same source (host guarantees an even unit count in source 0)
         const bool second_src = (kt * 2) >= p.units0;
         const __amdgpu_buffer_rsrc_t rs = second_src ? r_src1 : r_src0;
-        const unsigned cbase4 = second_src ? (unsigned)p.c[0] * 4u : 0u;
-        const unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * 4u;
+        const unsigned cbase4 = second_src ? (unsigned)p.c[0] * (unsigned)SB : 0u;
+        const unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * (unsigned)SB;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             const int u = 2 * kt + it_uu[ia];
             const bool uok = kt < KT && u < p.units && it_ok[ia];
             const int* e = utab + (uok ? u : 0) * 8;
             const int dyk = e[3], dxk = e[4];
-            const unsigned ch = (unsigned)e[5] - cbase4 + (unsigned)it_c4[ia] * 16u;
+            const unsigned ch = (unsigned)(S16 ? e[5] >> 1 : e[5]) - cbase4 + (unsigned)it_c4[ia] * 16u;
             const float* slot = graw + (rbuf * SLOTS + it_row[ia] * 2 + it_uu[ia]) * 8;
             const f32x4 rw = *reinterpret_cast<const f32x4*>(slot);
             float dy = rw[0], dx = rw[1], mk = rw[2];
@@ -266,6 +272,23 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             if (A_ITEMS % NG == 0 || (tid + ia * NG) < A_ITEMS) {
+                if constexpr (S16) {
+                    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                    const u32x4 q00 = __builtin_bit_cast(u32x4, c00[S][ia]), q01 = __builtin_bit_cast(u32x4, c01[S][ia]),
+                                q10 = __builtin_bit_cast(u32x4, c10[S][ia]), q11 = __builtin_bit_cast(u32x4, c11[S][ia]);
+                    bf16x8 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __builtin_bit_cast(float, q00[e] << 16) * w00[S][ia] + __builtin_bit_cast(float, q01[e] << 16) * w01[S][ia] +
+                                         __builtin_bit_cast(float, q10[e] << 16) * w10[S][ia] + __builtin_bit_cast(float, q11[e] << 16) * w11[S][ia];
+                        const float hi = __builtin_bit_cast(float, q00[e] & 0xFFFF0000u) * w00[S][ia] + __builtin_bit_cast(float, q01[e] & 0xFFFF0000u) * w01[S][ia] +
+                                         __builtin_bit_cast(float, q10[e] & 0xFFFF0000u) * w10[S][ia] + __builtin_bit_cast(float, q11[e] & 0xFFFF0000u) * w11[S][ia];
+                        hv[2 * e] = (__bf16)lo;
+                        hv[2 * e + 1] = (__bf16)hi;
+                    }
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(sA) + it_row[ia] * LDA16 + it_uu[ia] * 16 + it_c4[ia] * 8) = hv;
+                    continue;
+                }
                 const f32x4 v = c00[S][ia] * w00[S][ia] + c01[S][ia] * w01[S][ia] + c10[S][ia] * w10[S][ia] + c11[S][ia] * w11[S][ia];
                 if (BF) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -447,13 +470,15 @@ long long dcn_packed_size(int Cout, int C, int KH, int KW) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS>
-int launch_dcn(DcnParams& p, hipStream_t st, bool bf) {
+int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout, BN);
-    if (bf)
-        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+    if (s16)
+        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+    else if (bf)
+        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
     else
-        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, false, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
     E2_LAUNCH_CHECK("mdcn");
     return 0;
 }
@@ -498,9 +523,13 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     E2_REQUIRE(d->nsrc == 1 || d->nsrc == 2, E2FGVI_EINVAL, "mdcn: nsrc must be 1 or 2");
     DcnParams p;
     int C = 0;
+    E2_REQUIRE(d->src_dtype == E2FGVI_F32 || (d->src_dtype == E2FGVI_BF16 && d->mfma_dtype == E2FGVI_BF16), E2FGVI_EINVAL,
+               "mdcn: src_dtype must be E2FGVI_F32, or E2FGVI_BF16 together with mfma_dtype = E2FGVI_BF16");
+    const bool s16 = d->src_dtype == E2FGVI_BF16;
+    const int sb = s16 ? 2 : 4;
     for (int s = 0; s < 2; ++s) { p.src[s] = nullptr; p.ld[s] = 0; p.c[s] = 0; }
     for (int s = 0; s < d->nsrc; ++s) {
-        E2_REQUIRE(d->src[s] && d->src_c[s] > 0 && d->src_ld[s] >= d->src_c[s] && d->src_ld[s] % 4 == 0 &&
+        E2_REQUIRE(d->src[s] && d->src_c[s] > 0 && d->src_ld[s] >= d->src_c[s] && d->src_ld[s] % (16 / sb) == 0 &&
                        ((uintptr_t)d->src[s] & 15) == 0,
                    E2FGVI_EINVAL, "mdcn: bad source %d", s);
         p.src[s] = d->src[s]; p.ld[s] = d->src_ld[s]; p.c[s] = d->src_c[s];
@@ -536,7 +565,7 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     // buffer bounds (all < 4 GiB) and the source split
     {
         const long long P = (long long)d->N * d->Ho * d->Wo;
-        const long long sb0 = (long long)d->N * d->H * d->W * p.ld[0] * 4, sb1 = (long long)d->N * d->H * d->W * p.ld[1] * 4;
+        const long long sb0 = (long long)d->N * d->H * d->W * p.ld[0] * sb, sb1 = (long long)d->N * d->H * d->W * p.ld[1] * sb;
         const long long ob = P * d->off_ld * 4, mb = P * d->mask_ld * 4,
                         wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * (d->mfma_dtype == E2FGVI_BF16 ? 2 : 4);
         E2_REQUIRE(sb0 < 4294967295LL && sb1 < 4294967295LL && ob < 4294967295LL && mb < 4294967295LL && wb < 4294967295LL,
@@ -555,12 +584,12 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         tile = b64 >= 512 ? 1 : (b64 >= 256 ? 2 : 5);
     }
     const bool bf = d->mfma_dtype == E2FGVI_BF16;
-    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf);
-    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream, bf);
-    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream, bf);
-    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream, bf);
-    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream, bf);
-    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream, bf);
+    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf, s16);
+    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream, bf, s16);
+    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream, bf, s16);
+    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream, bf, s16);
+    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream, bf, s16);
+    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream, bf, s16);
     e2fgvi_set_error("mdcn: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }

@@ -143,7 +143,6 @@ class BF16Path:
         l_t, b, h, w, ch = loc.shape
         dev = loc.device
         stores = {}
-        zero32 = self._zero((b, h, w, ch))
         zero16 = self._zero16((b, h, w, ch))
         lk = dict(act=ACT_LRELU, slope=0.1)
         for name, flows in (("backward_", flows_a), ("forward_", flows_b)):
@@ -153,7 +152,8 @@ class BF16Path:
             if name == "backward_":
                 order = order[::-1]
             img_stride = (l_t - 1) * h * w * 2
-            hist = []                       # fp32 propagated features in processing order (DCN / warp sources)
+            hist = []                       # fp32 propagated features in processing order (flow-warp sources)
+            hist16 = []                     # their bf16 copies (the DCN gathers these: 8 channels per 16-byte corner fetch)
             aligned = zero16
             for i, idx in enumerate(order):
                 cur = loc[idx]
@@ -166,10 +166,11 @@ class BF16Path:
                     x = off[1]([x], **lk)
                     x = off[2]([x], **lk)
                     offs = off[3]([x], out_dtype=torch.float32, residual=fl, act=ACT_DCNPOST, slope=10.0)
-                    aligned = dcn([hist[-1], feat_n2 if feat_n2 is not None else zero32], offs, out_dtype=BF16)
+                    aligned = dcn([hist16[-1], hist16[-2] if i > 1 else zero16], offs, out_dtype=BF16)
                 srcs = [cur, stores["backward_"][idx], aligned] if name == "forward_" else [cur, aligned]
                 y = bb[0](srcs, **lk)
                 hist.append(bb[1]([y], out_dtype=torch.float32, residual=aligned, out2=store16[idx]))
+                hist16.append(store16[idx])
             stores[name] = store16
         out = self.xfusion([stores["backward_"].view(l_t * b, h, w, ch), stores["forward_"].view(l_t * b, h, w, ch)],
                            residual=loc.view(l_t * b, h, w, ch))

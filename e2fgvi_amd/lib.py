@@ -54,7 +54,7 @@ class MdcnDesc(C.Structure):
         ("flows", _fp), ("max_residue", C.c_float),
         ("wpacked", _fp), ("bias", _fp),
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("tile", C.c_int32), ("dst_dtype", C.c_int32),
-        ("mfma_dtype", C.c_int32),
+        ("mfma_dtype", C.c_int32), ("src_dtype", C.c_int32),
     ]
 
 

@@ -542,9 +542,12 @@ class PackedDcn:
         N, H, W, _ = sources[0].shape
         ctot = 0
         for i, t in enumerate(sources):
-            _chk(t, "source %d" % i)
+            _chk_any(t, "source %d" % i)
+            if t.dtype != sources[0].dtype:
+                raise ValueError("sources must share one dtype")
             d.src[i], d.src_ld[i], d.src_c[i] = t.data_ptr(), t.shape[3], t.shape[3]
             ctot += t.shape[3]
+        d.src_dtype = _dt(sources[0])                 # bf16 sources: only with mfma="bf16" (checked by the library)
         if ctot != self.C:
             raise ValueError("sources carry %d channels, weight expects %d" % (ctot, self.C))
         d.nsrc = len(sources)

@@ -159,7 +159,7 @@ int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream);
  * rest), mask = sigmoid(raw); flows is [P,4] = (u1,v1,u2,v2).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-    const float* src[2];
+    const void* src[2];                /* fp32 NHWC (bf16 NHWC with src_dtype = E2FGVI_BF16)       */
     int32_t src_ld[2];
     int32_t src_c[2];                  /* channels of each source; C = sum; C/dg multiple of 16    */
     int32_t nsrc;
@@ -179,6 +179,8 @@ typedef struct {
     int32_t mfma_dtype;                /* E2FGVI_F32 (0, default): fp32 MFMA, wpacked from e2fgvi_pack_dcn_weight;
                                           E2FGVI_BF16: the sampled slab is rounded to bf16 and multiplied on bf16 MFMA
                                           (fp32 gather / blend / accumulation), wpacked from e2fgvi_pack_dcn_weight_bf16 */
+    int32_t src_dtype;                 /* E2FGVI_F32 (0, default); E2FGVI_BF16 (needs mfma_dtype = E2FGVI_BF16): the sources
+                                          are bf16 NHWC (src_ld multiple of 8): half the gather fetches                 */
 } e2fgvi_mdcn_desc;
 
 int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream);

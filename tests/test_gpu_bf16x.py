@@ -264,6 +264,19 @@ def test_mdcn_bf16_mfma(dev, tile):
     assert_close(nchw(out.cpu()), ref, 1.5e-2, "mdcn bf16 mfma tile %d" % tile)
     out16 = layer(xs, nhwc(off).to(dev), mask=nhwc(msk).to(dev), tile=tile, out_dtype=torch.bfloat16)
     assert torch.equal(out16, out.bfloat16())
+    # bf16 sources (8 channels per corner fetch): the reference takes the SAME bf16-rounded features, so the bound is unchanged;
+    # with the conv_offset post-processing fused (flows) as the bf16 path calls it
+    x16 = x.bfloat16()
+    ref16 = modulated_deform_conv2d(x16.float(), off, msk, w, b, 1, 1, 1, 1, dg)
+    xs16 = [nhwc(x16[:, :128]).contiguous().to(dev), nhwc(x16[:, 128:]).contiguous().to(dev)]
+    o = layer(xs16, nhwc(off).to(dev), mask=nhwc(msk).to(dev), tile=tile)
+    assert_close(nchw(o.cpu()), ref16, 1.5e-2, "mdcn bf16 sources tile %d" % tile)
+    one = ops.PackedDcn(w[:, :128].contiguous().to(dev), b.to(dev), dg // 2, pad=1, mfma="bf16")
+    o1 = one([xs16[0]], nhwc(off[:, :dg * 9]).contiguous().to(dev), mask=nhwc(msk[:, :dg * 9 // 2]).contiguous().to(dev), tile=tile)
+    ref1 = modulated_deform_conv2d(x16[:, :128].float(), off[:, :dg * 9], msk[:, :dg * 9 // 2], w[:, :128], b, 1, 1, 1, 1, dg // 2)
+    assert_close(nchw(o1.cpu()), ref1, 1.5e-2, "mdcn bf16 single source tile %d" % tile)
+    with pytest.raises(Exception):
+        ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)(xs16, nhwc(off).to(dev), mask=nhwc(msk).to(dev))   # bf16 sources need mfma="bf16"
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])

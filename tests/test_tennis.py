@@ -34,3 +34,27 @@ def test_tennis_clip_matches_reference_loop(dev, model, batch_windows):
     # outside the (dilated) masks the frames are the input, bit-exact
     masks = video.prepare_masks(z["masks_raw"], (h, w), dev).cpu().numpy().astype(bool)
     assert (out[~masks] == z["frames"][~masks]).all()
+
+
+@pytest.mark.gpu
+def test_tennis_clip_bf16_path_in_db(dev):
+    """SURVEY.md 8(f) rank 3's purpose: the bf16 data path's quality cost measured in dB on real frames rather than as a
+    max-abs bound.  Same clip, same reference output (fp32 reference loop); PSNR over the hole pixels of the stored
+    stride-4 samples (outside the holes the output is the input, bit-exact, and would only inflate the figure)."""
+    from e2fgvi_amd import video
+    from e2fgvi_amd.synth import synth_state_dict
+    z = np.load(GOLD)
+    L, h, w, sub = [int(v) for v in z["meta"]]
+    net = importlib.import_module("model.e2fgvi_hq").InpaintGenerator()
+    net.load_state_dict(synth_state_dict("e2fgvi_hq", "stress", 0))
+    net = net.to(dev).eval()
+    net.precision = "bf16"
+    out = video.inpaint_video(net, z["frames"], z["masks_raw"])
+    masks = video.prepare_masks(z["masks_raw"], (h, w), dev).cpu().numpy().astype(bool)
+    assert (out[~masks] == z["frames"][~masks]).all()
+    hole = masks[:, ::sub, ::sub]
+    d = (out[:, ::sub, ::sub].astype(np.float64) - z["e2fgvi_hq_sub"].astype(np.float64))[hole]
+    psnr = 10 * np.log10(255.0 ** 2 / max((d ** 2).mean(), 1e-12))
+    print("tennis e2fgvi_hq bf16 vs fp32 reference inside the holes: PSNR %.2f dB, max |diff| %d grey levels, mean |diff| %.3f"
+          % (psnr, np.abs(d).max(), np.abs(d).mean()))
+    assert psnr > 40.0
