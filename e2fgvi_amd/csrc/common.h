@@ -77,6 +77,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// sigmoid / tanh on the hardware exp2 + rcp (1 ulp each): absolute error <= ~5e-7 -- used by the DCN offset / mask
+// post-processing epilogues (10 * tanh -> 5e-6 px), where libm's branchy tanhf / expf cost a few microseconds per launch
+__device__ __forceinline__ float e2_fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float e2_fast_tanh(float x) {
+    // 1 - 2 / (1 + e^{2x}): saturates correctly for large |x| (exp2 -> inf / 0)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == E2FGVI_ACT_RELU) return fmaxf(v, 0.f);
     if (act == E2FGVI_ACT_LRELU) return v > 0.f ? v : v * slope;

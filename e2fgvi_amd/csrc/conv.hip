@@ -50,10 +50,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // flow_2); channels [2C/3, C) are masks -> sigmoid(v).  fl = this pixel's (u1, v1, u2, v2).
 __device__ __forceinline__ float dcn_post(float v, int co, int C, const float* fl, float max_residue) {
     const int noff = (C / 3) * 2;
-    if (co >= noff) return 1.f / (1.f + expf(-v));
+    if (co >= noff) return e2_fast_sigmoid(v);
     const int which = (co * 2 >= noff) ? 2 : 0;
     const float f = fl[which + ((co & 1) ? 0 : 1)];       // even channel = dy <- v (index 1), odd = dx <- u (index 0)
-    return max_residue * tanhf(v) + f;
+    return max_residue * e2_fast_tanh(v) + f;
 }
 
 // raw buffer resource: out-of-range offsets (>= bytes) return 0 -- the hardware does the zero padding of the

@@ -55,9 +55,9 @@ struct WinoParams {
 // conv.hip::dcn_post (feat_prop.py:38-53)
 __device__ __forceinline__ float wino_dcn_post(float v, int co, int C, const float* fl, float max_residue) {
     const int noff = (C / 3) * 2;
-    if (co >= noff) return 1.f / (1.f + expf(-v));
+    if (co >= noff) return e2_fast_sigmoid(v);
     const int which = (co * 2 >= noff) ? 2 : 0;
-    return max_residue * tanhf(v) + fl[which + ((co & 1) ? 0 : 1)];
+    return max_residue * e2_fast_tanh(v) + fl[which + ((co & 1) ? 0 : 1)];
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -44,6 +44,13 @@ def empty_nhwc(n, h, w, c, device):
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
+# wide-tile Winograd variants (csrc/conv_wino4.hip): tile code -> (fy, couts per workgroup); F(2x4,3x3) issues 3 and
+# F(4x4,3x3) 2.25 multiplies per output and input channel (F(2x2,3x3): 4)
+W4_CODES = {2464: (2, 64), 2432: (2, 32), 4432: (4, 32)}
+# E2FGVI_WINO4=<code>: force that variant on every qualifying Winograd call with >= E2FGVI_WINO4_MINPIX output pixels
+# (A/B measurements); unset: the static per-size rule of PackedConv._wino4_rule
+_W4_FORCE = int(os.environ.get("E2FGVI_WINO4", "0") or 0)
+_W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
 # bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles; tile codes +10
 # are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
 XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
@@ -104,6 +111,8 @@ class PackedConv:
             algo = "auto" if wino_ok else "igemm"
         self.algo = algo
         self.wino_packed = None
+        self._w4 = {}              # fy -> packed F(fy x 4, 3x3) weights, built on first use
+        self._w_oihw = w if algo in ("winograd", "auto") else None
         if algo in ("winograd", "auto"):
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
             n = lib.e2fgvi_packed_winograd_weight_size(self.Cout, groups, len(self.cpg), arr)
@@ -144,6 +153,35 @@ class PackedConv:
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
         self._w_raw = w            # for the alternative LDS-DMA kernel (built on the first tuned call)
         self.alt = None
+
+    def _wino4(self, fy):
+        """packed weights of the wide-tile Winograd kernel (conv_wino4.hip), built on first use"""
+        t = self._w4.get(fy)
+        if t is None:
+            lib = _L.load()
+            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+            n = lib.e2fgvi_packed_winograd4_weight_size(self.Cout, self.groups, len(self.cpg), arr, fy)
+            if n < 0:
+                _L.check(int(n), "packed_winograd4_weight_size")
+            t = torch.empty(int(n), dtype=torch.float32, device=self._w_oihw.device)
+            _L.check(lib.e2fgvi_pack_winograd4_weight(_ptr(self._w_oihw), _ptr(t), self.Cout, self.groups, len(self.cpg), arr, fy,
+                                                      _stream()), "pack_winograd4_weight")
+            self._w4[fy] = t
+        return t
+
+    def _wino4_rule(self, N, H, W):
+        """tile code of the wide-tile Winograd variant for this call, or 0 for the F(2x2,3x3) kernel"""
+        if W % 4 or self._w_oihw is None:
+            return 0
+        if _W4_FORCE:
+            fy = W4_CODES[_W4_FORCE][0]
+            return _W4_FORCE if (N * H * W >= _W4_MINPIX and H % fy == 0) else 0
+        # Measured on MI355X (tools/wino_bench.py, profiles/r02_wino4_bench.txt): F(2x4) x 64 couts beats the F(2x2) kernel
+        # by 6-8 % on the batched layers with >= 256 output channels per group (encoder.layers.8 / .10) and loses
+        # everywhere else (one workgroup per CU: the 16x16-pixel x 32-cout F(2x2) shape runs two); F(4x4) ties at best.
+        if self.Cout // self.groups >= 256 and N * H * W >= _W4_MINPIX and os.environ.get("E2FGVI_WINO4_AUTO", "1") != "0":
+            return 2464
+        return 0
 
     def _alt(self):
         """the LDS-DMA fp32 kernel (conv_bf16x.hip, F32 variant) as a tuning alternative of the implicit GEMM"""
@@ -189,7 +227,14 @@ class PackedConv:
         Implicit GEMM: output channels padded to 32, every source's channels to the K granule."""
         cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
         macs = N * Ho * Wo * self.Cout * cin_g * K2
-        if use_wino:
+        if use_wino and tile in W4_CODES:
+            fy, bn = W4_CODES[tile]
+            pix = N * (-(-H // (8 * fy)) * 8 * fy) * (-(-W // 16) * 16)
+            cin_p = sum(-(-c // 8) * 8 for c in self.cpg)
+            # (fy+2)*6 positions per fy x 4 pixels
+            issued = pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * (fy + 2) * 6 // (fy * 4)
+            kern = "conv_wino4<F(%dx4),%d>" % (fy, bn)
+        elif use_wino:
             if not tile:
                 big = N * -(-H // 16) * -(-W // 16) * -(-cout_g // 64) * self.groups
                 tile = 64 if (cout_g >= 256 and big >= 128) else 132
@@ -244,8 +289,11 @@ class PackedConv:
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
         use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and not out_nchw
-                                               and (tile in (0, 32, 64, 132, 164) or tile > 1000))
-        d.wpacked = (self.wino_packed if use_wino else self.wpacked).data_ptr()
+                                               and (tile in (0, 32, 64, 132, 164) or tile in W4_CODES or tile > 1000))
+        if use_wino and tile == 0:
+            tile = self._wino4_rule(N, H, W)
+        w4 = W4_CODES.get(tile) if use_wino else None
+        d.wpacked = (self._wino4(w4[0]) if w4 else self.wino_packed if use_wino else self.wpacked).data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         dev = srcs[0][0].device
         if out is None:
@@ -296,7 +344,10 @@ class PackedConv:
             d.tile = best or 0
         if _L.TRACE is not None:
             _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile))
-        if use_wino:
+        if w4:
+            d.tile = w4[1]
+            _L.check(lib.e2fgvi_conv3x3_winograd4(C.byref(d), w4[0], _stream()), "conv3x3_winograd4")
+        elif use_wino:
             _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
         elif self.precision == "bf16":
             _L.check(lib.e2fgvi_conv2d_nhwc_bf16(C.byref(d), _stream()), "conv2d_nhwc_bf16")

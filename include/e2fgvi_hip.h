@@ -147,6 +147,18 @@ int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32_t Cout, in
                                 const int32_t* src_cpg, void* stream);
 int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream);
 
+/* Wide-tile Winograd forms of the same operator (csrc/conv_wino4.hip): F(fy x 4, 3x3) with fy = 2 (24 transform positions
+ * per 2x4 outputs: 3 multiplies per output and input channel) or fy = 4 (36 per 4x4: 2.25), against 4 for F(2x2,3x3) and
+ * 9 for the direct convolution the reference runs (F.conv2d at e2fgvi.py:77-93,112-150, feat_prop.py:20-28,73-79).
+ * Same descriptor and restrictions as e2fgvi_conv3x3_winograd, plus H % fy == 0 and W % 4 == 0; tile = 0 (auto), 32 or
+ * 64 couts per workgroup (fy = 4: 32).  Weights: [group][8-channel chunk][(fy+2)*6 positions][2][Npad][4] holding
+ * G_y g G_x^T.  fp32 throughout; rounding relative to the output rms on 512 input channels: 6.5e-6 (fy = 2), 1.9e-5
+ * (fy = 4) -- the direct fp32 convolution sits at 7.7e-6. */
+int64_t e2fgvi_packed_winograd4_weight_size(int32_t Cout, int32_t groups, int32_t nsrc, const int32_t* src_cpg, int32_t fy);
+int e2fgvi_pack_winograd4_weight(const float* w, float* wpacked, int32_t Cout, int32_t groups, int32_t nsrc,
+                                 const int32_t* src_cpg, int32_t fy, void* stream);
+int e2fgvi_conv3x3_winograd4(const e2fgvi_conv_desc* d, int32_t fy, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Modulated deformable convolution (DCNv2), im2col-free: bilinear gather straight into LDS + MFMA.
  * Replaces mmcv.ops.modulated_deform_conv2d (mmcv-full 1.4.8) called at
