@@ -57,9 +57,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 __device__ __forceinline__ float dcn_post(float v, int co, int C, const f32x4& fl, float max_residue) {
     const int noff = (C / 3) * 2;
-    if (co >= noff) return 1.f / (1.f + expf(-v));
-    const int which = (co * 2 >= noff) ? 2 : 0;
-    return max_residue * tanhf(v) + fl[which + ((co & 1) ? 0 : 1)];
+    if (co >= noff) return e2_fast_sigmoid(v);           // hardware exp2 / rcp: libm's tanhf / expf on 432 channels x 58 320
+    const int which = (co * 2 >= noff) ? 2 : 0;          // pixels cost ~40 us of a 110 us launch at 720p
+    return max_residue * e2_fast_tanh(v) + fl[which + ((co & 1) ? 0 : 1)];
 }
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }

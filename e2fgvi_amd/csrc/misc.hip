@@ -55,6 +55,31 @@ template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = h;
 }
 
+// Flat thread index -> coordinates.  A 64-bit division by a run-time value is ~100 instructions on this ISA, a 32-bit
+// unsigned one ~25: with three or four of them per thread the 64-bit form cost more than the memory traffic of these
+// HBM-bound kernels (the x2 bilinear upsample of the decoder ran at 350 us per call at 720p against a 120-240 us floor).
+// Every launch whose flat extent fits 32 bits -- all of them up to 1080p -- takes the 32-bit path (a uniform branch).
+struct FlatIdx {
+    unsigned u;
+    long long l;
+    bool small;
+    __device__ __forceinline__ FlatIdx(long long idx, long long total) : u((unsigned)idx), l(idx), small(total <= 0xFFFFFFFFLL) {}
+    // returns (index % d) and keeps (index / d)
+    __device__ __forceinline__ int pop(int d) {
+        if (small) {
+            const unsigned q = u / (unsigned)d;
+            const int r = (int)(u - q * (unsigned)d);
+            u = q;
+            return r;
+        }
+        const long long q = l / d;
+        const int r = (int)(l - q * d);
+        l = q;
+        return r;
+    }
+    __device__ __forceinline__ long long rest() const { return small ? (long long)u : l; }
+};
+
 // ------------------------------------------------------------------------------------------ layout
 template <typename TO>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, TO* __restrict__ dst, int C, int HW, int ld,
@@ -81,8 +106,9 @@ __global__ void nchw_small_to_nhwc8_kernel(const float* __restrict__ src, TO* __
                                            float shift, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const long long n = idx / HW;
-    const int p = (int)(idx - n * HW);
+    FlatIdx fi(idx, total);
+    const int p = fi.pop(HW);
+    const long long n = fi.rest();
     f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -121,12 +147,11 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ src, int src_nc
                                        long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % C);
-    long long r = idx / C;
-    const int ox = (int)(r % Wo);
-    r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    FlatIdx fi(idx, total);
+    const int c = fi.pop(C);
+    const int ox = fi.pop(Wo);
+    const int oy = fi.pop(Ho);
+    const int n = (int)fi.rest();
     int y0, y1, x0, x1;
     float ly, lx;
     src_index(oy, sh, align, H, y0, y1, ly);
@@ -156,12 +181,11 @@ __global__ void resize_bilinear_vec4_kernel(const T* __restrict__ src, int src_l
     constexpr int NV = VT<T>::N, Q = VT<T>::Q;          // CV = C / NV channel vectors per pixel
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int cv = (int)(idx % CV);
-    long long r = idx / CV;
-    const int ox = (int)(r % Wo);
-    r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
+    FlatIdx fi(idx, total);
+    const int cv = fi.pop(CV);
+    const int ox = fi.pop(Wo);
+    const int oy = fi.pop(Ho);
+    const int n = (int)fi.rest();
     int y0, y1, x0, x1;
     float ly, lx;
     src_index(oy, sh, align, H, y0, y1, ly);
@@ -186,12 +210,11 @@ __global__ void avgpool2_kernel(const float* __restrict__ src, float* __restrict
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int Ho = H / 2, Wo = W / 2;
-    const int c = (int)(idx % C);
-    long long r = idx / C;
-    const int ox = (int)(r % Wo);
-    r /= Wo;
-    const int oy = (int)(r % Ho);
-    const long long n = r / Ho;
+    FlatIdx fi(idx, total);
+    const int c = fi.pop(C);
+    const int ox = fi.pop(Wo);
+    const int oy = fi.pop(Ho);
+    const long long n = fi.rest();
     const float* b = src + ((n * H + 2 * oy) * W + 2 * ox) * C + c;
     dst[idx] = (b[0] + b[C] + b[(long long)W * C] + b[(long long)W * C + C]) * 0.25f;
 }
@@ -203,9 +226,10 @@ __global__ void spynet_level_input_kernel(const float* __restrict__ pyr, const i
                                           float* __restrict__ out, __bf16* __restrict__ out16, int Np, int h, int w) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Np * h * w) return;
-    const int x = (int)(idx % w);
-    const int y = (int)((idx / w) % h);
-    const int n = (int)(idx / ((long long)w * h));
+    FlatIdx fi(idx, (long long)Np * h * w);
+    const int x = fi.pop(w);
+    const int y = fi.pop(h);
+    const int n = (int)fi.rest();
     float fu = 0.f, fv = 0.f;
     if (flow_prev) {   // flow_up = 2 * bilinear x2 (align_corners=True) of the previous level
         const int hp = h / 2, wp = w / 2;
@@ -283,11 +307,12 @@ __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const 
     const int cq = C / NV;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * H * W * cq) return;
-    const int c4 = (int)(idx % cq);                    // channel vector index
-    const long long pix = idx / cq;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long long)W * H));
+    FlatIdx fi(idx, (long long)N * H * W * cq);
+    const int c4 = fi.pop(cq);                         // channel vector index
+    const long long pix = fi.rest();
+    const int x = fi.pop(W);
+    const int y = fi.pop(H);
+    const int n = (int)fi.rest();
     const long long ip = (long long)y * W + x;
     const float* fa = flow_a + n * flow_img_stride;
     const float2 f1 = *reinterpret_cast<const float2*>(fa + ip * 2);
@@ -379,12 +404,11 @@ __global__ void window_pool_kernel(const T* __restrict__ x, const float* __restr
     const int nWw = fw / 9, nWh = fh / 5;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)BT * nWh * nWw * cq) return;
-    const int c4 = (int)(idx % cq);
-    long long r = idx / cq;
-    const int wx = (int)(r % nWw);
-    r /= nWw;
-    const int wy = (int)(r % nWh);
-    const long long bt = r / nWh;
+    FlatIdx fi(idx, (long long)BT * nWh * nWw * cq);
+    const int c4 = fi.pop(cq);
+    const int wx = fi.pop(nWw);
+    const int wy = fi.pop(nWh);
+    const long long bt = fi.rest();
     const float b = bias1[0];
     f32x4 acc[Q];
 #pragma unroll
@@ -418,12 +442,11 @@ __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict_
     const int cq = C / NV;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)F * H * W * cq) return;
-    const int c4 = (int)(idx % cq);
-    long long r = idx / cq;
-    const int X = (int)(r % W);
-    r /= W;
-    const int Y = (int)(r % H);
-    const long long f = r / H;
+    FlatIdx fi(idx, (long long)F * H * W * cq);
+    const int c4 = fi.pop(cq);
+    const int X = fi.pop(W);
+    const int Y = fi.pop(H);
+    const long long f = fi.rest();
     int ly0, ly1, lx0, lx1;
     fold_range(Y, fh, ly0, ly1);
     fold_range(X, fw, lx0, lx1);
@@ -462,6 +485,9 @@ __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict_
     stv(dst + o, acc);
 }
 
+// GELU, exact (erf) form of torch.nn.GELU (tfocal_transformer.py:82).  (Measured in round 2: Abramowitz-Stegun 7.1.26 on
+// the hardware exp2 / rcp instead of libm's erff made this kernel SLOWER, 92 -> 114 us per call at 720p -- most hidden
+// activations sit in erff's cheap polynomial branch.)
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <typename T>
@@ -471,14 +497,12 @@ __global__ void unfold_gelu_kernel(const T* __restrict__ folded, T* __restrict__
     const int cq = C / NV;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)F * fh * fw * 49 * cq) return;
-    const int c4 = (int)(idx % cq);
-    long long r = idx / cq;
-    const int tap = (int)(r % 49);
-    r /= 49;
-    const int lx = (int)(r % fw);
-    r /= fw;
-    const int ly = (int)(r % fh);
-    const long long f = r / fh;
+    FlatIdx fi(idx, (long long)F * fh * fw * 49 * cq);
+    const int c4 = fi.pop(cq);
+    const int tap = fi.pop(49);
+    const int lx = fi.pop(fw);
+    const int ly = fi.pop(fh);
+    const long long f = fi.rest();
     const int Y = 3 * ly - 3 + tap / 7, X = 3 * lx - 3 + tap % 7;
     f32x4 v[Q];
 #pragma unroll
