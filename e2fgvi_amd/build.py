@@ -65,6 +65,8 @@ def build(force=False, verbose=False, nopk_all=False, lib=None):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     if jobs:
         verify_isa(objdir)
+        if not nopk_all:
+            verify_wino_waits(objdir)
     return out
 
 
@@ -98,6 +100,85 @@ def verify_isa(objdir=None):
         if bad or not isa:
             raise RuntimeError("%s: %s" % (obj, "%d packed-fp32 instructions in a unit that must have none" % len(bad) if isa
                                            else "no gfx950 code object found"))
+
+
+def _kernels(isa):
+    """{kernel name: [(address, mnemonic, operand text)]} of a disassembly"""
+    import re
+    out, cur = {}, None
+    for line in isa.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return out
+
+
+def check_kernel_waits(obj, name, ins):
+    """One kernel's instruction list [(address, mnemonic, operands)]: every marked explicit wait inside a loop must carry
+    the number of vector-memory instructions issued since the previous marked wait (cyclically over the back edge).
+    Returns the number of loops checked; raises RuntimeError on a mismatch."""
+    import re
+    vmem = re.compile(r"^(buffer|global|flat|scratch)_(load|store|atomic)")
+    marks = [i for i in range(len(ins) - 1) if ins[i][1] == "s_waitcnt" and ins[i + 1][1] == "s_waitcnt"
+             and ins[i][2] == ins[i + 1][2] and "vmcnt" in ins[i][2]]
+    if not marks:
+        return 0
+    addr_to_idx = {a: i for i, (a, _, _) in enumerate(ins)}
+    spans = []
+    for i, (a, mn, ops_) in enumerate(ins):
+        if mn.startswith("s_cbranch") or mn == "s_branch":
+            # objdump prints the target as the unsigned 16-bit word offset from the next instruction
+            try:
+                off = int(ops_.split()[0])
+            except (ValueError, IndexError):
+                continue
+            if off >= 32768:
+                off -= 65536
+            tgt = a + 4 + 4 * off
+            if off < 0 and tgt in addr_to_idx:
+                spans.append((addr_to_idx[tgt], i))
+    loops = 0
+    for lo, hi in spans:
+        inner = [m for m in marks if lo <= m <= hi]
+        if not inner or any(lo <= l2 and h2 <= hi and (l2, h2) != (lo, hi) and any(l2 <= m <= h2 for m in inner)
+                            for l2, h2 in spans):
+            continue                                   # no marked wait, or an inner loop owns them
+        loops += 1
+        for j, m in enumerate(inner):
+            n = int(re.search(r"vmcnt\((\d+)\)", ins[m][2]).group(1))
+            if j:
+                rng = range(inner[j - 1] + 2, m)
+            else:                                       # over the back edge: tail of the loop + its head
+                rng = list(range(inner[-1] + 2, hi + 1)) + list(range(lo, m))
+            cnt = sum(1 for k in rng if vmem.match(ins[k][1]))
+            if cnt != n:
+                raise RuntimeError("%s: %s: explicit s_waitcnt vmcnt(%d) at 0x%x follows %d vector-memory instructions "
+                                   "since the previous explicit wait" % (obj, name[:60], n, ins[m][0], cnt))
+    return loops
+
+
+def verify_wino_waits(objdir=None, objects=("conv_wino.o", "conv_wino4.o")):
+    """The Winograd kernels issue their weight loads through pinned inline asm and wait for them with an explicit
+    ``s_waitcnt vmcnt(N)`` whose N is the number of vector-memory instructions issued since (conv_wino.hip): a count the
+    compiler does not maintain.  This check re-derives it from the generated code on every build.  The explicit waits are
+    marked by being issued twice in a row; in every K loop (a backward branch around marked waits) the wait that follows
+    another must carry exactly the number of VMEM instructions between the two -- cyclically over the loop's back edge --
+    because the loads a wait claims were issued immediately before the previous marked wait.  Raises on a mismatch
+    (a compiler that adds, removes or moves a load in the loop), returns the number of loops checked."""
+    objdir = objdir or os.path.join(CSRC, "build")
+    if not os.path.exists(OBJDUMP):
+        return 0
+    loops = 0
+    for obj in objects:
+        for name, ins in _kernels(device_isa(os.path.join(objdir, obj))).items():
+            loops += check_kernel_waits(obj, name, ins)
+    if not loops:
+        raise RuntimeError("verify_wino_waits: no K loop with marked waits found (disassembly format changed?)")
+    return loops
 
 
 if __name__ == "__main__":

@@ -93,7 +93,9 @@ __device__ __forceinline__ void buf_load4_pinned(f32x4& v, i32x4 rsrc, unsigned 
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    // issued twice on purpose: the (free) duplicate marks this wait in the disassembly, where build.verify_wino_waits()
+    // re-counts the vector-memory instructions between consecutive marked waits against N on every build
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
@@ -162,8 +164,11 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;   // a source may end in the middle of a chunk (cpg % 8 == 4)
 #pragma unroll
         for (int it = 0; it < RAW_IT; ++it) {
-            const unsigned off = raw_off[it] * cur_ld4 + chan;
-            q[it] = buf_load4(arsrc, (cvalid && raw_off[it] != OOB) ? off : OOB);
+            // a select, never control flow: exactly ONE load per item on every path (the explicit vmcnt counts rely on
+            // it; with a branch per condition the compiler issued one load per arm)
+            unsigned off = (cvalid && raw_off[it] != OOB) ? raw_off[it] * cur_ld4 + chan : OOB;
+            asm volatile("" : "+v"(off));
+            q[it] = buf_load4(arsrc, off);
         }
         c0 += 8;
         if (c0 >= cur_cpg) {

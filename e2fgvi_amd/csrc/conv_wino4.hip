@@ -142,7 +142,9 @@ __device__ __forceinline__ void w4_load4_pinned(f32x4& v, w4_i32x4 rsrc, unsigne
 }
 template <int N>
 __device__ __forceinline__ void w4_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    // issued twice on purpose: the (free) duplicate marks this wait in the disassembly, where build.verify_wino_waits()
+    // re-counts the vector-memory instructions between consecutive marked waits against N on every build
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // PIPE: the K loop is software-pipelined by one chunk (see k_loop).  Measured on MI355X (profiles/r02_wino4_bench.txt):
@@ -214,8 +216,10 @@ __global__ __launch_bounds__(128 * (FY + 2), (FY == 4 ? 3 : 2)) void conv_wino4_
         const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;
 #pragma unroll
         for (int it = 0; it < RAW_IT; ++it) {
-            const unsigned off = raw_off[it] * cur_ld4 + chan;
-            q[it] = w4_load4(arsrc, (cvalid && raw_off[it] != W4_OOB) ? off : W4_OOB);
+            // a select, never control flow: exactly ONE load per item on every path (the explicit vmcnt counts rely on it)
+            unsigned off = (cvalid && raw_off[it] != W4_OOB) ? raw_off[it] * cur_ld4 + chan : W4_OOB;
+            asm volatile("" : "+v"(off));
+            q[it] = w4_load4(arsrc, off);
         }
         c0 += 8;
         if (c0 >= cur_cpg) {

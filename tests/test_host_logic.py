@@ -189,3 +189,38 @@ def test_engine_cache_is_dropped_when_parameters_can_change():
     a = net._fingerprint()
     net.decoder[6].weight.data = net.decoder[6].weight.data.clone()          # a .data swap far down the parameter list
     assert net._fingerprint() != a
+
+
+def _loop_isa(count_in_tail, n_wait):
+    """a loop: head wait (marked), 2 loads, marked wait vmcnt(2), `count_in_tail` loads, back edge"""
+    ins, a = [], 0x100
+
+    def add(mn, ops=""):
+        nonlocal a
+        ins.append((a, mn, ops))
+        a += 4
+    add("s_waitcnt", "vmcnt(%d)" % n_wait); add("s_waitcnt", "vmcnt(%d)" % n_wait)        # marked wait A (claims over the back edge)
+    add("v_mfma_f32_32x32x2_f32", "v[0:15], v1, v2, v[0:15]")
+    add("buffer_load_dwordx4", "v[4:7], v3, s[0:3], 0 offen"); add("buffer_load_dwordx4", "v[8:11], v3, s[0:3], 0 offen")
+    add("s_waitcnt", "vmcnt(2)"); add("s_waitcnt", "vmcnt(2)")                            # marked wait B: 2 loads since A
+    add("s_waitcnt", "vmcnt(0)")                                                           # a compiler wait: not marked
+    for _ in range(count_in_tail):
+        add("buffer_load_dwordx4", "v[12:15], v3, s[4:7], 0 offen")
+    back = (0x100 - (a + 4)) // 4 + 65536                                                 # as objdump prints simm16
+    add("s_cbranch_scc1", str(back))
+    return ins
+
+
+def test_winograd_explicit_waits_are_checked_against_the_disassembly():
+    """the Winograd kernels' explicit s_waitcnt vmcnt(N) counts compiler-emitted loads.  build.verify_wino_waits
+    re-derives every N from the generated code at build time; here: the checker on a synthetic loop (right and wrong
+    counts) and on the objects of this build."""
+    from e2fgvi_amd import build
+    assert build.check_kernel_waits("x.o", "k", _loop_isa(3, 3)) == 1
+    with pytest.raises(RuntimeError):
+        build.check_kernel_waits("x.o", "k", _loop_isa(4, 3))      # the compiler added a load in the loop
+    with pytest.raises(RuntimeError):
+        build.check_kernel_waits("x.o", "k", _loop_isa(2, 3))      # ... or removed one: the wait would under-wait
+    import os
+    if os.path.exists(build.OBJDUMP) and os.path.exists(os.path.join(build.CSRC, "build", "conv_wino.o")):
+        assert build.verify_wino_waits() >= 32 + 28                 # 4 F(2x2) kernels x 8 wave roles + the wide-tile kernels
