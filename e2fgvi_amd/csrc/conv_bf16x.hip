@@ -709,9 +709,11 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
         // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
         case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, f32);
         case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, f32);
+        case 13: return launch_x<128, 32, 4, 1, true>(p, d->groups, st, f32);      // narrow layers (decoder tail): the A stream is
         case 14: return launch_x<64, 128, 2, 2, true>(p, d->groups, st, f32);
         case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, f32);
         case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, f32);
+        case 18: return launch_x<256, 64, 4, 2, true>(p, d->groups, st, f32);       // all of their traffic, a third of it here
         default: break;
     }
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);

@@ -54,7 +54,7 @@ _W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
 # bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles; tile codes +10
 # are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
 XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
-XTUNE_ROWSHIFT = (11, 16, 17)
+XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
 # exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
@@ -509,7 +509,7 @@ class PackedConvX:
             for code in XTUNE_CANDIDATES + (XTUNE_ROWSHIFT if rowshift else ()):
                 if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
                     continue
-                if code % 10 == 2 and self.Cout // self.groups > 64 and code > 10:
+                if code in (12, 18) and self.Cout // self.groups > 64:
                     continue
                 d.tile = code
                 if self._fn(C.byref(d), st) != 0:

@@ -9,7 +9,9 @@ dev = torch.device("cuda:0")
 # name, N, H, W, cpg, groups, Cout, k, stride, pad
 LAYERS = [("encoder.10", 10, 180, 324, [128, 192], 2, 512, 3, 1, 1), ("encoder.8", 10, 180, 324, [256], 1, 384, 3, 1, 1),
           ("encoder.16", 10, 180, 324, [256, 256], 1, 128, 3, 1, 1), ("encoder.2", 10, 360, 648, [64], 1, 64, 3, 1, 1),
-          ("decoder.4", 10, 720, 1296, [64], 1, 64, 3, 1, 1), ("conv_offset.0", 1, 180, 324, [128, 128, 128, 8], 1, 128, 3, 1, 1),
+          ("decoder.4", 10, 720, 1296, [64], 1, 64, 3, 1, 1), ("decoder.6", 10, 720, 1296, [64], 1, 3, 3, 1, 1),
+          ("decoder.2", 10, 360, 648, [128], 1, 64, 3, 1, 1), ("encoder.14", 10, 180, 324, [32, 48], 8, 256, 3, 1, 1),
+          ("encoder.12", 10, 180, 324, [64, 128], 4, 384, 3, 1, 1), ("conv_offset.0", 1, 180, 324, [128, 128, 128, 8], 1, 128, 3, 1, 1),
           ("conv_offset.2", 1, 180, 324, [128], 1, 128, 3, 1, 1), ("conv_offset.6", 1, 180, 324, [128], 1, 432, 3, 1, 1),
           ("soft split", 10, 180, 324, [128], 1, 512, 7, 3, 3),
           ("qkv", 64800 + 1440, 1, 1, [512], 1, 1536, 1, 1, 0), ("proj", 64800, 1, 1, [512], 1, 512, 1, 1, 0),
