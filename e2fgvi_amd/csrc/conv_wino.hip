@@ -105,7 +105,11 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
     constexpr int NT = 512;
     constexpr int TN = BN / 32;
     constexpr int RAW_H = 8 * MT + 2;
-    constexpr int PLANE_BYTES = RAW_H * PLANE_ROW * 16;
+    constexpr int PLANE_RAW = RAW_H * PLANE_ROW * 16;
+    // plane pitch = 16 (mod 128): the 8 lanes of a staging store (4 pixels x 2 channel quads = the 4 planes twice) hit 8
+    // distinct bank quads; with a pitch of 0 (mod 128) the planes collided 4-way (SQ_LDS_BANK_CONFLICT was 32 % of the LDS
+    // cycles, profiles/r02_wino4_pmc_enc10.txt)
+    constexpr int PLANE_BYTES = PLANE_RAW + ((16 - PLANE_RAW % 128) + 128) % 128;
     constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;              // planes of one 8-channel chunk: [kq][column parity]
     constexpr int STAGE_BYTES = SC * CHUNK_BYTES;             // an LDS stage holds SC chunks (one barrier per 8 SC channels)
     constexpr int TILES = 32 * MT;
@@ -542,6 +546,7 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
         case 32: return launch_wino<2, 32, 2>(p, d->groups, st);
         case 164: return launch_wino<1, 64, 2>(p, d->groups, st);
         case 132: return launch_wino<1, 32, 2>(p, d->groups, st);
+        // (four chunks per LDS stage -- half the barriers -- measured 1-6 % slower on every layer, profiles/r02_wino_sc4.txt)
         default: break;
     }
     e2fgvi_set_error("conv3x3_winograd: tile must be 0 (auto), 32, 64 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");

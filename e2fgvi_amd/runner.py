@@ -134,11 +134,11 @@ class ShardedStep:
 
 
 def dominant_kernel_probe(net, dev, iters=20):
-    """Device time of the dominant kernel (conv_wino_kernel, fp32 Winograd F(2x2,3x3) on the fp32 MFMA pipe) on its
-    heaviest single launch of the north-star clip: encoder layer 10 (640 -> 512 in 2 groups, 3x3, 10 frames of 60x108),
-    hip events on the launch stream.  `achieved` / `frac` count the FLOPs ISSUED to the matrix pipe (16 of the 36
-    direct-convolution multiplies per 2x2 outputs, on 16x16-pixel blocks: 64x112 padded pixels per frame);
-    `achieved_algorithmic` counts the direct-convolution FLOPs and can exceed the peak."""
+    """Device time of the dominant kernel (the fp32 Winograd convolution on the fp32 MFMA pipe: conv_wino4_kernel,
+    F(2x4,3x3), since round 2) on its heaviest single launch of the north-star clip: encoder layer 10 (640 -> 512 in 2
+    groups, 3x3, 10 frames of 60x108), hip events on the launch stream.  `achieved` / `frac` count the FLOPs ISSUED to the
+    matrix pipe (24 of the 72 direct-convolution multiplies per 2x4 outputs, on 16x16-pixel blocks: 64x112 padded pixels
+    per frame); `achieved_algorithmic` counts the direct-convolution FLOPs and can exceed the peak."""
     from . import ops
     eng = net.engine()
     layer = eng.enc[5]
@@ -154,7 +154,7 @@ def dominant_kernel_probe(net, dev, iters=20):
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
     wino = layer.algo == "auto"
-    wk = layer._work(10, 60, 108, 60, 108, wino, 0)
+    wk = layer._work(10, 60, 108, 60, 108, wino, layer._wino4_rule(10, 60, 108) if wino else 0)
     gflop, gflop_iss = 2e-9 * wk["macs"], 2e-9 * wk["issued"]
     tf, tf_iss = gflop / (us * 1e-6) / 1e3, gflop_iss / (us * 1e-6) / 1e3
     return {"kernel": "%s (encoder.layers.10: 3x3 640->512 g2 on 10x60x108)" % wk["kernel"], "avg_us": round(us, 2),
