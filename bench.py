@@ -228,16 +228,22 @@ def main():
     }
     # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the
     # summary of the last collection is committed under profiles/ and quoted here (bytes per forward of one clip)
+    traffic_cfg = None
     if b == 1 and (t, lt) == (10, 10) and not hq and args.precision == "fp32":
+        traffic_cfg = ""
+    elif b == 1 and (t, lt) == (10, 10) and hq and (H, W) == (720, 1296) and args.precision == "bf16":
+        traffic_cfg = "_hq720_bf16"
+    if traffic_cfg is not None:
         for tag in ("r02", "r01"):
-            tfile = os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)
+            tfile = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (tag, traffic_cfg))
             if os.path.exists(tfile):
                 try:
                     tj = json.load(open(tfile))
                     out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
                     out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, "
-                                                       "separate passes (profiles/%s_hbm_traffic.json); fabric-side, includes "
-                                                       "Infinity-Cache hits; algorithmic minimum is 0.19 GB/clip" % tag)
+                                                       "separate passes (profiles/%s_hbm_traffic%s.json); fabric-side, includes "
+                                                       "Infinity-Cache hits; compulsory minimum (input + weights + output) is %s GB/clip"
+                                                       % (tag, traffic_cfg, "0.19" if not hq else "0.39"))
                     break
                 except Exception:
                     pass

@@ -2,8 +2,8 @@
 # HBM traffic of one forward from rocprofv3 PMC counters (separate passes, no trace domains besides kernel-trace),
 # corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 # half of a wide coalesced read stream, so the read side is doubled.
-#   bash tools/pmc.sh <tag>    -> gpurun_out/pmc_<tag>/traffic.json
-TAG=${1:-run}
+#   bash tools/pmc.sh <tag> [bench.py args...]    -> gpurun_out/pmc_<tag>/traffic.json
+TAG=${1:-run}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -11,9 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 # the tile choices of the benchmark (written by a first un-profiled run), no tuning launches inside the counted forwards
 export E2FGVI_TUNE_FILE=$OUT/tune.txt
 rm -f $E2FGVI_TUNE_FILE
-python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/tune_run.log 2>&1
+python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $OUT/tune_run.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > $OUT/$C.log 2>&1 || true
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 "$@" > $OUT/$C.log 2>&1 || true
 done
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
