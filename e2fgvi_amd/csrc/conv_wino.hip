@@ -25,6 +25,21 @@
 // 32), produced by e2fgvi_pack_winograd_weight.
 #include "common.h"
 
+#ifndef E2_WINO_VARIANT
+#define E2_WINO_VARIANT 0      // experiment switches (tools only): 1 = mid-stage prefetch of the upper waves, 2 = static s_setprio by SIMD partner, 4 = s_setprio around the MFMA block
+#endif
+#ifdef E2_WINO_TIMING
+// tools/wino_timing.py builds this file once more with -DE2_WINO_TIMING: every wave of the first 64 workgroups accumulates
+// the s_memtime cycles it spends in five segments of the K loop (waiting for its weights / transform + MFMA issue /
+// parking the next stage / issuing the stage after / the stage barrier) and writes the sums here at the end.  Diagnostics
+// only -- the product library is built without it.
+__device__ unsigned long long e2_wino_dbg[64 * 8 * 8];
+#define E2T_NOW() __builtin_readcyclecounter()
+#define E2T(...) __VA_ARGS__
+#else
+#define E2T(...)
+#endif
+
 namespace {
 
 struct WinoParams {
@@ -101,7 +116,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
 template <int MT, int BN, int SC>
 __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
-    static_assert(SC == 2 || SC == 4, "chunks per LDS stage");
+    static_assert(SC == 2, "chunks per LDS stage (the explicit vmcnt counts of k_loop assume two)");
     constexpr int NT = 512;
     constexpr int TN = BN / 32;
     constexpr int RAW_H = 8 * MT + 2;
@@ -262,21 +277,34 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
     for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
     __syncthreads();
 
+    E2T(unsigned long long tsum[5]; for (int k_ = 0; k_ < 5; ++k_) tsum[k_] = 0; const unsigned long long t_k0 = E2T_NOW();)
     // the K loop, specialised on the wave's role so that the input transform is plain adds / subtracts
     auto k_loop = [&](auto XI_, auto PB_) {
         constexpr int XI = decltype(XI_)::value;
         constexpr bool PB = decltype(PB_)::value != 0;
+        // Waves w and w + 4 share a SIMD.  Measured with tools/wino_timing.py (profiles/r02_wino_timing.txt): per stage a wave
+        // spends ~10 % of its K-loop cycles parking the next stage's patch and issuing the loads of the stage after, and with
+        // every wave doing that right before the stage barrier the matrix pipe idled meanwhile.  The upper four waves (xi >= 2)
+        // therefore do it in the MIDDLE of the stage, under the MFMAs of their SIMD partners, and vice versa.  The target
+        // buffer is free for the whole stage (its readers passed the previous barrier) and the stage barrier still follows
+        // every wave's stores.
+        constexpr bool LATE = XI >= 2 && (E2_WINO_VARIANT & 1);
+        if (E2_WINO_VARIANT & 2) __builtin_amdgcn_s_setprio(XI >= 2 ? 1 : 2);      // static priority by SIMD partner
         for (int st = 0; st < nstages; ++st) {
             const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
             for (int q = 0; q < SC; ++q) {
+                E2T(const unsigned long long t_a = E2T_NOW();)
                 load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);            // next chunk's weights land during this chunk
                 // loads issued after this chunk's weights: the next chunk's (2 TN) and, across a stage boundary, the
                 // patch prefetch (SC * RAW_IT)
-                if (q == 0) claim_b(IC<2 * TN + SC * RAW_IT>{}, bq[q & 1]);
+                // (upper waves: the patch prefetch sits between chunk 0 and chunk 1 of the stage)
+                if ((q == 0) != LATE) claim_b(IC<2 * TN + SC * RAW_IT>{}, bq[q & 1]);
                 else claim_b(IC<2 * TN>{}, bq[q & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                E2T(const unsigned long long t_b = E2T_NOW(); tsum[0] += t_b - t_a;)
                 const unsigned char* raw = stage + q * CHUNK_BYTES;
+                if (E2_WINO_VARIANT & 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const unsigned char* rm = raw + m * (8 * PLANE_ROW * 16);
@@ -297,12 +325,20 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
                             acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q & 1][1][n][k], acc[1][m][n], 0, 0, 0);
                         }
                 }
-            }
-            // the registers hold stage st+1: park it in the other buffer (its readers passed the previous barrier)
-            store_raw((st & 1) ^ 1);
+                E2T(__builtin_amdgcn_sched_barrier(0); tsum[1] += E2T_NOW() - t_b;)
+                if ((q == 0 && LATE) || (q == SC - 1 && !LATE)) {
+                    // the registers hold stage st+1: park it in the other buffer (its readers passed the previous barrier)
+                    E2T(const unsigned long long t_c = E2T_NOW();)
+                    store_raw((st & 1) ^ 1);
+                    E2T(__builtin_amdgcn_sched_barrier(0); const unsigned long long t_d = E2T_NOW(); tsum[2] += t_d - t_c;)
 #pragma unroll
-            for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
+                    for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
+                    E2T(__builtin_amdgcn_sched_barrier(0); tsum[3] += E2T_NOW() - t_d;)
+                }
+            }
+            E2T(const unsigned long long t_e = E2T_NOW();)
             __syncthreads();
+            E2T(tsum[4] += E2T_NOW() - t_e;)
         }
     };
     switch (wave) {          // wave-uniform
@@ -316,6 +352,10 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         default: k_loop(IC<3>{}, IC<1>{}); break;
     }
 
+#ifdef E2_WINO_TIMING
+    const unsigned long long t_k1 = E2T_NOW();
+    const unsigned long long t_start = t_k0;
+#endif
     // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
     float* E = reinterpret_cast<float*>(smem);
     const int HW = p.H * p.W;
@@ -392,6 +432,15 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
             }
         }
     }
+#ifdef E2_WINO_TIMING
+    if (blockIdx.x < 64 && blockIdx.y == 0 && lane == 0) {
+        unsigned long long* o = e2_wino_dbg + (blockIdx.x * 8 + wave) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = tsum[k];
+        o[5] = t_k1 - t_start;                     // the whole K loop
+        o[6] = E2T_NOW() - t_k1;                   // the epilogue
+        o[7] = (unsigned long long)nstages;
+    }
+#endif
 }
 
 struct WinoPack {
@@ -552,3 +601,9 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
     e2fgvi_set_error("conv3x3_winograd: tile must be 0 (auto), 32, 64 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");
     return E2FGVI_EINVAL;
 }
+
+#ifdef E2_WINO_TIMING
+extern "C" int e2fgvi_wino_timing_read(unsigned long long* host_dst, int32_t n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(e2_wino_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
