@@ -243,6 +243,35 @@ def test_bf16_path_end_to_end(dev, model, hw, t, lt):
     assert torch.equal(got, got2), "bf16 path is not deterministic (two streams)"
 
 
+@pytest.mark.parametrize("fixture", ["g5_hq_stress_720x1296_t3_lt2.npz", "g6_hq_stress_1080x1944_t2_lt2.npz", "g3_hq_stress_120x216_t4_lt3.npz"])
+def test_bf16_path_against_reference_golden(dev, fixture):
+    """The bf16 data path at the BASELINE HQ resolutions (720x1296: 12x12 window grid, 1080x1944: 18x18) against the
+    sub-sampled outputs of the REAL reference (tests/golden/make_golden.py) -- the same bound as at the small sizes
+    (max abs <= 2.5e-2 on frames in [-1,1], <= 6 % of the reference's rms; flows <= 5e-2 px)."""
+    import importlib
+    import os
+    import numpy as np
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    H, W, t, lt, b, seed, so, sf = [int(v) for v in z["meta"]]
+    model, kind = str(z["model"]), str(z["kind"])
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(synth_state_dict(model, kind, 0))
+    net = net.to(dev).eval()
+    net.precision = "bf16"
+    x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
+    out, (ff, fb) = net(x.to(dev), lt)
+    out, ff, fb = out.cpu(), ff.cpu(), fb.cpu()
+    diff = out[:, :, ::so, ::so].numpy() - z["out_sub"]
+    d, rms = np.abs(diff).max(), float(z["out_stats"][2])
+    print("bf16 path vs reference %s: max abs %.3e, rms of the difference %.2e x rms(reference)"
+          % (fixture, d, np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms))
+    assert np.isfinite(out.numpy()).all() and d <= 2.5e-2 and np.sqrt((diff.astype(np.float64) ** 2).mean()) <= 6e-2 * rms
+    fmax = max(1.0, float(z["flow_fwd_stats"][3]))
+    assert np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max() <= 5e-2 * max(1.0, fmax / 4)
+    assert np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max() <= 5e-2 * max(1.0, fmax / 4)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 5, 6])
 def test_mdcn_bf16_mfma(dev, tile):
     """deformable conv with the sampled columns and the weights rounded to bf16 for the MFMA (fp32 gather, blend and
