@@ -48,6 +48,8 @@ struct ConvXParams {
     int dst2_ld, dst2_coff;
     int act;
     float slope;
+    int tp_cq;                            // tap-packed K-steps (narrow single-source layers): 16-byte chunks per tap (1, 2 or 4), 0 = off
+    unsigned tp_magic;                    //   ceil(2^32 / KW): tap -> kernel row by __umulhi
     int dbg_noload;                       // tools only (tile codes 21 / 26): skip every DMA after the first stage -> the MFMA + LDS ceiling
 };
 
@@ -297,11 +299,71 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             }
         }
     };
-    issue_a(0);
+    const bool tap_packed = !S3 && !F32 && p.tp_cq != 0;          // its first A stage is issued by the packed branch below
+    if (!tap_packed) issue_a(0);
     issue_b(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if constexpr (!S3) {
+    if (!tap_packed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if constexpr (!S3 && !F32) {
+        if (p.tp_cq) {
+            // Tap-packed K-steps: a source of <= 32 channels fills only 1 / 2 / 4 of the 8 chunks of a K-step, so a step
+            // carries 8 / 4 / 2 TAPS instead of one (SPyNet's 7x7 layers on 8-64 channels, the encoder's first layer: 49 -> 7 /
+            // 13 / 25 steps).  Logical chunk c of a step = tap TP * step + c / cq, channel chunk c % cq; the lanes of a row then
+            // fetch from different taps, so the byte offsets are formed per step (a dozen VALU per item -- cheap against the
+            // steps it removes).
+            const int cq = p.tp_cq, TP = 8 / cq, KK = p.KH * p.KW;
+            int t_j[A_IT];
+            unsigned t_cb[A_IT];
+            bool t_ok[A_IT];
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int c = (int)(a_ch16[it] >> 4);
+                const int cc = c % cq;
+                t_j[it] = c / cq;
+                t_cb[it] = sc0 + (unsigned)cc * 16u;
+                t_ok[it] = cc * 8 < sg0;
+            }
+            const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(sp0, sb0);
+            auto issue_a_packed = [&](int stage, int step) {
+                unsigned char* sa = smem + stage * A_BYTES + wave * 1024;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) {
+                    const int tap = TP * step + t_j[it];
+                    const int tky = (int)__umulhi((unsigned)tap, p.tp_magic), tkx = tap - tky * p.KW;
+                    const bool ok = t_ok[it] && tap < KK && ((a_msk[it] >> tky) & (a_msk[it] >> (8 + tkx)) & 1u) != 0;
+                    const unsigned off = ok ? (unsigned)(a_pix[it] + tky * p.W + tkx) * sl0 + t_cb[it] : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + it * NT * 16), 16, off, 0, 0, 0);
+                }
+            };
+            issue_a_packed(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int step = 0; step < p.nsteps; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < p.nsteps) {
+                    issue_a_packed(cur ^ 1, step + 1);
+                    issue_b(cur ^ 1, step + 1);
+                }
+                compute(smem + cur * A_BYTES, smem_b + cur * B_BYTES, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        } else
+        for (int step = 0; step < p.nsteps; ++step) {
+            const int cur = step & 1;
+            const bool more = step + 1 < p.nsteps && !(p.dbg_noload & 1);
+            if (more) {
+                if (advance()) retarget();
+                issue_a(cur ^ 1);
+                issue_b(cur ^ 1, step + 1);
+            }
+            compute(smem + cur * A_BYTES, smem_b + cur * B_BYTES, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next stage has landed (this wave's share)
+            __syncthreads();                                        // ... everybody's, and this stage's readers are done
+        }
+    } else if constexpr (!S3) {
         for (int step = 0; step < p.nsteps; ++step) {
             const int cur = step & 1;
             const bool more = step + 1 < p.nsteps && !(p.dbg_noload & 1);
@@ -519,12 +581,14 @@ struct PackX {
     int cpg[E2FGVI_MAX_SRC];
     int Cout_g, Npad, Cin_g, steps_per_tap;
     int kc, ch;                           // channels per K-step (64 bf16 / 32 fp32) and per 16-byte chunk (8 / 4)
+    int tp_cq;                            // tap-packed steps: chunks per tap (0 = off)
     long long total, wgroup_elems;        // elements
 };
 
 bool geometry_x(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* cpg, PackX* q, bool f32 = false) {
     q->kc = f32 ? 32 : 64;
     q->ch = f32 ? 4 : 8;
+    q->tp_cq = 0;
     if (Cout <= 0 || groups <= 0 || Cout % groups || KH <= 0 || KW <= 0 || nsrc < 1 || nsrc > E2FGVI_MAX_SRC) return false;
     q->Cout = Cout; q->groups = groups; q->KH = KH; q->KW = KW; q->nsrc = nsrc;
     q->Cout_g = Cout / groups;
@@ -556,6 +620,15 @@ __global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __rest
     rem /= p.Npad;
     const int koct = (int)(rem & 7);
     const int step = (int)(rem >> 3);
+    if (p.tp_cq) {                        // tap-packed: chunk koct of a step = tap TP * step + koct / cq, channels (koct % cq) * 8 ...
+        const int tapk = (8 / p.tp_cq) * step + koct / p.tp_cq;
+        const int chk = (koct % p.tp_cq) * 8 + e;
+        float vk = 0.f;
+        if (tapk < p.KH * p.KW && chk < p.cpg[0] && n < p.Cout_g)
+            vk = w[((long long)n * p.Cin_g + chk) * (p.KH * p.KW) + tapk];
+        wp[idx] = (T)vk;
+        return;
+    }
     const int tap = step / p.steps_per_tap;
     int blk = step - tap * p.steps_per_tap;
     int s = 0, prefix = 0;
@@ -631,6 +704,38 @@ extern "C" int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int3
     return 0;
 }
 
+// tap-packed variant of the bf16 packing: one source of <= 32 channels (multiple of 8), no groups, more than one tap
+static bool geometry_taps(int Cout, int KH, int KW, int cin, PackX* q) {
+    const int32_t cpg[1] = {cin};
+    if (cin > 32 || KW < 2 || !geometry_x(Cout, 1, KH, KW, 1, cpg, q, false)) return false;
+    q->tp_cq = cin <= 8 ? 1 : (cin <= 16 ? 2 : 4);
+    const int TP = 8 / q->tp_cq;
+    const int steps = cdiv(KH * KW, TP);
+    q->wgroup_elems = (long long)steps * 64 * q->Npad;
+    q->total = q->wgroup_elems;
+    return true;
+}
+
+extern "C" int64_t e2fgvi_packed_conv_weight_bf16x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin) {
+    PackX q;
+    if (!geometry_taps(Cout, KH, KW, cin, &q)) {
+        e2fgvi_set_error("packed_conv_weight_bf16x_taps_size: one source of 8 / 16 / 24 / 32 channels, more than one tap");
+        return E2FGVI_EINVAL;
+    }
+    return q.total;
+}
+
+extern "C" int e2fgvi_pack_conv_weight_bf16x_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
+                                                  void* stream) {
+    PackX q;
+    E2_REQUIRE(w && wpacked, E2FGVI_EINVAL, "pack_conv_weight_bf16x_taps: null pointer");
+    E2_REQUIRE(geometry_taps(Cout, KH, KW, cin, &q), E2FGVI_EINVAL, "pack_conv_weight_bf16x_taps: bad geometry");
+    hipLaunchKernelGGL(pack_conv_weight_x_kernel<__bf16>, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (__bf16*)wpacked, q);
+    E2_LAUNCH_CHECK("pack_conv_weight_bf16x_taps");
+    return 0;
+}
+
 static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv2d_bf16x: null descriptor");
     PackX q;
@@ -677,6 +782,17 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
     p.M = d->N * d->Ho * d->Wo;
     p.nsteps = d->KH * d->KW * q.steps_per_tap;
+    p.tp_cq = 0; p.tp_magic = 0;
+    if (d->tap_packed) {
+        PackX qt;
+        E2_REQUIRE(!f32 && d->nsrc == 1 && d->groups == 1 && geometry_taps(d->Cout, d->KH, d->KW, d->src_cpg[0], &qt), E2FGVI_EINVAL,
+                   "conv2d_bf16x: tap-packed weights are for one bf16 source of <= 32 channels, no groups, more than one tap");
+        E2_REQUIRE(d->tile < 10 || d->tile > 20, E2FGVI_EUNSUP, "conv2d_bf16x: the row-shift tiles do not take tap-packed weights");
+        q.wgroup_elems = qt.wgroup_elems;
+        p.tp_cq = qt.tp_cq;
+        p.tp_magic = 0xFFFFFFFFu / (unsigned)d->KW + 1u;
+        p.nsteps = cdiv(d->KH * d->KW, 8 / qt.tp_cq);
+    }
     p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * esz);
     p.w = d->wpacked; p.bias = d->bias;
     p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff; p.res_bf16 = d->res_dtype == E2FGVI_BF16;

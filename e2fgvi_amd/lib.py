@@ -40,7 +40,7 @@ class ConvXDesc(C.Structure):
         ("res_dtype", C.c_int32),
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("dst_dtype", C.c_int32),
         ("dst2", _fp), ("dst2_ld", C.c_int32), ("dst2_coff", C.c_int32),
-        ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32), ("dst_nchw", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32), ("dst_nchw", C.c_int32), ("tap_packed", C.c_int32),
     ]
 
 
@@ -73,6 +73,8 @@ SYMBOLS = {
     "e2fgvi_conv2d_bf16x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
     "e2fgvi_packed_conv_weight_bf16x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_bf16x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
+    "e2fgvi_packed_conv_weight_bf16x_taps_size": (_i64, [_i32, _i32, _i32, _i32]),
+    "e2fgvi_pack_conv_weight_bf16x_taps": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_conv2d_f32x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
     "e2fgvi_packed_conv_weight_f32x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_f32x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),

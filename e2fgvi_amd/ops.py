@@ -385,7 +385,9 @@ class PackedConvX:
     Either way: fp32 epilogue (bias, fp32 / bf16 residual, activation or the DCN offset post-processing), bf16 or fp32
     result (NHWC, or fp32 NCHW), optional second bf16 copy (`out2`)."""
 
-    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, dtype=torch.bfloat16):
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, dtype=torch.bfloat16, taps=None):
+        """taps: None = tap-packed K-steps whenever the layer qualifies (one bf16 source of <= 32 channels, no groups, more
+        than one tap), False = never (A/B measurements)"""
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -401,14 +403,25 @@ class PackedConvX:
         self.name = "conv"
         self.tune = False          # time XTUNE_CANDIDATES on the first call of every new size class and keep the fastest
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
-        size_fn = lib.e2fgvi_packed_conv_weight_f32x_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size
-        pack_fn = lib.e2fgvi_pack_conv_weight_f32x if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x
-        n = size_fn(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
-        if n < 0:
-            _L.check(int(n), "packed_conv_weight_x_size")
-        self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
-        _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, _stream()),
-                 "pack_conv_weight_x")
+        # narrow single-source layers (SPyNet's 7x7 stacks, the encoder's first layer): K-steps that carry several taps
+        self.taps = (not self.f32 and len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 32 and self.KW > 1
+                     and taps is not False and os.environ.get("E2FGVI_TAPS", "1") != "0")
+        if self.taps:
+            n = lib.e2fgvi_packed_conv_weight_bf16x_taps_size(self.Cout, self.KH, self.KW, self.cpg[0])
+            if n < 0:
+                _L.check(int(n), "packed_conv_weight_bf16x_taps_size")
+            self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
+            _L.check(lib.e2fgvi_pack_conv_weight_bf16x_taps(_ptr(w), _ptr(self.wpacked), self.Cout, self.KH, self.KW, self.cpg[0],
+                                                            _stream()), "pack_conv_weight_bf16x_taps")
+        else:
+            size_fn = lib.e2fgvi_packed_conv_weight_f32x_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size
+            pack_fn = lib.e2fgvi_pack_conv_weight_f32x if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x
+            n = size_fn(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
+            if n < 0:
+                _L.check(int(n), "packed_conv_weight_x_size")
+            self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
+            _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, _stream()),
+                     "pack_conv_weight_x")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
 
     def out_hw(self, H, W):
@@ -450,6 +463,7 @@ class PackedConvX:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff, d.res_dtype = residual.data_ptr(), residual.shape[3], res_coff, _dt(residual)
         d.act, d.slope, d.tile = act, slope, 0
+        d.tap_packed = 1 if self.taps else 0
         return d
 
     def __call__(self, sources, out=None, out_dtype=None, out_coff=0, residual=None, res_coff=0, act=ACT_NONE,
@@ -489,10 +503,13 @@ class PackedConvX:
             cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
             kc = 32 if self.f32 else 64
             cin_p = sum(-(-c // kc) * kc for c in self.cpg)
-            _L.annotate(layer=self.name, kernel="conv_%s tile=%d" % ("f32x" if self.f32 else "bf16x", tile),
+            if self.taps:                                   # K-steps of several taps: issued K = steps * 64
+                tp = 8 // (1 if self.cpg[0] <= 8 else 2 if self.cpg[0] <= 16 else 4)
+                cin_p = -(-K2 // tp) * 64 / K2
+            _L.annotate(layer=self.name, kernel="conv_%s tile=%d%s" % ("f32x" if self.f32 else "bf16x", tile, " taps" if self.taps else ""),
                         shape="N%d %dx%d %d->%d k%d s%d g%d" % (N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
                         macs=N * Ho * Wo * self.Cout * cin_g * K2,
-                        issued=N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2)
+                        issued=int(N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2))
         _L.check(self._fn(C.byref(d), _stream()), "conv2d_x")
         return out
 
@@ -505,7 +522,7 @@ class PackedConvX:
         for _ in range(2):
             self._fn(C.byref(d), st)
         for _ in range(rounds):
-            rowshift = (self.KH, self.KW, self.stride, self.pad) == (3, 3, 1, 1) and not self.f32
+            rowshift = (self.KH, self.KW, self.stride, self.pad) == (3, 3, 1, 1) and not self.f32 and not self.taps
             for code in XTUNE_CANDIDATES + (XTUNE_ROWSHIFT if rowshift else ()):
                 if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
                     continue

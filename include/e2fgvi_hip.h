@@ -312,6 +312,7 @@ typedef struct {
     float slope;
     int32_t tile;                      /* 0 = auto                                                          */
     int32_t dst_nchw;                  /* 1: dst is plain fp32 NCHW [N,Cout,Ho,Wo] (dst_ld / dst_coff ignored)  */
+    int32_t tap_packed;                /* 1: wpacked comes from e2fgvi_pack_conv_weight_bf16x_taps (ABI version 3)  */
 } e2fgvi_convx_desc;
 
 int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream);
@@ -322,6 +323,14 @@ int64_t e2fgvi_packed_conv_weight_bf16x_size(int32_t Cout, int32_t groups, int32
 /* w: fp32 [Cout, sum(cpg), KH, KW] (torch OIHW) */
 int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
                                   int32_t nsrc, const int32_t* src_cpg, void* stream);
+
+/* Tap-packed weights for narrow layers (ONE bf16 source of <= 32 channels, no groups, KH*KW > 1: SPyNet's 7x7 stacks
+ * model/modules/flow_comp.py:180-215 and the encoder's first layer e2fgvi.py:76): a K-step of 64 carries 8 / 4 / 2 taps of
+ * 8 / 16 / 32 channels instead of one padded tap -- 49 taps in 7 / 13 / 25 steps.  Set tap_packed = 1 in the descriptor;
+ * the row-shift tile codes do not apply. */
+int64_t e2fgvi_packed_conv_weight_bf16x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin);
+int e2fgvi_pack_conv_weight_bf16x_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
+                                       void* stream);
 
 /* The same LDS-DMA kernel on fp32 operands: fp32 NHWC sources (channels per source in multiples of 4), fp32 packed weights,
  * v_mfma_f32_32x32x2_f32 (exact fp32, a K-step = 32 channels).  Same descriptor; used by the fp32 path for its GEMM-shaped

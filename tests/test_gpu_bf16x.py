@@ -47,6 +47,13 @@ CASES = [
     ("3x3 72 -> 128, one-pixel-wide and one-row images (row-shift masks)", 5, 7, 1, [72], 1, 128, 3, 1, 1, (1, 11, 13, 14, 18)),
     ("3x3 64 -> 128, W = 2", 3, 9, 2, [64], 1, 128, 3, 1, 1, (1, 11, 16)),
     ("3x3 64 -> 3 (decoder.6)", 2, 24, 36, [64], 1, 3, 3, 1, 1, (0, 3, 13, 18)),
+    # tap-packed K-steps (one source of <= 32 channels): 8 / 4 / 2 taps per step, tail taps past the kernel, a source that
+    # does not fill its padded chunk count (24 of 32 channels)
+    ("7x7 8 -> 32 (spynet .0): 8 taps per K-step", 2, 20, 28, [8], 1, 32, 7, 1, 3, (0, 1, 3, 5)),
+    ("7x7 16 -> 2 (spynet .4): 4 taps per K-step", 2, 20, 28, [16], 1, 2, 7, 1, 3, (0, 3)),
+    ("7x7 32 -> 64 (spynet .1): 2 taps per K-step", 1, 20, 28, [32], 1, 64, 7, 1, 3, (0, 1, 2, 4)),
+    ("3x3 24 -> 40: 24 of 32 channels, 2 taps per K-step", 2, 11, 13, [24], 1, 40, 3, 1, 1, (0, 2, 5)),
+    ("5x5 stride 2 pad 2, 16 -> 32: 4 taps per K-step", 2, 17, 22, [16], 1, 32, 5, 2, 2, (0, 5)),
 ]
 
 
