@@ -1002,13 +1002,27 @@ extern "C" int e2fgvi_conv2d_nhwc(const e2fgvi_conv_desc* d, void* stream) {
         const long long tiles = (long long)d->N * cdiv(d->Ho, 8) * cdiv(d->Wo, 16);
         bool c16 = true;     // a 16-channel block must be the pack granule or divide every source without padding
         for (int s = 0; s < d->nsrc; ++s) c16 = c16 && (d->bk == 16 || d->src_cpg[s] % 32 == 0);
-        if (tiles >= 512 && d->Wo >= 32 && c16) {
+        bool c8 = true;      // ... and an 8-channel block likewise
+        for (int s = 0; s < d->nsrc; ++s) c8 = c8 && d->src_cpg[s] % 8 == 0 && (d->bk == 8 || d->src_cpg[s] % d->bk == 0);
+        if (d->KH == 7) {
+            // SPyNet's 7x7 stacks (8 -> 32 -> 64 -> 32 -> 16 -> 2 on 18 frame pairs, 64x128 ... 2x4 images), measured per level
+            // with tools/spynet_bench.py (profiles/r02_spynet_bench.txt): the 16-wide halo tile for <= 16 output channels at
+            // EVERY level (73 vs 30 us on 32x64), the 8-channel-block halo tile 51 for wider outputs down to 32x64 images
+            // (the former rule left those to the implicit GEMM: 98 -> 78, 133 -> 102 us; on 64x128 it beats the former
+            // choices 27 / 10 by 6-22 %), four K-groups of the implicit GEMM for the 64-channel layer on the tiny levels.
+            // SPyNet runs beside the encoder but is not hidden by it: its microseconds count.
+            int cin = 0;
+            for (int s = 0; s < d->nsrc; ++s) cin += d->src_cpg[s];
+            if (q.Cout_g <= 16 && c16) code = 10041;
+            else if (c8 && (tiles >= 128 || cin <= 8 || (cin <= 32 && tiles >= 64))) code = 10051;
+            else if (d->bk == 32 && cin % 32 == 0 && tiles < 128) code = 3225;
+        } else if (tiles >= 512 && d->Wo >= 32 && c16) {
             const bool narrow = q.Cout_g <= 32;
-            code = 10000 + (d->KH == 3 ? (narrow ? 12 : 11) : (narrow ? 27 : 10));   // 27: 7 taps per barrier
-            if (q.Cout_g <= 16) code = 10000 + (d->KH == 3 ? 42 : 41);              // 16-wide MFMA tiles
-        } else if (tiles >= 512 && d->Wo >= 32 && d->bk == 8) {                     // 4/8-channel inputs (SPyNet conv 1)
+            code = 10000 + (narrow ? 12 : 11);
+            if (q.Cout_g <= 16) code = 10042;                                       // 16-wide MFMA tiles
+        } else if (tiles >= 512 && d->Wo >= 32 && d->bk == 8) {                     // 4/8-channel inputs
             const bool narrow = q.Cout_g <= 32;
-            code = 10000 + (d->KH == 3 ? (narrow ? 52 : 53) : (narrow ? 51 : 54));
+            code = 10000 + (narrow ? 52 : 53);
         }
     }
     if (code >= 10000) {   // halo-staged kernel
