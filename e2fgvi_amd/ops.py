@@ -179,7 +179,9 @@ class PackedConv:
         # Measured on MI355X (tools/wino_bench.py, profiles/r02_wino4_bench.txt): F(2x4) x 64 couts beats the F(2x2) kernel
         # by 6-8 % on the batched layers with >= 256 output channels per group (encoder.layers.8 / .10) and loses
         # everywhere else (one workgroup per CU: the 16x16-pixel x 32-cout F(2x2) shape runs two); F(4x4) ties at best.
-        if self.Cout // self.groups >= 256 and N * H * W >= _W4_MINPIX and os.environ.get("E2FGVI_WINO4_AUTO", "1") != "0":
+        # (... and >= 256 input channels per group: on encoder.layers.6, 128 -> 256, the 8x16x32 F(2x2) shape is 6-10 % faster)
+        if (self.Cout // self.groups >= 256 and sum(self.cpg) >= 256 and N * H * W >= _W4_MINPIX
+                and os.environ.get("E2FGVI_WINO4_AUTO", "1") != "0"):
             return 2464
         return 0
 

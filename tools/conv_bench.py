@@ -36,7 +36,11 @@ SHAPES = {
     "spy5": (18, 64, 128, [16], 1, 2, 7, 1, 3, 16),
 }
 ALLW = [0, 223, 213, 222, 212, 122, 1122, 1222, 224, 214, 1224, 225, 215, 1225, 3225, 227, 217, 1227, 2227, 2123, 2223, 3123, 1233, 1133, 1213, 2213, 3213, 228, 118, 211, 219]
+HALO3 = [10000 + i for i in (1, 2, 3, 4, 5, 11, 6, 12, 22, 24, 31, 25, 32, 26, 52, 53, 42, 44, 45)]
 CODES = {"proj": ALLW, "fc2_bk32": ALLW, "fc2_bk16": ALLW, "sc": ALLW}
+if os.environ.get("CONV_BENCH_SET") == "narrow":          # the non-Winograd 3x3 layers of the fp32 forward
+    SHAPES["enc4"] = (10, 120, 216, [64], 1, 128, 3, 2, 1, 32)
+    CODES = {"dec6": [0] + HALO3 + ALLW, "enc0_b8": [0] + ALLW, "enc0_b16": [0] + ALLW, "enc4": [0] + ALLW}
 SHAPES = {k: v for k, v in SHAPES.items() if k in CODES}
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 g = torch.Generator(); g.manual_seed(0)
