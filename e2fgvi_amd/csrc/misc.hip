@@ -433,7 +433,16 @@ __device__ __forceinline__ void fold_range(int Y, int L, int& l_lo, int& l_hi) {
     l_hi = min((Y + 3) / 3, L - 1);
 }
 
-template <bool NORMALISE, typename TE, typename TR, typename TD>
+// GELU, exact (erf) form of torch.nn.GELU (tfocal_transformer.py:82).  (Measured in round 2: Abramowitz-Stegun 7.1.26 on
+// the hardware exp2 / rcp instead of libm's erff made this kernel SLOWER, 92 -> 114 us per call at 720p -- most hidden
+// activations sit in erff's cheap polynomial branch.)
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// GELU_OUT (with NORMALISE): the FFN's GELU applied to the folded value.  The reference applies it AFTER the unfold
+// (tfocal_transformer.py:82,95-97), but the unfold is a pure gather with zero padding and GELU(0) = 0, so GELU commutes
+// with it -- and the folded tensor has 5.4x fewer elements than the unfolded one (erff on 127 M values per block at 720p was
+// the unfold kernel's bottleneck: 92 us against an HBM floor of 55).
+template <bool NORMALISE, typename TE, typename TR, typename TD, bool GELU_OUT = false>
 __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict__ bias_hwc,
                             const TR* __restrict__ residual, TD* __restrict__ dst, int F, int fh, int fw, int H,
                             int W, int C) {
@@ -469,6 +478,12 @@ __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict_
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[q] = acc[q] / cnt;
     }
+    if (GELU_OUT) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q][e] = gelu_exact(acc[q][e]);
+    }
     const long long o = ((f * H + Y) * W + X) * C + c4 * NV;
     if (bias_hwc) {
         f32x4 bq[Q];
@@ -485,12 +500,7 @@ __global__ void fold_kernel(const TE* __restrict__ emb, const float* __restrict_
     stv(dst + o, acc);
 }
 
-// GELU, exact (erf) form of torch.nn.GELU (tfocal_transformer.py:82).  (Measured in round 2: Abramowitz-Stegun 7.1.26 on
-// the hardware exp2 / rcp instead of libm's erff made this kernel SLOWER, 92 -> 114 us per call at 720p -- most hidden
-// activations sit in erff's cheap polynomial branch.)
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-
-template <typename T>
+template <typename T, bool GELU = true>
 __global__ void unfold_gelu_kernel(const T* __restrict__ folded, T* __restrict__ out, int F, int fh, int fw,
                                    int H, int W, int C) {
     constexpr int NV = VT<T>::N, Q = VT<T>::Q;
@@ -509,10 +519,12 @@ __global__ void unfold_gelu_kernel(const T* __restrict__ folded, T* __restrict__
     for (int q = 0; q < Q; ++q) v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (Y >= 0 && Y < H && X >= 0 && X < W) {
         ldv(folded + ((f * H + Y) * W + X) * C + c4 * NV, v);
+        if (GELU) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
+            for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[q][e] = gelu_exact(v[q][e]);
+                for (int e = 0; e < 4; ++e) v[q][e] = gelu_exact(v[q][e]);
+        }
     }
     stv(out + idx * NV, v);
 }
@@ -763,6 +775,39 @@ extern "C" int e2fgvi_ffn_unfold_gelu_x(const void* folded, void* out, int32_t d
 extern "C" int e2fgvi_ffn_unfold_gelu(const float* folded, float* out, int32_t F, int32_t fh, int32_t fw, int32_t H,
                                       int32_t W, int32_t C, void* stream) {
     return e2fgvi_ffn_unfold_gelu_x(folded, out, E2FGVI_F32, F, fh, fw, H, W, C, stream);
+}
+
+// The same pair with the GELU moved in front of the unfold (see fold_kernel): folded = GELU(fold(hid) / count), then a pure
+// gather.  fp32: bit-identical to ffn_fold + ffn_unfold_gelu; bf16: one rounding less (GELU sees the unrounded fold).
+extern "C" int e2fgvi_ffn_fold_gelu_x(const void* hid, void* folded, int32_t dtype, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                                      int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(hid && folded && E2_DT_OK(dtype), E2FGVI_EINVAL, "ffn_fold_gelu: bad arguments");
+    if (int rc = check_fold("ffn_fold_gelu", F, fh, fw, H, W, C)) return rc;
+    E2_REQUIRE(dtype == E2FGVI_F32 || C % 8 == 0, E2FGVI_EINVAL, "ffn_fold_gelu: bf16 needs C %% 8 == 0");
+    const long long total = (long long)F * H * W * (C / (dtype == E2FGVI_BF16 ? 8 : 4));
+    if (dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL((fold_kernel<true, __bf16, __bf16, __bf16, true>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const __bf16*)hid, (const float*)nullptr, (const __bf16*)nullptr, (__bf16*)folded, F, fh, fw, H, W, C);
+    else
+        hipLaunchKernelGGL((fold_kernel<true, float, float, float, true>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const float*)hid, (const float*)nullptr, (const float*)nullptr, (float*)folded, F, fh, fw, H, W, C);
+    E2_LAUNCH_CHECK("ffn_fold_gelu");
+    return 0;
+}
+extern "C" int e2fgvi_ffn_unfold_x(const void* folded, void* out, int32_t dtype, int32_t F, int32_t fh, int32_t fw, int32_t H,
+                                   int32_t W, int32_t C, void* stream) {
+    E2_REQUIRE(folded && out && E2_DT_OK(dtype), E2FGVI_EINVAL, "ffn_unfold: bad arguments");
+    if (int rc = check_fold("ffn_unfold", F, fh, fw, H, W, C)) return rc;
+    E2_REQUIRE(dtype == E2FGVI_F32 || C % 8 == 0, E2FGVI_EINVAL, "ffn_unfold: bf16 needs C %% 8 == 0");
+    const long long total = (long long)F * fh * fw * 49 * (C / (dtype == E2FGVI_BF16 ? 8 : 4));
+    if (dtype == E2FGVI_BF16)
+        hipLaunchKernelGGL((unfold_gelu_kernel<__bf16, false>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const __bf16*)folded, (__bf16*)out, F, fh, fw, H, W, C);
+    else
+        hipLaunchKernelGGL((unfold_gelu_kernel<float, false>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                           (const float*)folded, (float*)out, F, fh, fw, H, W, C);
+    E2_LAUNCH_CHECK("ffn_unfold");
+    return 0;
 }
 
 extern "C" int e2fgvi_softcomp_fold(const float* emb, const float* bias_hwc, const float* residual, float* dst, int32_t F,

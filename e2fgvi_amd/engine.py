@@ -357,8 +357,9 @@ class Engine(BF16Path):
         x1 = blk["proj"](att, residual=x)
         n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"])
         hid = blk["fc1"](n2)
-        folded = ops.ffn_fold(hid, b * t, fh, fw, H, W, 40)
-        unf = ops.ffn_unfold_gelu(folded, fh, fw, out=hid)
+        # GELU in front of the unfold (a gather with zero padding: GELU commutes with it, 5.4x fewer erf evaluations)
+        folded = ops.ffn_fold_gelu(hid, b * t, fh, fw, H, W, 40)
+        unf = ops.ffn_unfold(folded, fh, fw, out=hid)
         return blk["fc2"](unf, residual=x1), x1
 
     def compose(self, tokens, enc, b, t, fh, fw):

@@ -192,8 +192,9 @@ class BF16Path:
         x1 = xb["proj"](att, out_dtype=torch.float32, residual=x)
         n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"], out_dtype=BF16)
         hid = xb["fc1"](n2)
-        folded = ops.ffn_fold(hid, b * t, fh, fw, H, W, 40)
-        unf = ops.ffn_unfold_gelu(folded, fh, fw, out=hid)
+        # GELU in front of the unfold (a gather with zero padding: GELU commutes with it, 5.4x fewer erf evaluations)
+        folded = ops.ffn_fold_gelu(hid, b * t, fh, fw, H, W, 40)
+        unf = ops.ffn_unfold(folded, fh, fw, out=hid)
         copy = torch.empty((rows, 512), dtype=BF16, device=x.device) if want_bf16_copy else None
         return xb["fc2"](unf, out_dtype=torch.float32, residual=x1, out2=copy), x1, copy
 

@@ -116,6 +116,8 @@ SYMBOLS = {
     "e2fgvi_window_pool_x": (C.c_int, [_fp, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_ffn_fold_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_ffn_unfold_gelu_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_ffn_fold_gelu_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_ffn_unfold_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_softcomp_fold_bf16": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_cast": (C.c_int, [_fp, _i32, _fp, _i32, _i64, _fp]),
 }

@@ -882,6 +882,26 @@ def ffn_unfold_gelu(folded, fh, fw, out=None):
     return out
 
 
+def ffn_fold_gelu(hid, F_, fh, fw, H, W, Cc):
+    """GELU(fold(hid) / count): the FFN middle with the GELU in front of the (pure-gather) unfold -- see ffn_unfold"""
+    lib = _L.load()
+    _chk_any(hid, "hid")
+    out = torch.empty((F_, H, W, Cc), dtype=hid.dtype, device=hid.device)
+    _L.check(lib.e2fgvi_ffn_fold_gelu_x(_ptr(hid), _ptr(out), _dt(hid), F_, fh, fw, H, W, Cc, _stream()), "ffn_fold_gelu")
+    return out
+
+
+def ffn_unfold(folded, fh, fw, out=None):
+    lib = _L.load()
+    _chk_any(folded, "folded")
+    F_, H, W, Cc = folded.shape
+    if out is None:
+        out = torch.empty((F_ * fh * fw, 49 * Cc), dtype=folded.dtype, device=folded.device)
+    _chk(out, "out", folded.dtype)
+    _L.check(lib.e2fgvi_ffn_unfold_x(_ptr(folded), _ptr(out), _dt(folded), F_, fh, fw, H, W, Cc, _stream()), "ffn_unfold")
+    return out
+
+
 def softcomp_fold(emb, F_, fh, fw, H, W, Cc, bias_hwc=None, residual=None):
     lib = _L.load()
     if isinstance(emb, torch.Tensor) and emb.dtype == torch.bfloat16:     # bf16 data path: emb, residual, result bf16

@@ -204,6 +204,11 @@ def test_typed_helper_kernels(dev):
     assert f16.dtype == torch.bfloat16 and torch.equal(f16, f32.bfloat16())
     u16, u32 = ops.ffn_unfold_gelu(f16, fh, fw), ops.ffn_unfold_gelu(f16.float(), fh, fw)
     assert torch.equal(u16, u32.bfloat16())
+    # the engine's form (GELU in front of the unfold): the bf16 kernel == the fp32 kernel on the same operands, rounded once
+    g16, g32 = ops.ffn_fold_gelu(hid, BT, fh, fw, H, W, 40), ops.ffn_fold_gelu(hid.float(), BT, fh, fw, H, W, 40)
+    assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.bfloat16())
+    assert torch.equal(ops.ffn_unfold(g16, fh, fw), ops.ffn_unfold(g16.float(), fh, fw).bfloat16())
+    assert torch.equal(ops.ffn_unfold(g32, fh, fw), ops.ffn_unfold_gelu(f32, fh, fw))
     emb = torch.randn(BT * fh * fw, 49 * 128, generator=g).bfloat16().to(dev)
     res = torch.randn(BT, H, W, 128, generator=g).bfloat16().to(dev)
     bias = torch.randn(H, W, 128, generator=g).to(dev)

@@ -467,6 +467,9 @@ def test_fold_unfold(dev, H, W):
     unf = ops.ffn_unfold_gelu(folded, fh, fw)
     unf_ref_p = unf_ref.reshape(Fr, fh * fw, Cc, 49).permute(0, 1, 3, 2).reshape(Fr * fh * fw, 49 * Cc)
     assert_close(unf.cpu(), unf_ref_p, 1e-5, "ffn_unfold_gelu")
+    # the engine's form: GELU in front of the (pure-gather) unfold -- bit-identical in fp32
+    unf2 = ops.ffn_unfold(ops.ffn_fold_gelu(hid_p.to(dev), Fr, fh, fw, H, W, Cc), fh, fw)
+    assert torch.equal(unf2, unf), "GELU(fold) + unfold != fold + GELU(unfold)"
     C2 = 128
     emb = torch.randn(Fr, fh * fw, C2 * 49, generator=g)
     bias = torch.randn(C2, H, W, generator=g)
