@@ -48,8 +48,9 @@ struct ConvXParams {
     int dst2_ld, dst2_coff;
     int act;
     float slope;
-    int tp_cq;                            // tap-packed K-steps (narrow single-source layers): 16-byte chunks per tap (1, 2 or 4), 0 = off
+    int tp_cq;                            // tap-packed K-steps (narrow single-source layers): 16-byte chunks per tap (1..7), 0 = off
     unsigned tp_magic;                    //   ceil(2^32 / KW): tap -> kernel row by __umulhi
+    unsigned tp_magic_cq;                 //   ceil(2^32 / cq): chunk of the stream -> tap (unused for cq = 1)
     int dbg_noload;                       // tools only (tile codes 21 / 26): skip every DMA after the first stage -> the MFMA + LDS ceiling
 };
 
@@ -308,32 +309,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     }
     if constexpr (!S3 && !F32) {
         if (p.tp_cq) {
-            // Tap-packed K-steps: a source of <= 32 channels fills only 1 / 2 / 4 of the 8 chunks of a K-step, so a step
-            // carries 8 / 4 / 2 TAPS instead of one (SPyNet's 7x7 layers on 8-64 channels, the encoder's first layer: 49 -> 7 /
-            // 13 / 25 steps).  Logical chunk c of a step = tap TP * step + c / cq, channel chunk c % cq; the lanes of a row then
-            // fetch from different taps, so the byte offsets are formed per step (a dozen VALU per item -- cheap against the
-            // steps it removes).
-            const int cq = p.tp_cq, TP = 8 / cq, KK = p.KH * p.KW;
-            int t_j[A_IT];
-            unsigned t_cb[A_IT];
-            bool t_ok[A_IT];
+            // Tap-packed K-steps: a source of fewer than 64 channels fills only cq = cpg / 8 of the 8 chunks of a K-step, so the
+            // (tap, channel chunk) pairs are laid out as ONE stream of chunks, tap-major, cut into K-steps of 8 -- a step then
+            // carries 8 / cq taps (8 channels: 8 taps, 16: 4, 32: 2, 40: 1.6) instead of one zero-padded tap: SPyNet's 7x7 layers
+            // on 8 / 16 / 32 channels (49 -> 7 / 13 / 25 steps), the encoder's first layer, the FFN's second Linear read as the 7x7
+            // stride-3 convolution it is over the 40-channel folded tensor (49 -> 31 steps).  Chunk L = 8 step + c of the stream =
+            // tap L / cq, channel chunk L % cq; the lanes of a row then fetch from different taps, so the byte offsets are formed
+            // per step (a dozen VALU per item -- cheap against the steps it removes).
+            const int cq = p.tp_cq, KK = p.KH * p.KW;
+            int t_c[A_IT];
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) {
-                const int c = (int)(a_ch16[it] >> 4);
-                const int cc = c % cq;
-                t_j[it] = c / cq;
-                t_cb[it] = sc0 + (unsigned)cc * 16u;
-                t_ok[it] = cc * 8 < sg0;
-            }
+            for (int it = 0; it < A_IT; ++it) t_c[it] = (int)(a_ch16[it] >> 4);
             const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(sp0, sb0);
             auto issue_a_packed = [&](int stage, int step) {
                 unsigned char* sa = smem + stage * A_BYTES + wave * 1024;
 #pragma unroll
                 for (int it = 0; it < A_IT; ++it) {
-                    const int tap = TP * step + t_j[it];
+                    const int L = 8 * step + t_c[it];
+                    const int tap = cq == 1 ? L : (int)__umulhi((unsigned)L, p.tp_magic_cq);
+                    const int cc = L - tap * cq;
                     const int tky = (int)__umulhi((unsigned)tap, p.tp_magic), tkx = tap - tky * p.KW;
-                    const bool ok = t_ok[it] && tap < KK && ((a_msk[it] >> tky) & (a_msk[it] >> (8 + tkx)) & 1u) != 0;
-                    const unsigned off = ok ? (unsigned)(a_pix[it] + tky * p.W + tkx) * sl0 + t_cb[it] : OOB;
+                    const bool ok = tap < KK && ((a_msk[it] >> tky) & (a_msk[it] >> (8 + tkx)) & 1u) != 0;
+                    const unsigned off = ok ? (unsigned)(a_pix[it] + tky * p.W + tkx) * sl0 + sc0 + (unsigned)cc * 16u : OOB;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_void*)(sa + it * NT * 16), 16, off, 0, 0, 0);
                 }
             };
@@ -620,9 +617,10 @@ __global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __rest
     rem /= p.Npad;
     const int koct = (int)(rem & 7);
     const int step = (int)(rem >> 3);
-    if (p.tp_cq) {                        // tap-packed: chunk koct of a step = tap TP * step + koct / cq, channels (koct % cq) * 8 ...
-        const int tapk = (8 / p.tp_cq) * step + koct / p.tp_cq;
-        const int chk = (koct % p.tp_cq) * 8 + e;
+    if (p.tp_cq) {                        // tap-packed: chunk L = 8 step + koct of the stream = tap L / cq, channels (L % cq) * 8 ...
+        const int L = 8 * step + koct;
+        const int tapk = L / p.tp_cq;
+        const int chk = (L - tapk * p.tp_cq) * 8 + e;
         float vk = 0.f;
         if (tapk < p.KH * p.KW && chk < p.cpg[0] && n < p.Cout_g)
             vk = w[((long long)n * p.Cin_g + chk) * (p.KH * p.KW) + tapk];
@@ -707,10 +705,9 @@ extern "C" int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int3
 // tap-packed variant of the bf16 packing: one source of <= 32 channels (multiple of 8), no groups, more than one tap
 static bool geometry_taps(int Cout, int KH, int KW, int cin, PackX* q) {
     const int32_t cpg[1] = {cin};
-    if (cin > 32 || KW < 2 || !geometry_x(Cout, 1, KH, KW, 1, cpg, q, false)) return false;
-    q->tp_cq = cin <= 8 ? 1 : (cin <= 16 ? 2 : 4);
-    const int TP = 8 / q->tp_cq;
-    const int steps = cdiv(KH * KW, TP);
+    if (cin > 56 || KW < 2 || !geometry_x(Cout, 1, KH, KW, 1, cpg, q, false)) return false;
+    q->tp_cq = cin / 8;
+    const int steps = cdiv(KH * KW * q->tp_cq, 8);
     q->wgroup_elems = (long long)steps * 64 * q->Npad;
     q->total = q->wgroup_elems;
     return true;
@@ -719,7 +716,7 @@ static bool geometry_taps(int Cout, int KH, int KW, int cin, PackX* q) {
 extern "C" int64_t e2fgvi_packed_conv_weight_bf16x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin) {
     PackX q;
     if (!geometry_taps(Cout, KH, KW, cin, &q)) {
-        e2fgvi_set_error("packed_conv_weight_bf16x_taps_size: one source of 8 / 16 / 24 / 32 channels, more than one tap");
+        e2fgvi_set_error("packed_conv_weight_bf16x_taps_size: one source of 8 ... 56 channels (multiple of 8), KW >= 2");
         return E2FGVI_EINVAL;
     }
     return q.total;
@@ -782,16 +779,17 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
     p.M = d->N * d->Ho * d->Wo;
     p.nsteps = d->KH * d->KW * q.steps_per_tap;
-    p.tp_cq = 0; p.tp_magic = 0;
+    p.tp_cq = 0; p.tp_magic = 0; p.tp_magic_cq = 0;
     if (d->tap_packed) {
         PackX qt;
         E2_REQUIRE(!f32 && d->nsrc == 1 && d->groups == 1 && geometry_taps(d->Cout, d->KH, d->KW, d->src_cpg[0], &qt), E2FGVI_EINVAL,
-                   "conv2d_bf16x: tap-packed weights are for one bf16 source of <= 32 channels, no groups, more than one tap");
+                   "conv2d_bf16x: tap-packed weights are for one bf16 source of <= 56 channels, no groups, KW >= 2");
         E2_REQUIRE(d->tile < 10 || d->tile > 20, E2FGVI_EUNSUP, "conv2d_bf16x: the row-shift tiles do not take tap-packed weights");
         q.wgroup_elems = qt.wgroup_elems;
         p.tp_cq = qt.tp_cq;
         p.tp_magic = 0xFFFFFFFFu / (unsigned)d->KW + 1u;
-        p.nsteps = cdiv(d->KH * d->KW, 8 / qt.tp_cq);
+        p.tp_magic_cq = qt.tp_cq > 1 ? 0xFFFFFFFFu / (unsigned)qt.tp_cq + 1u : 0u;
+        p.nsteps = cdiv(d->KH * d->KW * qt.tp_cq, 8);
     }
     p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * esz);
     p.w = d->wpacked; p.bias = d->bias;

@@ -12,12 +12,15 @@ bytes live and which pipe multiplies them:
   * LayerNorm, window pooling, fold / unfold + GELU, SoftComp fold and the x2 upsamples read / write bf16 and compute
     in fp32 (typed variants of the fp32 kernels, csrc/misc.hip).
 """
+import os
+
 import torch
 
 from . import ops
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_TANH, PackedConvX, PackedLinearX
 
 BF16 = torch.bfloat16
+FC2_CONV = os.environ.get("E2FGVI_FC2_CONV", "1") != "0"     # FFN second Linear as a conv of the folded tensor
 
 
 class BF16Path:
@@ -88,6 +91,11 @@ class BF16Path:
             blk = dict(qkv=PackedLinearX(f(p + "attn.qkv.weight"), f(p + "attn.qkv.bias")),
                        proj=PackedLinearX(f(p + "attn.proj.weight"), f(p + "attn.proj.bias")),
                        fc1=PackedLinearX(w1, b1), fc2=PackedLinearX(w2, f(p + "mlp.conv2.1.bias")))
+            if FC2_CONV:
+                # Linear(1960 -> 512) of the unfolded 7x7 patches == the 7x7 / stride 3 / pad 3 convolution of the folded
+                # [F, H, W, 40] tensor (tfocal_transformer.py:81,95-97): no unfold kernel, no [rows, 1960] tensor
+                blk["fc2"] = PackedConvX(f(p + "mlp.conv2.1.weight").view(512, 40, 7, 7), f(p + "mlp.conv2.1.bias"), [40],
+                                         stride=3, pad=3)
             for k in ("qkv", "proj", "fc1", "fc2"):
                 blk[k].name = "transformer.%d.%s" % (i, k)
             self.xblocks.append(blk)
@@ -194,8 +202,13 @@ class BF16Path:
         hid = xb["fc1"](n2)
         # GELU in front of the unfold (a gather with zero padding: GELU commutes with it, 5.4x fewer erf evaluations)
         folded = ops.ffn_fold_gelu(hid, b * t, fh, fw, H, W, 40)
-        unf = ops.ffn_unfold(folded, fh, fw, out=hid)
         copy = torch.empty((rows, 512), dtype=BF16, device=x.device) if want_bf16_copy else None
+        if FC2_CONV:
+            y = torch.empty((rows, 512), dtype=torch.float32, device=x.device)
+            xb["fc2"]([folded], out=y.view(b * t, fh, fw, 512), residual=x1.view(b * t, fh, fw, 512),
+                      out2=None if copy is None else copy.view(b * t, fh, fw, 512))
+            return y, x1, copy
+        unf = ops.ffn_unfold(folded, fh, fw, out=hid)
         return xb["fc2"](unf, out_dtype=torch.float32, residual=x1, out2=copy), x1, copy
 
     def compose_x(self, tok16, enc, b, t, fh, fw):

@@ -406,7 +406,7 @@ class PackedConvX:
         self.tune = False          # time XTUNE_CANDIDATES on the first call of every new size class and keep the fastest
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         # narrow single-source layers (SPyNet's 7x7 stacks, the encoder's first layer): K-steps that carry several taps
-        self.taps = (not self.f32 and len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 32 and self.KW > 1
+        self.taps = (not self.f32 and len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 56 and self.KW > 1
                      and taps is not False and os.environ.get("E2FGVI_TAPS", "1") != "0")
         if self.taps:
             n = lib.e2fgvi_packed_conv_weight_bf16x_taps_size(self.Cout, self.KH, self.KW, self.cpg[0])
@@ -506,8 +506,7 @@ class PackedConvX:
             kc = 32 if self.f32 else 64
             cin_p = sum(-(-c // kc) * kc for c in self.cpg)
             if self.taps:                                   # K-steps of several taps: issued K = steps * 64
-                tp = 8 // (1 if self.cpg[0] <= 8 else 2 if self.cpg[0] <= 16 else 4)
-                cin_p = -(-K2 // tp) * 64 / K2
+                cin_p = -(-K2 * (self.cpg[0] // 8) // 8) * 64 / K2
             _L.annotate(layer=self.name, kernel="conv_%s tile=%d%s" % ("f32x" if self.f32 else "bf16x", tile, " taps" if self.taps else ""),
                         shape="N%d %dx%d %d->%d k%d s%d g%d" % (N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
                         macs=N * Ho * Wo * self.Cout * cin_g * K2,

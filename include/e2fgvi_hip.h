@@ -324,9 +324,10 @@ int64_t e2fgvi_packed_conv_weight_bf16x_size(int32_t Cout, int32_t groups, int32
 int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
                                   int32_t nsrc, const int32_t* src_cpg, void* stream);
 
-/* Tap-packed weights for narrow layers (ONE bf16 source of <= 32 channels, no groups, KH*KW > 1: SPyNet's 7x7 stacks
- * model/modules/flow_comp.py:180-215 and the encoder's first layer e2fgvi.py:76): a K-step of 64 carries 8 / 4 / 2 taps of
- * 8 / 16 / 32 channels instead of one padded tap -- 49 taps in 7 / 13 / 25 steps.  Set tap_packed = 1 in the descriptor;
+/* Tap-packed weights for narrow layers (ONE bf16 source of 8 ... 56 channels, no groups, KW >= 2: SPyNet's 7x7 stacks
+ * model/modules/flow_comp.py:180-215, the encoder's first layer e2fgvi.py:76, the FFN's second Linear read as a 7x7 stride-3
+ * convolution of the folded tensor tfocal_transformer.py:81,95-97): the (tap, 8-channel chunk) pairs form one stream cut into
+ * K-steps of 8 chunks -- 49 taps of 8 / 16 / 32 / 40 channels in 7 / 13 / 25 / 31 steps instead of 49 zero-padded ones.  Set tap_packed = 1 in the descriptor;
  * the row-shift tile codes do not apply. */
 int64_t e2fgvi_packed_conv_weight_bf16x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin);
 int e2fgvi_pack_conv_weight_bf16x_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,

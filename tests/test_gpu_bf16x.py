@@ -52,7 +52,9 @@ CASES = [
     ("7x7 8 -> 32 (spynet .0): 8 taps per K-step", 2, 20, 28, [8], 1, 32, 7, 1, 3, (0, 1, 3, 5)),
     ("7x7 16 -> 2 (spynet .4): 4 taps per K-step", 2, 20, 28, [16], 1, 2, 7, 1, 3, (0, 3)),
     ("7x7 32 -> 64 (spynet .1): 2 taps per K-step", 1, 20, 28, [32], 1, 64, 7, 1, 3, (0, 1, 2, 4)),
-    ("3x3 24 -> 40: 24 of 32 channels, 2 taps per K-step", 2, 11, 13, [24], 1, 40, 3, 1, 1, (0, 2, 5)),
+    ("3x3 24 -> 40: 3 chunks per tap", 2, 11, 13, [24], 1, 40, 3, 1, 1, (0, 2, 5)),
+    ("7x7 stride 3 pad 3, 40 -> 512 (FFN fc2 as a conv): 5 chunks per tap", 2, 30, 54, [40], 1, 512, 7, 3, 3, (0, 1, 7)),
+    ("3x3 56 -> 64: 7 chunks per tap", 1, 12, 14, [56], 1, 64, 3, 1, 1, (0, 2)),
     ("5x5 stride 2 pad 2, 16 -> 32: 4 taps per K-step", 2, 17, 22, [16], 1, 32, 5, 2, 2, (0, 5)),
 ]
 
