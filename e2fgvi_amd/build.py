@@ -18,7 +18,7 @@ NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # their normal build (6-8 % on the MFMA kernels' transforms / epilogues, profiles/r02_c2_*) and get a second, packed-free
 # build for the side-stream launches (SPyNet).
 UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
-         ("conv_bf16.hip", "conv_bf16.o", []), ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino4.hip", "conv_wino4.o", []),
+         ("conv_bf16.hip", "conv_bf16.o", []), ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", []),
          ("mdcn.hip", "mdcn.o", []), ("attention.hip", "attention.o", []),
          ("attention_bf16.hip", "attention_bf16.o", []), ("misc.hip", "misc.o", NOPK),
          ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]

@@ -24,6 +24,7 @@ from . import ops
 from .engine_x import BF16Path
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedDcn, PackedLinear
 
+TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
 WIN = (5, 9)
 
 
@@ -105,7 +106,8 @@ class Engine(BF16Path):
         self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1, **ww),
                     PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1, **ww),
                     PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1, **ww),
-                    PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
+                    (ops.PackedTailConv(f("decoder.6.weight"), f("decoder.6.bias")) if TAIL_KERNEL else
+                     PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1))]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)
         # (Measured and rejected in round 2: splitting conv_offset.0 / backbone.0 into a batched non-recurrent half for all

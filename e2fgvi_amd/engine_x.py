@@ -20,6 +20,7 @@ from . import ops
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_TANH, PackedConvX, PackedLinearX
 
 BF16 = torch.bfloat16
+TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
 FC2_CONV = os.environ.get("E2FGVI_FC2_CONV", "1") != "0"     # FFN second Linear as a conv of the folded tensor
 
 
@@ -41,7 +42,8 @@ class BF16Path:
         self.xdec = [PackedConvX(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1),
                      PackedConvX(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1),
                      PackedConvX(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1),
-                     PackedConvX(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1)]
+                     (ops.PackedTailConv(f("decoder.6.weight"), f("decoder.6.bias"), dtype=BF16) if TAIL_KERNEL else
+                      PackedConvX(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1))]
         for k, n in enumerate(("decoder.0.conv", "decoder.2", "decoder.4.conv", "decoder.6")):
             self.xdec[k].name = n
         self.xprop = {}

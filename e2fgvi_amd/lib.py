@@ -84,6 +84,9 @@ SYMBOLS = {
     "e2fgvi_packed_winograd4_weight_size": (_i64, [_i32, _i32, _i32, C.POINTER(_i32), _i32]),
     "e2fgvi_pack_winograd4_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.POINTER(_i32), _i32, _fp]),
     "e2fgvi_conv3x3_winograd4": (C.c_int, [C.POINTER(ConvDesc), _i32, _fp]),
+    "e2fgvi_packed_tail_weight_size": (_i64, [_i32, _i32]),
+    "e2fgvi_pack_tail_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp]),
+    "e2fgvi_conv3x3_tail": (C.c_int, [_fp, _i32, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, C.c_float, _fp]),
     "e2fgvi_mdcn_nhwc": (C.c_int, [C.POINTER(MdcnDesc), _fp]),
     "e2fgvi_packed_dcn_weight_size": (_i64, [_i32, _i32, _i32, _i32]),
     "e2fgvi_pack_dcn_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),

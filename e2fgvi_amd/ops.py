@@ -578,6 +578,47 @@ class PackedLinear(PackedConv):
         return out
 
 
+class PackedTailConv:
+    """The decoder's last layer, Conv2d(64, 3, 3, padding=1) + activation -> fp32 NCHW frames (csrc/conv_tail.hip): the nine
+    taps on the N side of one [pixels x 64] x [64 x 27] GEMM, shifted sum in LDS.  dtype = the source's (fp32 / bf16)."""
+
+    def __init__(self, weight, bias, dtype=torch.float32):
+        lib = _L.load()
+        w = _chk(weight.detach().float().contiguous(), "weight")
+        self.Cout, self.Cin, self.KH, self.KW = w.shape
+        if (self.KH, self.KW) != (3, 3):
+            raise ValueError("PackedTailConv: 3x3 kernels only")
+        n = lib.e2fgvi_packed_tail_weight_size(self.Cout, self.Cin)
+        if n < 0:
+            _L.check(int(n), "packed_tail_weight_size")
+        self.dtype = dtype
+        self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
+        _L.check(lib.e2fgvi_pack_tail_weight(_ptr(w), _ptr(self.wpacked), self.Cout, self.Cin, _dt(self.wpacked), _stream()),
+                 "pack_tail_weight")
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        self.name = "conv_tail"
+
+    def __call__(self, sources, out=None, act=ACT_NONE, slope=0.0, out_nchw=True, tile=0):
+        """call-compatible with PackedConv / PackedConvX for one NHWC source and an NCHW fp32 result"""
+        x = sources[0] if isinstance(sources, (list, tuple)) else sources
+        if not out_nchw:
+            raise ValueError("PackedTailConv writes NCHW frames")
+        _chk(x, "x", self.dtype)
+        N, H, W, ld = x.shape
+        if out is None:
+            out = torch.empty((N, self.Cout, H, W), dtype=torch.float32, device=x.device)
+        _chk(out, "out")
+        if tuple(out.shape) != (N, self.Cout, H, W):
+            raise ValueError("out shape %s != %s" % (tuple(out.shape), (N, self.Cout, H, W)))
+        macs = N * H * W * self.Cout * self.Cin * 9
+        tiles = N * -(-H // 16) * -(-W // 32)
+        _L.annotate(layer=self.name, kernel="conv_tail", shape="N%d %dx%d %d->%d k3 s1 g1" % (N, H, W, self.Cin, self.Cout),
+                    macs=macs, issued=tiles * 640 * 64 * 32)
+        _L.check(_L.load().e2fgvi_conv3x3_tail(_ptr(x), _dt(x), ld, _ptr(self.wpacked), _ptr(self.bias), _ptr(out), N, H, W, act,
+                                               float(slope), _stream()), "conv3x3_tail")
+        return out
+
+
 # ------------------------------------------------------------------------------------------ deformable conv
 class PackedDcn:
     def __init__(self, weight, bias, deform_groups, stride=1, pad=0, dil=1, mfma="fp32"):

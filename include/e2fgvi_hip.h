@@ -159,6 +159,18 @@ int e2fgvi_pack_winograd4_weight(const float* w, float* wpacked, int32_t Cout, i
                                  const int32_t* src_cpg, int32_t fy, void* stream);
 int e2fgvi_conv3x3_winograd4(const e2fgvi_conv_desc* d, int32_t fy, void* stream);
 
+/* The decoder's last layer (csrc/conv_tail.hip): nn.Conv2d(64, 3, kernel_size=3, stride=1, padding=1) + torch.tanh
+ * (model/e2fgvi.py:99-103,261 / model/e2fgvi_hq.py:99-103,263).  With 3 output channels the nine taps move to the N side of
+ * ONE [pixels x 64] x [64 x 27] GEMM (every input pixel read once, 9x fewer matrix instructions than the implicit GEMM),
+ * followed by the shifted 9-term sum in LDS.  src: NHWC [N,H,W,src_ld >= 64] of src_dtype (E2FGVI_F32: exact fp32 MFMA;
+ * E2FGVI_BF16: bf16 MFMA, fp32 accumulation), 16-byte aligned rows; wpacked: 64 x 32 elements of src_dtype from
+ * e2fgvi_pack_tail_weight (w: fp32 OIHW [3,64,3,3]); bias fp32 [3] or NULL; dst fp32 NCHW [N,3,H,W]; act: E2FGVI_ACT_*.
+ * Only Cin = 64, Cout = 3 is built (E2FGVI_EUNSUP otherwise). */
+int64_t e2fgvi_packed_tail_weight_size(int32_t Cout, int32_t Cin);
+int e2fgvi_pack_tail_weight(const float* w, void* wpacked, int32_t Cout, int32_t Cin, int32_t dtype, void* stream);
+int e2fgvi_conv3x3_tail(const void* src, int32_t src_dtype, int32_t src_ld, const void* wpacked, const float* bias, float* dst,
+                        int32_t N, int32_t H, int32_t W, int32_t act, float slope, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Modulated deformable convolution (DCNv2), im2col-free: bilinear gather straight into LDS + MFMA.
  * Replaces mmcv.ops.modulated_deform_conv2d (mmcv-full 1.4.8) called at
