@@ -300,16 +300,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             }
         }
     };
-    const bool tap_packed = !S3 && !F32 && p.tp_cq != 0;          // its first A stage is issued by the packed branch below
+    const bool tap_packed = !S3 && p.tp_cq != 0;          // its first A stage is issued by the packed branch below
     if (!tap_packed) issue_a(0);
     issue_b(0, 0);
     if (!tap_packed) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if constexpr (!S3 && !F32) {
+    if constexpr (!S3) {
         if (p.tp_cq) {
-            // Tap-packed K-steps: a source of fewer than 64 channels fills only cq = cpg / 8 of the 8 chunks of a K-step, so the
+            // Tap-packed K-steps: a source of fewer than 64 channels (bf16; fp32: 32 channels per step, 4 per chunk -- the same
+            // bytes) fills only cq = cpg / 8 of the 8 chunks of a K-step, so the
             // (tap, channel chunk) pairs are laid out as ONE stream of chunks, tap-major, cut into K-steps of 8 -- a step then
             // carries 8 / cq taps (8 channels: 8 taps, 16: 4, 32: 2, 40: 1.6) instead of one zero-padded tap: SPyNet's 7x7 layers
             // on 8 / 16 / 32 channels (49 -> 7 / 13 / 25 steps), the encoder's first layer, the FFN's second Linear read as the 7x7
@@ -620,7 +621,7 @@ __global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __rest
     if (p.tp_cq) {                        // tap-packed: chunk L = 8 step + koct of the stream = tap L / cq, channels (L % cq) * 8 ...
         const int L = 8 * step + koct;
         const int tapk = L / p.tp_cq;
-        const int chk = (L - tapk * p.tp_cq) * 8 + e;
+        const int chk = (L - tapk * p.tp_cq) * p.ch + e;
         float vk = 0.f;
         if (tapk < p.KH * p.KW && chk < p.cpg[0] && n < p.Cout_g)
             vk = w[((long long)n * p.Cin_g + chk) * (p.KH * p.KW) + tapk];
@@ -702,13 +703,13 @@ extern "C" int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int3
     return 0;
 }
 
-// tap-packed variant of the bf16 packing: one source of <= 32 channels (multiple of 8), no groups, more than one tap
-static bool geometry_taps(int Cout, int KH, int KW, int cin, PackX* q) {
+// tap-packed variant of the packing: one source of fewer channels than two K-steps (a multiple of the chunk), no groups, KW >= 2
+static bool geometry_taps(int Cout, int KH, int KW, int cin, PackX* q, bool f32 = false) {
     const int32_t cpg[1] = {cin};
-    if (cin > 56 || KW < 2 || !geometry_x(Cout, 1, KH, KW, 1, cpg, q, false)) return false;
-    q->tp_cq = cin / 8;
+    if (cin > 56 || KW < 2 || !geometry_x(Cout, 1, KH, KW, 1, cpg, q, f32)) return false;
+    q->tp_cq = cin / q->ch;
     const int steps = cdiv(KH * KW * q->tp_cq, 8);
-    q->wgroup_elems = (long long)steps * 64 * q->Npad;
+    q->wgroup_elems = (long long)steps * q->kc * q->Npad;
     q->total = q->wgroup_elems;
     return true;
 }
@@ -730,6 +731,26 @@ extern "C" int e2fgvi_pack_conv_weight_bf16x_taps(const float* w, void* wpacked,
     hipLaunchKernelGGL(pack_conv_weight_x_kernel<__bf16>, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
                        w, (__bf16*)wpacked, q);
     E2_LAUNCH_CHECK("pack_conv_weight_bf16x_taps");
+    return 0;
+}
+
+extern "C" int64_t e2fgvi_packed_conv_weight_f32x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin) {
+    PackX q;
+    if (!geometry_taps(Cout, KH, KW, cin, &q, true)) {
+        e2fgvi_set_error("packed_conv_weight_f32x_taps_size: one source of 4 ... 56 channels (multiple of 4), KW >= 2");
+        return E2FGVI_EINVAL;
+    }
+    return q.total;
+}
+
+extern "C" int e2fgvi_pack_conv_weight_f32x_taps(const float* w, float* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
+                                                 void* stream) {
+    PackX q;
+    E2_REQUIRE(w && wpacked, E2FGVI_EINVAL, "pack_conv_weight_f32x_taps: null pointer");
+    E2_REQUIRE(geometry_taps(Cout, KH, KW, cin, &q, true), E2FGVI_EINVAL, "pack_conv_weight_f32x_taps: bad geometry");
+    hipLaunchKernelGGL(pack_conv_weight_x_kernel<float>, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, wpacked, q);
+    E2_LAUNCH_CHECK("pack_conv_weight_f32x_taps");
     return 0;
 }
 
@@ -782,8 +803,8 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     p.tp_cq = 0; p.tp_magic = 0; p.tp_magic_cq = 0;
     if (d->tap_packed) {
         PackX qt;
-        E2_REQUIRE(!f32 && d->nsrc == 1 && d->groups == 1 && geometry_taps(d->Cout, d->KH, d->KW, d->src_cpg[0], &qt), E2FGVI_EINVAL,
-                   "conv2d_bf16x: tap-packed weights are for one bf16 source of <= 56 channels, no groups, KW >= 2");
+        E2_REQUIRE(d->nsrc == 1 && d->groups == 1 && geometry_taps(d->Cout, d->KH, d->KW, d->src_cpg[0], &qt, f32), E2FGVI_EINVAL,
+                   "conv2d_bf16x: tap-packed weights are for one source of <= 56 channels, no groups, KW >= 2");
         E2_REQUIRE(d->tile < 10 || d->tile > 20, E2FGVI_EUNSUP, "conv2d_bf16x: the row-shift tiles do not take tap-packed weights");
         q.wgroup_elems = qt.wgroup_elems;
         p.tp_cq = qt.tp_cq;

@@ -22,9 +22,12 @@ import torch
 
 from . import ops
 from .engine_x import BF16Path
-from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedDcn, PackedLinear
+from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedConvX, PackedDcn, PackedLinear
 
 TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
+# fp32 path: the FFN's second Linear as a conv of the folded tensor (as the bf16 path runs it).  Measured neutral in fp32
+# (15.785 vs 15.775 ms, profiles/r02_fc2_conv.txt: the 16-byte tap-packed fetches cost what the unfold kernel saved) -> off
+FC2_CONV = os.environ.get("E2FGVI_FC2_CONV_FP32", "0") != "0"
 WIN = (5, 9)
 
 
@@ -155,7 +158,12 @@ class Engine(BF16Path):
                 n1w=f(p + "norm1.weight"), n1b=f(p + "norm1.bias"), n2w=f(p + "norm2.weight"), n2b=f(p + "norm2.bias"),
                 qkv=PackedLinear(f(p + "attn.qkv.weight"), f(p + "attn.qkv.bias"), **pw),
                 proj=PackedLinear(f(p + "attn.proj.weight"), f(p + "attn.proj.bias"), **pw),
-                fc1=PackedLinear(w1, b1, **pw), fc2=PackedLinear(w2, f(p + "mlp.conv2.1.bias"), **pw),
+                fc1=PackedLinear(w1, b1, **pw),
+                # fc2: Linear(1960 -> 512) of the unfolded 7x7 patches == the 7x7 / stride 3 / pad 3 convolution of the folded
+                # [F, H, W, 40] tensor (tfocal_transformer.py:81,95-97): no unfold kernel, no [rows, 1960] tensor
+                fc2=(PackedConvX(f(p + "mlp.conv2.1.weight").view(512, 40, 7, 7), f(p + "mlp.conv2.1.bias"), [40], stride=3,
+                                 pad=3, dtype=torch.float32, taps=True) if FC2_CONV and precision == "fp32" else
+                     PackedLinear(w2, f(p + "mlp.conv2.1.bias"), **pw)),
                 valid=sd[p + "attn.valid_ind_rolled"].cpu().tolist()))
 
         # ---- SPyNet (flow_comp.py:49-82,172-215)
@@ -361,6 +369,10 @@ class Engine(BF16Path):
         hid = blk["fc1"](n2)
         # GELU in front of the unfold (a gather with zero padding: GELU commutes with it, 5.4x fewer erf evaluations)
         folded = ops.ffn_fold_gelu(hid, b * t, fh, fw, H, W, 40)
+        if isinstance(blk["fc2"], PackedConvX):
+            y = torch.empty((x1.shape[0], 512), dtype=torch.float32, device=x1.device)
+            blk["fc2"]([folded], out=y.view(b * t, fh, fw, 512), residual=x1.view(b * t, fh, fw, 512))
+            return y, x1
         unf = ops.ffn_unfold(folded, fh, fw, out=hid)
         return blk["fc2"](unf, residual=x1), x1
 

@@ -75,6 +75,8 @@ SYMBOLS = {
     "e2fgvi_pack_conv_weight_bf16x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_packed_conv_weight_bf16x_taps_size": (_i64, [_i32, _i32, _i32, _i32]),
     "e2fgvi_pack_conv_weight_bf16x_taps": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_packed_conv_weight_f32x_taps_size": (_i64, [_i32, _i32, _i32, _i32]),
+    "e2fgvi_pack_conv_weight_f32x_taps": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_conv2d_f32x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
     "e2fgvi_packed_conv_weight_f32x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_f32x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),

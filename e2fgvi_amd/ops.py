@@ -406,15 +406,18 @@ class PackedConvX:
         self.tune = False          # time XTUNE_CANDIDATES on the first call of every new size class and keep the fastest
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         # narrow single-source layers (SPyNet's 7x7 stacks, the encoder's first layer): K-steps that carry several taps
-        self.taps = (not self.f32 and len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 56 and self.KW > 1
-                     and taps is not False and os.environ.get("E2FGVI_TAPS", "1") != "0")
+        # (fp32 operands: only on request -- the one fp32 user is the FFN's second Linear as a conv, engine.py)
+        self.taps = (len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 56 and self.KW > 1
+                     and (taps is True if self.f32 else taps is not False) and os.environ.get("E2FGVI_TAPS", "1") != "0")
         if self.taps:
-            n = lib.e2fgvi_packed_conv_weight_bf16x_taps_size(self.Cout, self.KH, self.KW, self.cpg[0])
+            size_fn = lib.e2fgvi_packed_conv_weight_f32x_taps_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_taps_size
+            pack_fn = lib.e2fgvi_pack_conv_weight_f32x_taps if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x_taps
+            n = size_fn(self.Cout, self.KH, self.KW, self.cpg[0])
             if n < 0:
-                _L.check(int(n), "packed_conv_weight_bf16x_taps_size")
+                _L.check(int(n), "packed_conv_weight_x_taps_size")
             self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
-            _L.check(lib.e2fgvi_pack_conv_weight_bf16x_taps(_ptr(w), _ptr(self.wpacked), self.Cout, self.KH, self.KW, self.cpg[0],
-                                                            _stream()), "pack_conv_weight_bf16x_taps")
+            _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, self.KH, self.KW, self.cpg[0], _stream()),
+                     "pack_conv_weight_x_taps")
         else:
             size_fn = lib.e2fgvi_packed_conv_weight_f32x_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size
             pack_fn = lib.e2fgvi_pack_conv_weight_f32x if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x
@@ -494,7 +497,7 @@ class PackedConvX:
         d.tile = tile
         if tile == 0 and self.tune and N * Ho * Wo >= 2048:
             key = ("x32" if self.f32 else "x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
-                   int(4.0 * math.log2(N * Ho * Wo)), _dt(out), out_nchw)
+                   int(4.0 * math.log2(N * Ho * Wo)), _dt(out), out_nchw, self.taps)
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
@@ -506,7 +509,7 @@ class PackedConvX:
             kc = 32 if self.f32 else 64
             cin_p = sum(-(-c // kc) * kc for c in self.cpg)
             if self.taps:                                   # K-steps of several taps: issued K = steps * 64
-                cin_p = -(-K2 * (self.cpg[0] // 8) // 8) * 64 / K2
+                cin_p = -(-K2 * (self.cpg[0] // (4 if self.f32 else 8)) // 8) * kc / K2
             _L.annotate(layer=self.name, kernel="conv_%s tile=%d%s" % ("f32x" if self.f32 else "bf16x", tile, " taps" if self.taps else ""),
                         shape="N%d %dx%d %d->%d k%d s%d g%d" % (N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
                         macs=N * Ho * Wo * self.Cout * cin_g * K2,

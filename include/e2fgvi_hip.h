@@ -339,11 +339,16 @@ int e2fgvi_pack_conv_weight_bf16x(const float* w, void* wpacked, int32_t Cout, i
 /* Tap-packed weights for narrow layers (ONE bf16 source of 8 ... 56 channels, no groups, KW >= 2: SPyNet's 7x7 stacks
  * model/modules/flow_comp.py:180-215, the encoder's first layer e2fgvi.py:76, the FFN's second Linear read as a 7x7 stride-3
  * convolution of the folded tensor tfocal_transformer.py:81,95-97): the (tap, 8-channel chunk) pairs form one stream cut into
- * K-steps of 8 chunks -- 49 taps of 8 / 16 / 32 / 40 channels in 7 / 13 / 25 / 31 steps instead of 49 zero-padded ones.  Set tap_packed = 1 in the descriptor;
- * the row-shift tile codes do not apply. */
+ * K-steps of 8 chunks -- 49 taps of 8 / 16 / 32 / 40 channels in 7 / 13 / 25 / 31 steps instead of 49 zero-padded ones.
+ * Set tap_packed = 1 in the descriptor; the row-shift tile codes do not apply.  The _f32x_ pair is the same layout for
+ * e2fgvi_conv2d_f32x (chunks of 4 fp32 channels, K-steps of 32: the fp32 path's FFN second Linear, 40 channels = 10 chunks
+ * per tap, 62 steps instead of 98). */
 int64_t e2fgvi_packed_conv_weight_bf16x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin);
 int e2fgvi_pack_conv_weight_bf16x_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
                                        void* stream);
+int64_t e2fgvi_packed_conv_weight_f32x_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin);
+int e2fgvi_pack_conv_weight_f32x_taps(const float* w, float* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
+                                      void* stream);
 
 /* The same LDS-DMA kernel on fp32 operands: fp32 NHWC sources (channels per source in multiples of 4), fp32 packed weights,
  * v_mfma_f32_32x32x2_f32 (exact fp32, a K-step = 32 channels).  Same descriptor; used by the fp32 path for its GEMM-shaped

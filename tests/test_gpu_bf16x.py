@@ -348,6 +348,35 @@ def test_conv_f32x(dev, case):
         assert_close(nchw(out.cpu()), F.leaky_relu(ref0 + nchw(res), 0.1), 2e-5, "%s f32x tile %d" % (name, tile))
 
 
+F32_TAP_CASES = [
+    ("7x7 stride 3 pad 3, 40 -> 512 (FFN fc2 as a conv, fp32): 10 chunks per tap", 2, 30, 54, 40, 512, 7, 3, 3, (0, 1, 4, 7)),
+    ("3x3 24 -> 40: 6 chunks per tap", 2, 11, 13, 24, 40, 3, 1, 1, (0, 2, 5)),
+    ("7x7 8 -> 32 pad 3: 2 chunks per tap", 1, 16, 24, 8, 32, 7, 1, 3, (0, 3)),
+    ("3x3 stride 2, 4 -> 64: one chunk per tap", 1, 24, 40, 4, 64, 3, 2, 1, (0, 2)),
+]
+
+
+@pytest.mark.parametrize("case", F32_TAP_CASES, ids=[c[0] for c in F32_TAP_CASES])
+def test_conv_f32x_tap_packed(dev, case):
+    """tap-packed K-steps on fp32 operands (chunks of 4 channels) against torch fp32 conv2d, and against the unpacked layout"""
+    from e2fgvi_amd import ops
+    name, N, H, W, cin, Cout, k, stride, pad, tiles = case
+    g = _gen(abs(hash(name)) % 1000 + 11)
+    w = torch.randn(Cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    wide = torch.randn(N, H, W, cin + 8, generator=g)
+    ref0 = F.conv2d(nchw(wide[..., 4:4 + cin]), w, bias, stride=stride, padding=pad)
+    layer = ops.PackedConvX(w.to(dev), bias.to(dev), [cin], stride=stride, pad=pad, dtype=torch.float32, taps=True)
+    plain = ops.PackedConvX(w.to(dev), bias.to(dev), [cin], stride=stride, pad=pad, dtype=torch.float32)
+    assert layer.taps and not plain.taps and layer.wpacked.numel() < plain.wpacked.numel()
+    res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
+    src = [(wide.to(dev), 4)]
+    for tile in tiles:
+        out = layer(src, residual=res.to(dev), tile=tile)
+        assert_close(nchw(out.cpu()), ref0 + nchw(res), 2e-5, "%s f32x taps tile %d" % (name, tile))
+    assert_close(layer(src, residual=res.to(dev)), plain(src, residual=res.to(dev)), 2e-5, name + ": packed vs unpacked")
+
+
 def test_fp32_layers_may_pick_the_lds_dma_kernel(dev):
     """PackedConv / PackedLinear with tune=True time the register-staged implicit GEMM AND the LDS-DMA kernel on the first
     call and keep the faster; whatever is chosen, the result is the fp32 one"""
