@@ -120,27 +120,15 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     const __amdgpu_buffer_rsrc_t r_w = make_rsrc(p.w, p.w_bytes);
 
     // fixed per-thread item geometry
-    int it_row[A_IT], it_uu[A_IT], it_c4[A_IT], it_by[A_IT], it_bx[A_IT], it_imgrow[A_IT];
-    unsigned it_pix[A_IT];
+    int it_row[A_IT], it_uu[A_IT], it_c4[A_IT];
     bool it_ok[A_IT];
 #pragma unroll
     for (int ia = 0; ia < A_IT; ++ia) {
         const int f = tid + ia * NG;
-        const int row = f / (2 * CQ);
-        it_row[ia] = row;
+        it_row[ia] = f / (2 * CQ);
         it_uu[ia] = (f / CQ) & 1;
         it_c4[ia] = f & (CQ - 1);
-        const int m = m0 + row;
-        const bool ok = (A_ITEMS % NG == 0 || f < A_ITEMS) && m < p.M;
-        const int mm = ok ? m : 0;
-        const int img = mm / HoWo;
-        const int rem = mm - img * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        it_imgrow[ia] = img * p.H;
-        it_by[ia] = oy * p.stride - p.pad;
-        it_bx[ia] = ox * p.stride - p.pad;
-        it_pix[ia] = (unsigned)mm;
-        it_ok[ia] = ok;
+        it_ok[ia] = A_ITEMS % NG == 0 || f < A_ITEMS;
     }
     unsigned b_off[B_IT];
 #pragma unroll
@@ -180,24 +168,42 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     __syncthreads();
     const unsigned c_W = (unsigned)__builtin_amdgcn_readfirstlane(p.W);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    // ---- loader threads (tid < SLOTS): slot = (pixel row, unit in chunk)
+    // ---- sampler threads: slot = (pixel row, unit in chunk).  SLOTS / 64 whole waves of the group fetch the raw offset /
+    // mask / flow words of a chunk AND turn them into the sample's four corner addresses and bilinear weights, once per
+    // (row, unit): the 16 channels of a unit are 2 (bf16 sources) or 4 (fp32) 16-byte items that used to repeat this
+    // arithmetic (~100 VALU instructions each; the kernel is VALU-bound: 4 MFMAs against ~600 VALU cycles per wave and
+    // chunk in the bf16 instantiation).  The sampler waves rotate with the K group so that every SIMD hosts one.
+    // Measured (tools/dcn_bench.py, dcn_bench_x.py): fp32 60x108 tile 5 64.6 -> 60.6 us; bf16 180x324 tile 6 unchanged
+    // (195 -> 199 us): there the corner fetches themselves (16-byte pieces of 512-byte pixels, L1 working set > 32 KB) bound it.
     float* const graw = sraw + kg * (2 * SLOTS * 8);
-    const bool loader = tid < SLOTS;                       // wave-uniform
+    constexpr int NWG = WGM * WGN, LW = SLOTS / 64;
+    const int lw = (KS == 1) ? wave : (wave - (kg * LW) % NWG + NWG) % NWG;
+    const bool loader = lw < LW;                           // wave-uniform
+    const int ltid = lw * 64 + lane;
     unsigned l_po = 0, l_pm = 0, l_pf = 0;
+    int l_by = 0, l_bx = 0, l_imgrow = 0;
     bool l_ok = false;
     {
-        const int m = m0 + (tid >> 1);
+        const int m = m0 + (ltid >> 1);
         l_ok = loader && m < p.M;
-        const unsigned pix = l_ok ? (unsigned)m : 0u;
+        const int mm = l_ok ? m : 0;
+        const unsigned pix = (unsigned)mm;
         l_po = pix * (unsigned)p.off_ld * 4u;
         l_pm = pix * (unsigned)p.msk_ld * 4u;
         l_pf = pix * 16u;
+        const int img = mm / HoWo;
+        const int rem = mm - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        l_imgrow = img * p.H;
+        l_by = oy * p.stride - p.pad;
+        l_bx = ox * p.stride - p.pad;
     }
+    constexpr unsigned OOBS = 0x80000000u;                 // out-of-range corner: stays out of range after + part * 16 (sources < 2 GiB)
     f32x2 l_d = {0.f, 0.f}, l_f = {0.f, 0.f};
     float l_mk = 0.f;
     auto load_offsets = [&](int kt) {
         if (loader) {
-            const int u = 2 * kt + (tid & 1);
+            const int u = 2 * kt + (ltid & 1);
             const bool ok = kt < KT && u < p.units && l_ok;
             const i32x4 e = *reinterpret_cast<const i32x4*>(utab + (ok ? u : 0) * 8);
             l_d = buf_load2(r_off, ok ? l_po + (unsigned)e[0] : OOB);
@@ -205,59 +211,63 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             l_f = buf_load2(r_flw, ok ? l_pf + (unsigned)e[2] : OOB);
         }
     };
-    auto store_offsets = [&](int buf) {
+    // the sampler's half: raw words of chunk kt (in its registers) -> slot {a00, a01, a10, a11, w00, w01, w10, w11}
+    auto store_offsets = [&](int buf, int kt) {
         if (loader) {
-            float* d = graw + (buf * SLOTS + tid) * 8;
-            const f32x4 a = {l_d[0], l_d[1], l_mk, 0.f};
-            *reinterpret_cast<f32x4*>(d) = a;
-            *reinterpret_cast<f32x2*>(d + 4) = l_f;
-        }
-    };
-    // turn the raw words (loaded for chunk kt) into corner fetches for chunk kt
-    auto issue_corners = [&](int kt, int S, int rbuf) {
-        // both units of a chunk read the same source (host guarantees an even unit count in source 0)
-        const bool second_src = (kt * 2) >= p.units0;
-        const __amdgpu_buffer_rsrc_t rs = second_src ? r_src1 : r_src0;
-        const unsigned cbase4 = second_src ? (unsigned)p.c[0] * (unsigned)SB : 0u;
-        const unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * (unsigned)SB;
-#pragma unroll
-        for (int ia = 0; ia < A_IT; ++ia) {
-            const int u = 2 * kt + it_uu[ia];
-            const bool uok = kt < KT && u < p.units && it_ok[ia];
+            const int u = 2 * kt + (ltid & 1);
+            const bool uok = kt < KT && u < p.units && l_ok;
             const int* e = utab + (uok ? u : 0) * 8;
             const int dyk = e[3], dxk = e[4];
-            const unsigned ch = (unsigned)(S16 ? e[5] >> 1 : e[5]) - cbase4 + (unsigned)it_c4[ia] * 16u;
-            const float* slot = graw + (rbuf * SLOTS + it_row[ia] * 2 + it_uu[ia]) * 8;
-            const f32x4 rw = *reinterpret_cast<const f32x4*>(slot);
-            float dy = rw[0], dx = rw[1], mk = rw[2];
+            // both units of a chunk read the same source (host guarantees an even unit count in source 0)
+            const bool second_src = (kt * 2) >= p.units0;
+            const unsigned cbase4 = second_src ? (unsigned)p.c[0] * (unsigned)SB : 0u;
+            const unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * (unsigned)SB;
+            const unsigned ch = (unsigned)(S16 ? e[5] >> 1 : e[5]) - cbase4;
+            float dy = l_d[0], dx = l_d[1], mk = l_mk;
             if (p.flows) {
-                const f32x2 fl = *reinterpret_cast<const f32x2*>(slot + 4);
                 // tanh / sigmoid through v_exp_f32 + v_rcp_f32 (abs error ~2e-7: <1e-5 px on the residual offset)
-                dy = p.max_residue * fast_tanh(dy) + fl[1];        // flip: dy takes the v (y) component
-                dx = p.max_residue * fast_tanh(dx) + fl[0];
+                dy = p.max_residue * fast_tanh(dy) + l_f[1];       // flip: dy takes the v (y) component
+                dx = p.max_residue * fast_tanh(dx) + l_f[0];
                 mk = fast_sigmoid(mk);
             }
-            const float py = (float)(it_by[ia] + dyk) + dy;
-            const float px = (float)(it_bx[ia] + dxk) + dx;
+            const float py = (float)(l_by + dyk) + dy;
+            const float px = (float)(l_bx + dxk) + dx;
             const bool inside = uok && py > -1.f && px > -1.f && py < (float)p.H && px < (float)p.W;
             const float fy = floorf(py), fx = floorf(px);
             const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
             const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
             const bool vy0 = inside && y0 >= 0, vy1 = inside && y1 <= p.H - 1, vx0 = x0 >= 0, vx1 = x1 <= p.W - 1;
             const float mm = inside ? mk : 0.f;
-            w00[S][ia] = hy * hx * mm; w01[S][ia] = hy * lx * mm; w10[S][ia] = ly * hx * mm; w11[S][ia] = ly * lx * mm;
             // 24-bit multiplies (full rate): pixel indices and pixel strides are < 2^24 (checked on the host).  The products
             // are formed from the row y1 and column x1, which are >= 0 whenever the sample is inside; the y0 / x0 addresses
-            // follow by subtraction (they may wrap when y0 or x0 is -1 -- those corners are replaced by OOB below)
-            const unsigned r1 = __umul24((unsigned)(it_imgrow[ia] + y1), c_W);
+            // follow by subtraction (they may wrap when y0 or x0 is -1 -- those corners are replaced by the sentinel)
+            const unsigned r1 = __umul24((unsigned)(l_imgrow + y1), c_W);
             const unsigned r0 = r1 - c_W;
             const unsigned a01 = __umul24(r0 + (unsigned)x1, ld4) + ch;
             const unsigned a11 = __umul24(r1 + (unsigned)x1, ld4) + ch;
             const unsigned a00 = a01 - ld4, a10 = a11 - ld4;
-            c00[S][ia] = buf_load4(rs, (vy0 && vx0) ? a00 : OOB);
-            c01[S][ia] = buf_load4(rs, (vy0 && vx1) ? a01 : OOB);
-            c10[S][ia] = buf_load4(rs, (vy1 && vx0) ? a10 : OOB);
-            c11[S][ia] = buf_load4(rs, (vy1 && vx1) ? a11 : OOB);
+            const u32x4 ad = {(vy0 && vx0) ? a00 : OOBS, (vy0 && vx1) ? a01 : OOBS, (vy1 && vx0) ? a10 : OOBS, (vy1 && vx1) ? a11 : OOBS};
+            const f32x4 ww = {hy * hx * mm, hy * lx * mm, ly * hx * mm, ly * lx * mm};
+            float* d = graw + (buf * SLOTS + ltid) * 8;
+            *reinterpret_cast<u32x4*>(d) = ad;
+            *reinterpret_cast<f32x4*>(d + 4) = ww;
+        }
+    };
+    // the items' half: a slot's addresses + this item's 16-byte part -> corner fetches of chunk kt
+    auto issue_corners = [&](int kt, int S, int rbuf) {
+        const bool second_src = (kt * 2) >= p.units0;
+        const __amdgpu_buffer_rsrc_t rs = second_src ? r_src1 : r_src0;
+#pragma unroll
+        for (int ia = 0; ia < A_IT; ++ia) {
+            const float* slot = graw + (rbuf * SLOTS + it_row[ia] * 2 + it_uu[ia]) * 8;
+            const u32x4 ad = *reinterpret_cast<const u32x4*>(slot);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(slot + 4);
+            const unsigned part = (unsigned)it_c4[ia] * 16u;
+            w00[S][ia] = ww[0]; w01[S][ia] = ww[1]; w10[S][ia] = ww[2]; w11[S][ia] = ww[3];
+            c00[S][ia] = buf_load4(rs, it_ok[ia] ? ad[0] + part : OOBS);
+            c01[S][ia] = buf_load4(rs, it_ok[ia] ? ad[1] + part : OOBS);
+            c10[S][ia] = buf_load4(rs, it_ok[ia] ? ad[2] + part : OOBS);
+            c11[S][ia] = buf_load4(rs, it_ok[ia] ? ad[3] + part : OOBS);
         }
     };
     auto load_w = [&](int kt, int S) {
@@ -322,18 +332,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     //   tile i in the LDS ring, corners + weights of chunk i+1 in flight in register set (i+1)&1,
     //   raw words of chunk i+2 in sraw buffer i&1, raw words of chunk i+3 in the loader's registers
     load_offsets(kg);
-    store_offsets(0);
+    store_offsets(0, kg);
     load_offsets(kg + KS);
     __syncthreads();
     issue_corners(kg, 0, 0);
     load_w(kg, 0);
-    store_offsets(1);
+    store_offsets(1, kg + KS);
     load_offsets(kg + 2 * KS);
     store_tile(0, 0);
     __syncthreads();
     issue_corners(kg + KS, 1, 1);
     load_w(kg + KS, 1);
-    store_offsets(0);
+    store_offsets(0, kg + 2 * KS);
     load_offsets(kg + 3 * KS);
     __syncthreads();
 
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                                                wn * TN * 32, lane);
             }
             store_tile(cur ^ 1, par ^ 1);                    // chunk i+1
-            store_offsets(par ^ 1);                          // chunk i+3 (that buffer's readers passed the last barrier)
+            store_offsets(par ^ 1, kt + 3 * KS);             // chunk i+3 (that buffer's readers passed the last barrier)
             load_offsets(kt + 4 * KS);
             __syncthreads();
             cur ^= 1;
@@ -568,8 +578,8 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         const long long sb0 = (long long)d->N * d->H * d->W * p.ld[0] * sb, sb1 = (long long)d->N * d->H * d->W * p.ld[1] * sb;
         const long long ob = P * d->off_ld * 4, mb = P * d->mask_ld * 4,
                         wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * (d->mfma_dtype == E2FGVI_BF16 ? 2 : 4);
-        E2_REQUIRE(sb0 < 4294967295LL && sb1 < 4294967295LL && ob < 4294967295LL && mb < 4294967295LL && wb < 4294967295LL,
-                   E2FGVI_EUNSUP, "mdcn: a tensor spans >= 4 GiB; buffer addressing needs less (split the batch)");
+        E2_REQUIRE(sb0 < 2147483392LL && sb1 < 2147483392LL && ob < 4294967295LL && mb < 4294967295LL && wb < 4294967295LL,
+                   E2FGVI_EUNSUP, "mdcn: a source spans >= 2 GiB (or offsets / masks >= 4 GiB); buffer addressing needs less (split the batch)");
         p.src_bytes[0] = (unsigned)sb0; p.src_bytes[1] = (unsigned)sb1;
         p.off_bytes = (unsigned)ob; p.msk_bytes = (unsigned)mb; p.flw_bytes = (unsigned)(P * 16); p.w_bytes = (unsigned)wb;
         // the mask may alias the offset tensor (raw conv_offset layout): bound it by what is left behind its base
