@@ -38,6 +38,7 @@ struct DcnParams {
     const float* bias;
     float* dst; int dst_ld, dst_coff, dst_bf16;
     int tilesM, tilesN;
+    int sw, swX, swY;      // sw: a tile's BM rows are an 8 x (BM / 8) pixel block (swX x swY blocks per image) instead of BM consecutive pixels
     int units0;            // units (of 16 channels x tap) that live in source 0
     unsigned src_bytes[2], off_bytes, msk_bytes, flw_bytes, w_bytes;
 };
@@ -184,16 +185,29 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     int l_by = 0, l_bx = 0, l_imgrow = 0;
     bool l_ok = false;
     {
-        const int m = m0 + (ltid >> 1);
-        l_ok = loader && m < p.M;
-        const int mm = l_ok ? m : 0;
-        const unsigned pix = (unsigned)mm;
+        int img, oy, ox;
+        if (p.sw) {                                        // block layout: tile_m = (img, block y, block x), row = (y, x) inside 8 wide
+            const int r = ltid >> 1;
+            img = tile_m / (p.swX * p.swY);
+            const int rem = tile_m - img * (p.swX * p.swY);
+            const int ty = rem / p.swX, tx = rem - ty * p.swX;
+            oy = ty * (BM / 8) + (r >> 3);
+            ox = tx * 8 + (r & 7);
+            l_ok = loader && oy < p.Ho && ox < p.Wo;
+            if (!l_ok) { img = 0; oy = 0; ox = 0; }
+        } else {
+            const int m = m0 + (ltid >> 1);
+            l_ok = loader && m < p.M;
+            const int mm = l_ok ? m : 0;
+            img = mm / HoWo;
+            const int rem = mm - img * HoWo;
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
+        const unsigned pix = (unsigned)((img * p.Ho + oy) * p.Wo + ox);
         l_po = pix * (unsigned)p.off_ld * 4u;
         l_pm = pix * (unsigned)p.msk_ld * 4u;
         l_pf = pix * 16u;
-        const int img = mm / HoWo;
-        const int rem = mm - img * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         l_imgrow = img * p.H;
         l_by = oy * p.stride - p.pad;
         l_bx = ox * p.stride - p.pad;
@@ -422,8 +436,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = m0 + (wm * TM + tm) * 32 + row;
-                if (m < p.M) {
+                int m = m0 + (wm * TM + tm) * 32 + row;
+                bool ok = m < p.M;
+                if (p.sw) {
+                    const int rr = (wm * TM + tm) * 32 + row;
+                    const int img = tile_m / (p.swX * p.swY);
+                    const int rem = tile_m - img * (p.swX * p.swY);
+                    const int ty = rem / p.swX, tx = rem - ty * p.swX;
+                    const int oy = ty * (BM / 8) + (rr >> 3), ox = tx * 8 + (rr & 7);
+                    ok = oy < p.Ho && ox < p.Wo;
+                    m = (img * p.Ho + oy) * p.Wo + ox;
+                }
+                if (ok) {
                     const long long o = (long long)m * p.dst_ld + p.dst_coff + n;
                     if (p.dst_bf16) reinterpret_cast<__bf16*>(p.dst)[o] = (__bf16)(acc[tm][tn][r] + bv);
                     else p.dst[o] = acc[tm][tn][r] + bv;
@@ -482,6 +506,11 @@ long long dcn_packed_size(int Cout, int C, int KH, int KW) {
 template <int BM, int BN, int WGM, int WGN, int KS>
 int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16) {
     p.tilesM = cdiv(p.M, BM);
+    if (p.sw) {
+        p.swX = cdiv(p.Wo, 8);
+        p.swY = cdiv(p.Ho, BM / 8);
+        p.tilesM = p.N * p.swX * p.swY;
+    }
     p.tilesN = cdiv(p.Cout, BN);
     if (s16)
         hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
@@ -589,12 +618,17 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         E2_REQUIRE(d->nsrc == 1 || p.units0 % 2 == 0, E2FGVI_EUNSUP, "mdcn: odd number of 16-channel units in source 0");
     }
     int tile = d->tile;
+    p.sw = 0; p.swX = p.swY = 1;
+    if (tile >= 100) { p.sw = 1; tile -= 100; }          // 101 ... 106: the same tiles on 8 x (BM / 8) pixel blocks
     if (!tile) {
         const long long b64 = (long long)cdiv(p.M, 64) * cdiv(p.Cout, 128);
         tile = b64 >= 512 ? 1 : (b64 >= 256 ? 2 : 5);
         // bf16 product: the 64-row tile with two K groups (tools/dcn_bench_x.py at 180x324: 195 vs 203 us with bf16 sources,
         // 221 vs 225 with fp32 sources)
-        if (tile == 1 && d->mfma_dtype == E2FGVI_BF16) tile = 6;
+        // ... and its 64 rows as an 8 x 8 pixel block: the corner fetches of a tile then fall into a (8 + 2r)^2 neighbourhood
+        // instead of (64 + 2r) x (1 + 2r) pixels -- 177.9 vs 196.2 us (profiles/r02_dcn_sampler.txt).  Not for the small fp32
+        // launches (60x108: 63.8 vs 60.0 us, the partial blocks cost more than the locality gains)
+        if (tile == 1 && d->mfma_dtype == E2FGVI_BF16) { tile = 6; p.sw = 1; }
     }
     const bool bf = d->mfma_dtype == E2FGVI_BF16;
     if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf, s16);

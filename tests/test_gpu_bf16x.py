@@ -287,7 +287,7 @@ def test_bf16_path_against_reference_golden(dev, fixture):
     assert np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max() <= 5e-2 * max(1.0, fmax / 4)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 101, 106])
 def test_mdcn_bf16_mfma(dev, tile):
     """deformable conv with the sampled columns and the weights rounded to bf16 for the MFMA (fp32 gather, blend and
     accumulation): against the fp32 oracle of mmcv's op.  Each of the K = 2304 products carries two 2^-9 roundings with

@@ -175,7 +175,7 @@ def test_linear(dev, rows, cin, cout):
     assert_close(out.cpu(), F.linear(x, w, b) + r, REL, "linear")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 101, 102, 105])
 @pytest.mark.parametrize("mag", [0.0, 3.0, 40.0])
 def test_mdcn_generic(dev, tile, mag):
     """mmcv semantics with explicit offset/mask tensors (oracle/dcn.py), incl. far out-of-bounds offsets."""

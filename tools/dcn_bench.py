@@ -12,7 +12,7 @@ raw = (torch.randn(N, H, W, 432, generator=g) * 0.5).to(dev); fl = (torch.randn(
 w = (torch.randn(128, 256, 3, 3, generator=g) / 48).to(dev); b = torch.randn(128, generator=g).to(dev)
 layer = ops.PackedDcn(w, b, 16, pad=1)
 ref = layer([a, c], raw, flows=fl, tile=2)
-for tile in (0, 1, 2, 3, 4, 5, 6):
+for tile in (0, 1, 2, 3, 4, 5, 6, 105, 104, 102, 5):
     out = layer([a, c], raw, flows=fl, tile=tile)
     diff = (out - ref).abs().max().item()
     iters = 20

@@ -13,7 +13,7 @@ w = (torch.randn(128, 256, 3, 3, generator=g) / 48).to(dev); b = torch.randn(128
 layer = ops.PackedDcn(w, b, 16, pad=1, mfma="bf16")
 gf = 2 * H * W * 128 * 2304 * 1e-9
 for name, srcs in (("fp32 src", [a, c]), ("bf16 src", [a.bfloat16(), c.bfloat16()])):
-    for tile in (1, 2, 3, 4, 5, 6):
+    for tile in (1, 2, 4, 6, 101, 102, 104, 106):
         out = layer(srcs, offs, tile=tile, out_dtype=torch.bfloat16)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
