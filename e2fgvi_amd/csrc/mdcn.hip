@@ -15,6 +15,7 @@
 //
 // Replaces mmcv.ops.modulated_deform_conv2d at model/modules/feat_prop.py:55-58.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -625,10 +626,16 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         tile = b64 >= 512 ? 1 : (b64 >= 256 ? 2 : 5);
         // bf16 product: the 64-row tile with two K groups (tools/dcn_bench_x.py at 180x324: 195 vs 203 us with bf16 sources,
         // 221 vs 225 with fp32 sources)
-        // ... and its 64 rows as an 8 x 8 pixel block: the corner fetches of a tile then fall into a (8 + 2r)^2 neighbourhood
-        // instead of (64 + 2r) x (1 + 2r) pixels -- 177.9 vs 196.2 us (profiles/r02_dcn_sampler.txt).  Not for the small fp32
-        // launches (60x108: 63.8 vs 60.0 us, the partial blocks cost more than the locality gains)
-        if (tile == 1 && d->mfma_dtype == E2FGVI_BF16) { tile = 6; p.sw = 1; }
+        // Its 64 rows as an 8 x 8 pixel block (tile 106: the corner fetches of a tile fall into a (8 + 2r)^2 neighbourhood instead
+        // of (64 + 2r) x (1 + 2r) pixels) is 9 % faster on i.i.d. random 3-pixel offsets (177.9 vs 196.2 us) and exactly neutral
+        // inside the forward, where the offsets follow the smooth flow field (34.46 / 34.57 vs 34.42 / 34.58 ms, same box,
+        // profiles/r02_dcn_sampler.txt): off by default, E2FGVI_DCN_BLOCKS=1 or tile codes 101 ... 106 select it
+        if (tile == 1 && d->mfma_dtype == E2FGVI_BF16) {
+            tile = 6;
+            static int blocks_env = -1;
+            if (blocks_env < 0) { const char* e = getenv("E2FGVI_DCN_BLOCKS"); blocks_env = e ? atoi(e) : 0; }
+            p.sw = blocks_env ? 1 : 0;
+        }
     }
     const bool bf = d->mfma_dtype == E2FGVI_BF16;
     if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf, s16);
