@@ -16,13 +16,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # (source, object, extra flags).  The HBM-bound kernels lose nothing without packed math; the fp32 conv kernels keep it in
 # their normal build (6-8 % on the MFMA kernels' transforms / epilogues, profiles/r02_c2_*) and get a second, packed-free
-# build for the side-stream launches (SPyNet).
+# build for the side-stream launches (SPyNet).  mdcn.hip: its sampler waves do arithmetic on freshly loaded offset / mask / flow
+# words while the other waves of the SAME workgroup stream LDS-fed bf16 MFMA tiles -- with packed math the 64-row / two-K-group
+# tile returned wrong rows 24-31 (lanes 48-63 of the sampler wave) in a few launches per hundred.
 UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
          ("conv_bf16.hip", "conv_bf16.o", []), ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", []),
-         ("mdcn.hip", "mdcn.o", []), ("attention.hip", "attention.o", []),
+         ("mdcn.hip", "mdcn.o", NOPK), ("attention.hip", "attention.o", []),
          ("attention_bf16.hip", "attention_bf16.o", []), ("misc.hip", "misc.o", NOPK),
          ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]
-NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "misc.o", "video.o", "metrics.o")
+NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "mdcn.o", "misc.o", "video.o", "metrics.o")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 

@@ -39,6 +39,8 @@ struct DcnParams {
     const float* bias;
     float* dst; int dst_ld, dst_coff, dst_bf16;
     int tilesM, tilesN;
+    int planar;            // bf16 sources laid out [group][pixel][16]: plane_bytes per group
+    unsigned plane_bytes;
     int sw, swX, swY;      // sw: a tile's BM rows are an 8 x (BM / 8) pixel block (swX x swY blocks per image) instead of BM consecutive pixels
     int units0;            // units (of 16 channels x tap) that live in source 0
     unsigned src_bytes[2], off_bytes, msk_bytes, flw_bytes, w_bytes;
@@ -236,8 +238,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             // both units of a chunk read the same source (host guarantees an even unit count in source 0)
             const bool second_src = (kt * 2) >= p.units0;
             const unsigned cbase4 = second_src ? (unsigned)p.c[0] * (unsigned)SB : 0u;
-            const unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * (unsigned)SB;
-            const unsigned ch = (unsigned)(S16 ? e[5] >> 1 : e[5]) - cbase4;
+            unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * (unsigned)SB;
+            unsigned ch = (unsigned)(S16 ? e[5] >> 1 : e[5]) - cbase4;
+            if (S16 && p.planar) {                         // [group][pixel][16 bf16]: pixel stride 32 bytes, a plane per group
+                ld4 = 32u;
+                ch = (ch >> 5) * p.plane_bytes;
+            }
             float dy = l_d[0], dx = l_d[1], mk = l_mk;
             if (p.flows) {
                 // tanh / sigmoid through v_exp_f32 + v_rcp_f32 (abs error ~2e-7: <1e-5 px on the residual offset)
@@ -591,6 +597,10 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
                    (d->nsrc == 1 || d->src_ld[1] * 4 < (1 << 24)),
                E2FGVI_EUNSUP, "mdcn: more than 2^24 input pixels per call (split the batch)");
     E2_REQUIRE(!d->flows || d->deform_groups % 2 == 0, E2FGVI_EINVAL, "mdcn: fused flows need an even group count");
+    E2_REQUIRE(!d->src_planar || (s16 && cg == 16), E2FGVI_EUNSUP, "mdcn: src_planar needs bf16 sources and 16 channels per deform group");
+    p.planar = d->src_planar ? 1 : 0;
+    p.plane_bytes = (unsigned)((long long)d->N * d->H * d->W * 32);
+    if (p.planar) { p.ld[0] = d->src_c[0]; p.ld[1] = d->nsrc == 2 ? d->src_c[1] : p.ld[0]; }      // byte bounds below: c / 16 planes
     E2_REQUIRE(d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "mdcn: dst slice exceeds dst_ld");
     p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
@@ -630,7 +640,8 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         // of (64 + 2r) x (1 + 2r) pixels) is 9 % faster on i.i.d. random 3-pixel offsets (177.9 vs 196.2 us) and exactly neutral
         // inside the forward, where the offsets follow the smooth flow field (34.46 / 34.57 vs 34.42 / 34.58 ms, same box,
         // profiles/r02_dcn_sampler.txt): off by default, E2FGVI_DCN_BLOCKS=1 or tile codes 101 ... 106 select it
-        if (tile == 1 && d->mfma_dtype == E2FGVI_BF16) {
+        // (planar sources: the single K group wins, 143 vs 156 us on a smooth offset field, 170 vs 178 on random offsets)
+        if (tile == 1 && d->mfma_dtype == E2FGVI_BF16 && !p.planar) {
             tile = 6;
             static int blocks_env = -1;
             if (blocks_env < 0) { const char* e = getenv("E2FGVI_DCN_BLOCKS"); blocks_env = e ? atoi(e) : 0; }

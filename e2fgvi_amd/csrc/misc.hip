@@ -846,3 +846,25 @@ extern "C" int e2fgvi_cast(const void* src, int32_t src_dtype, void* dst, int32_
     E2_LAUNCH_CHECK("cast");
     return 0;
 }
+
+// ---- bf16 NHWC [P][C] -> [C / 16][P][16]: the planar source layout of the deformable conv (mdcn.hip, src_planar)
+namespace {
+__global__ void nhwc_to_planar16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long P, int C8) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte octet of 8 channels
+    if (idx >= P * C8) return;
+    const long long pix = idx / C8;
+    const int o = (int)(idx - pix * C8);
+    dst[((long long)(o >> 1) * P + pix) * 2 + (o & 1)] = src[idx];
+}
+}  // namespace
+
+extern "C" int e2fgvi_nhwc_to_planar16(const void* src, void* dst, int64_t P, int32_t C, void* stream) {
+    E2_REQUIRE(src && dst, E2FGVI_EINVAL, "nhwc_to_planar16: null pointer");
+    E2_REQUIRE(P > 0 && C > 0 && C % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, E2FGVI_EINVAL,
+               "nhwc_to_planar16: C must be a multiple of 16, buffers 16-byte aligned");
+    const long long n = (long long)P * (C / 8);
+    hipLaunchKernelGGL(nhwc_to_planar16_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)src, (uint4*)dst, (long long)P, C / 8);
+    E2_LAUNCH_CHECK("nhwc_to_planar16");
+    return 0;
+}

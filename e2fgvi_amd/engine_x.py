@@ -21,6 +21,7 @@ from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_TANH, PackedConvX, Packed
 
 BF16 = torch.bfloat16
 TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
+DCN_PLANAR = os.environ.get("E2FGVI_DCN_PLANAR", "1") != "0"    # deformable conv gathers from [group][pixel][16] copies
 FC2_CONV = os.environ.get("E2FGVI_FC2_CONV", "1") != "0"     # FFN second Linear as a conv of the folded tensor
 
 
@@ -164,6 +165,10 @@ class BF16Path:
             img_stride = (l_t - 1) * h * w * 2
             hist = []                       # fp32 propagated features in processing order (flow-warp sources)
             hist16 = []                     # their bf16 copies (the DCN gathers these: 8 channels per 16-byte corner fetch)
+            # ... re-laid out [group][pixel][16]: the 32-byte runs a deform group's samples fetch are then adjacent for
+            # neighbouring pixels and share cache lines (NHWC: one run per 256-byte pixel) -- tools/dcn_bench_x.py
+            planar16 = []
+            zero16p = self._zero16((ch // 16, b, h, w, 16)) if DCN_PLANAR else None
             aligned = zero16
             for i, idx in enumerate(order):
                 cur = loc[idx]
@@ -176,11 +181,16 @@ class BF16Path:
                     x = off[1]([x], **lk)
                     x = off[2]([x], **lk)
                     offs = off[3]([x], out_dtype=torch.float32, residual=fl, act=ACT_DCNPOST, slope=10.0)
-                    aligned = dcn([hist16[-1], hist16[-2] if i > 1 else zero16], offs, out_dtype=BF16)
+                    if DCN_PLANAR:
+                        aligned = dcn([planar16[-1], planar16[-2] if i > 1 else zero16p], offs, out_dtype=BF16, planar=True)
+                    else:
+                        aligned = dcn([hist16[-1], hist16[-2] if i > 1 else zero16], offs, out_dtype=BF16)
                 srcs = [cur, stores["backward_"][idx], aligned] if name == "forward_" else [cur, aligned]
                 y = bb[0](srcs, **lk)
                 hist.append(bb[1]([y], out_dtype=torch.float32, residual=aligned, out2=store16[idx]))
                 hist16.append(store16[idx])
+                if DCN_PLANAR and i + 1 < l_t:
+                    planar16.append(ops.to_planar16(store16[idx]))
             stores[name] = store16
         out = self.xfusion([stores["backward_"].view(l_t * b, h, w, ch), stores["forward_"].view(l_t * b, h, w, ch)],
                            residual=loc.view(l_t * b, h, w, ch))

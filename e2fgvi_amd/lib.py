@@ -54,7 +54,7 @@ class MdcnDesc(C.Structure):
         ("flows", _fp), ("max_residue", C.c_float),
         ("wpacked", _fp), ("bias", _fp),
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("tile", C.c_int32), ("dst_dtype", C.c_int32),
-        ("mfma_dtype", C.c_int32), ("src_dtype", C.c_int32),
+        ("mfma_dtype", C.c_int32), ("src_dtype", C.c_int32), ("src_planar", C.c_int32),
     ]
 
 
@@ -63,6 +63,7 @@ _i32, _i64, _f = C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "e2fgvi_last_error": (C.c_char_p, []),
     "e2fgvi_abi_version": (C.c_int, []),
+    "e2fgvi_nhwc_to_planar16": (C.c_int, [_fp, _fp, _i64, _i32, _fp]),
     "e2fgvi_conv2d_nhwc": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "e2fgvi_conv2d_nhwc_nopk": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "e2fgvi_packed_conv_weight_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32]),

@@ -647,19 +647,27 @@ class PackedDcn:
         self.name = "dcn"
 
     def __call__(self, sources, offset, mask=None, off_cols=None, flows=None, max_residue=10.0, out=None, tile=0,
-                 out_dtype=torch.float32):
+                 out_dtype=torch.float32, planar=False):
         """sources: 1 or 2 NHWC tensors (virtual concat).  offset: [N,Ho,Wo,*] pixel-major; if ``mask`` is None
-        the mask words live in the same tensor starting at column dg*2*K (raw conv_offset layout)."""
+        the mask words live in the same tensor starting at column dg*2*K (raw conv_offset layout).
+        planar=True: the (bf16) sources are [C/16, N, H, W, 16] tensors from ops.to_planar16."""
         lib = _L.load()
         d = _L.MdcnDesc()
-        N, H, W, _ = sources[0].shape
+        if planar:
+            _, N, H, W, _ = sources[0].shape
+        else:
+            N, H, W, _ = sources[0].shape
+        d.src_planar = 1 if planar else 0
         ctot = 0
         for i, t in enumerate(sources):
             _chk_any(t, "source %d" % i)
             if t.dtype != sources[0].dtype:
                 raise ValueError("sources must share one dtype")
-            d.src[i], d.src_ld[i], d.src_c[i] = t.data_ptr(), t.shape[3], t.shape[3]
-            ctot += t.shape[3]
+            c = t.shape[0] * 16 if planar else t.shape[3]
+            if planar and (t.dim() != 5 or t.shape[4] != 16 or tuple(t.shape[1:4]) != (N, H, W)):
+                raise ValueError("planar source %d must be [C/16, N, H, W, 16]" % i)
+            d.src[i], d.src_ld[i], d.src_c[i] = t.data_ptr(), c, c
+            ctot += c
         d.src_dtype = _dt(sources[0])                 # bf16 sources: only with mfma="bf16" (checked by the library)
         if ctot != self.C:
             raise ValueError("sources carry %d channels, weight expects %d" % (ctot, self.C))
@@ -911,6 +919,17 @@ def ffn_fold(hid, F_, fh, fw, H, W, Cc):
     _chk_any(hid, "hid")
     out = torch.empty((F_, H, W, Cc), dtype=hid.dtype, device=hid.device)
     _L.check(lib.e2fgvi_ffn_fold_x(_ptr(hid), _ptr(out), _dt(hid), F_, fh, fw, H, W, Cc, _stream()), "ffn_fold")
+    return out
+
+
+def to_planar16(x, out=None):
+    """bf16 NHWC [N,H,W,C] -> [C/16, N, H, W, 16]: the deformable conv's planar source layout (PackedDcn(..., planar=True))"""
+    _chk(x, "x", torch.bfloat16)
+    N, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((Cc // 16, N, H, W, 16), dtype=torch.bfloat16, device=x.device)
+    _chk(out, "out", torch.bfloat16)
+    _L.check(_L.load().e2fgvi_nhwc_to_planar16(_ptr(x), _ptr(out), N * H * W, Cc, _stream()), "nhwc_to_planar16")
     return out
 
 

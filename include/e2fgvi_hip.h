@@ -205,6 +205,10 @@ typedef struct {
                                           (fp32 gather / blend / accumulation), wpacked from e2fgvi_pack_dcn_weight_bf16 */
     int32_t src_dtype;                 /* E2FGVI_F32 (0, default); E2FGVI_BF16 (needs mfma_dtype = E2FGVI_BF16): the sources
                                           are bf16 NHWC (src_ld multiple of 8): half the gather fetches                 */
+    int32_t src_planar;                /* 1 (ABI version 4; bf16 sources, 16 channels per deform group): source s is laid out
+                                          [src_c[s] / 16 groups][N*H*W pixels][16 channels] (e2fgvi_nhwc_to_planar16) instead
+                                          of NHWC -- the 32-byte runs of neighbouring pixels of one group are then adjacent in
+                                          memory, so the corner fetches of neighbouring output pixels share cache lines       */
 } e2fgvi_mdcn_desc;
 
 int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream);
@@ -215,6 +219,9 @@ int e2fgvi_pack_dcn_weight(const float* w, float* wpacked, int32_t Cout, int32_t
 /* bf16 packing (e2fgvi_packed_dcn_weight_size elements of 2 bytes) for mfma_dtype = E2FGVI_BF16 */
 int e2fgvi_pack_dcn_weight_bf16(const float* w, void* wpacked, int32_t Cout, int32_t C, int32_t KH,
                                 int32_t KW, int32_t deform_groups, void* stream);
+
+/* bf16 NHWC [P pixels][C] (C a multiple of 16) -> [C / 16][P][16]: the deformable conv's planar source layout (src_planar) */
+int e2fgvi_nhwc_to_planar16(const void* src, void* dst, int64_t P, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal focal window attention, fused (flash-style, fp32 MFMA, online softmax).

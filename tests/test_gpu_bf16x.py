@@ -323,6 +323,63 @@ def test_mdcn_bf16_mfma(dev, tile):
         ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)(xs16, nhwc(off).to(dev), mask=nhwc(msk).to(dev))   # bf16 sources need mfma="bf16"
 
 
+@pytest.mark.parametrize("tile", [1, 4, 5, 6])
+def test_mdcn_reruns_are_bit_identical(dev, tile):
+    """20 launches of the same deformable conv must agree bit for bit.  Guards the packed-fp32 hazard of DESIGN.md "Stream
+    overlap" INSIDE one workgroup: mdcn.hip's sampler waves do arithmetic on freshly loaded offset / mask / flow words beside
+    waves that stream LDS-fed bf16 MFMA tiles; built with packed-fp32 VALU the 64-row two-K-group tile (6) returned wrong rows
+    24-31 (lanes 48-63 of the sampler wave) in a few launches per hundred -- the unit is built without them (build.py)."""
+    from e2fgvi_amd import ops
+    g = _gen(91)
+    N, H, W, Co, dg = 2, 14, 22, 128, 16
+    a = torch.randn(N, H, W, 128, generator=g).bfloat16().to(dev)
+    c = torch.randn(N, H, W, 128, generator=g).bfloat16().to(dev)
+    raw = (torch.randn(N, H, W, 432, generator=g) * 0.7).to(dev)
+    fl = (torch.randn(N, H, W, 4, generator=g) * 2.5).to(dev)
+    w = (torch.randn(Co, 256, 3, 3, generator=g) / 48).to(dev)
+    layer = ops.PackedDcn(w, torch.randn(Co, generator=g).to(dev), dg, pad=1, mfma="bf16")
+    ref = layer([a, c], raw, flows=fl, tile=tile)
+    for _ in range(20):
+        assert torch.equal(layer([a, c], raw, flows=fl, tile=tile), ref)
+
+
+def test_to_planar16(dev):
+    """bf16 NHWC -> [C/16][N][H][W][16] (csrc/misc.hip) is the obvious permutation"""
+    from e2fgvi_amd import ops
+    x = torch.randn(2, 7, 9, 48, generator=_gen(3)).bfloat16().to(dev)
+    got = ops.to_planar16(x)
+    assert torch.equal(got, x.view(2, 7, 9, 3, 16).permute(3, 0, 1, 2, 4).contiguous())
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 106])
+def test_mdcn_planar_sources(dev, tile):
+    """deformable conv gathering from planar [group][pixel][16] bf16 sources: the same values in the same order as the NHWC
+    bf16 sources -> bit-identical; one and two sources, with the fused conv_offset post-processing (flows), N = 2"""
+    from e2fgvi_amd import ops
+    g = _gen(91)
+    N, H, W, Co, dg = 2, 14, 22, 128, 16
+    a = torch.randn(N, H, W, 128, generator=g).bfloat16().to(dev)
+    c = torch.randn(N, H, W, 128, generator=g).bfloat16().to(dev)
+    raw = (torch.randn(N, H, W, 432, generator=g) * 0.7).to(dev)
+    fl = (torch.randn(N, H, W, 4, generator=g) * 2.5).to(dev)
+    w = (torch.randn(Co, 256, 3, 3, generator=g) / 48).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    layer = ops.PackedDcn(w, b, dg, pad=1, mfma="bf16")
+    ref = layer([a, c], raw, flows=fl, tile=tile, out_dtype=torch.bfloat16)
+    got = layer([ops.to_planar16(a), ops.to_planar16(c)], raw, flows=fl, tile=tile, out_dtype=torch.bfloat16, planar=True)
+    if tile == 0:        # the automatic choice differs (one K group for planar sources): same sums in another order
+        assert_close(got.float(), ref.float(), 1e-2, "planar vs NHWC, automatic tiles")
+    else:
+        assert torch.equal(got, ref)
+    one = ops.PackedDcn(w[:, :128].contiguous(), b, dg // 2, pad=1, mfma="bf16")
+    off1 = (torch.randn(N, H, W, 8 * 18, generator=g) * 3).to(dev)
+    m1 = torch.rand(N, H, W, 8 * 9, generator=g).to(dev)
+    t1 = tile if tile else 6
+    assert torch.equal(one([ops.to_planar16(a)], off1, mask=m1, tile=t1, planar=True), one([a], off1, mask=m1, tile=t1))
+    with pytest.raises(Exception):     # fp32 sources have no planar form
+        layer([ops.to_planar16(a).float(), ops.to_planar16(c).float()], raw, flows=fl, planar=True)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_f32x(dev, case):
     """the same LDS-DMA kernel on fp32 operands (exact fp32 MFMA; the fp32 path's tuning alternative for its GEMM-shaped

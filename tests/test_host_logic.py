@@ -100,7 +100,7 @@ def test_abi_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().e2fgvi_abi_version() == 3
+    assert lib.load().e2fgvi_abi_version() == 4
 
 
 def test_desc_struct_sizes_are_plain_c():
