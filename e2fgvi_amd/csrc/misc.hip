@@ -297,9 +297,15 @@ __device__ __forceinline__ Bil bil_zeros(float px, float py, int H, int W) {
     return b;
 }
 
+// source loads of prop_cond: VT<TC>::N channels from an fp32 tensor, or (bf16 sources, bf16 cond) one 16-byte bf16 octet
+template <typename TS, int Q> __device__ __forceinline__ void ld_src(const TS* p, f32x4 (&v)[Q]);
+template <> __device__ __forceinline__ void ld_src<float, 1>(const float* p, f32x4 (&v)[1]) { ldf<1>(p, v); }
+template <> __device__ __forceinline__ void ld_src<float, 2>(const float* p, f32x4 (&v)[2]) { ldf<2>(p, v); }
+template <> __device__ __forceinline__ void ld_src<__bf16, 2>(const __bf16* p, f32x4 (&v)[2]) { ldv<__bf16>(p, v); }
+
 // thread = (pixel, 4-channel chunk); C/4 threads per pixel
-template <typename TC>
-__global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const float* __restrict__ f2, int f2_ld,
+template <typename TC, typename TS>
+__global__ void prop_cond_kernel(const TS* __restrict__ fp, int fp_ld, const TS* __restrict__ f2, int f2_ld,
                                  const float* __restrict__ flow_a, const float* __restrict__ flow_b,
                                  long long flow_img_stride, TC* __restrict__ cond, float* __restrict__ flows,
                                  __bf16* __restrict__ flows8, int N, int H, int W, int C) {
@@ -330,16 +336,16 @@ __global__ void prop_cond_kernel(const float* __restrict__ fp, int fp_ld, const 
         fl2.x = f1.x + (a00.x * b1.w00 + a01.x * b1.w01 + a10.x * b1.w10 + a11.x * b1.w11);
         fl2.y = f1.y + (a00.y * b1.w00 + a01.y * b1.w01 + a10.y * b1.w10 + a11.y * b1.w11);
         const Bil b2 = bil_zeros((float)x + fl2.x, (float)y + fl2.y, H, W);
-        const float* s2 = f2 + (long long)n * H * W * f2_ld + c4 * NV;
+        const TS* s2 = f2 + (long long)n * H * W * f2_ld + c4 * NV;
         f32x4 a[Q], bq[Q], cc[Q], dd[Q];
-        ldf<Q>(s2 + b2.o00 * f2_ld, a); ldf<Q>(s2 + b2.o01 * f2_ld, bq); ldf<Q>(s2 + b2.o10 * f2_ld, cc); ldf<Q>(s2 + b2.o11 * f2_ld, dd);
+        ld_src<TS, Q>(s2 + b2.o00 * f2_ld, a); ld_src<TS, Q>(s2 + b2.o01 * f2_ld, bq); ld_src<TS, Q>(s2 + b2.o10 * f2_ld, cc); ld_src<TS, Q>(s2 + b2.o11 * f2_ld, dd);
 #pragma unroll
         for (int q = 0; q < Q; ++q) c2[q] = a[q] * b2.w00 + bq[q] * b2.w01 + cc[q] * b2.w10 + dd[q] * b2.w11;
     }
     {
-        const float* s1 = fp + (long long)n * H * W * fp_ld + c4 * NV;
+        const TS* s1 = fp + (long long)n * H * W * fp_ld + c4 * NV;
         f32x4 a[Q], bq[Q], cc[Q], dd[Q];
-        ldf<Q>(s1 + b1.o00 * fp_ld, a); ldf<Q>(s1 + b1.o01 * fp_ld, bq); ldf<Q>(s1 + b1.o10 * fp_ld, cc); ldf<Q>(s1 + b1.o11 * fp_ld, dd);
+        ld_src<TS, Q>(s1 + b1.o00 * fp_ld, a); ld_src<TS, Q>(s1 + b1.o01 * fp_ld, bq); ld_src<TS, Q>(s1 + b1.o10 * fp_ld, cc); ld_src<TS, Q>(s1 + b1.o11 * fp_ld, dd);
 #pragma unroll
         for (int q = 0; q < Q; ++q) c1[q] = a[q] * b1.w00 + bq[q] * b1.w01 + cc[q] * b1.w10 + dd[q] * b1.w11;
     }
@@ -655,6 +661,26 @@ extern "C" int e2fgvi_spynet_level_input(const float* pyr, const int32_t* ref_id
     return e2fgvi_spynet_level_input_x(pyr, ref_idx, supp_idx, flow_prev, out, nullptr, Np, h, w, stream);
 }
 
+extern "C" int e2fgvi_prop_cond_xs(const void* feat_prop, int32_t fp_ld, const void* feat_n2, int32_t f2_ld, int32_t src_dtype,
+                                   const float* flow_a, const float* flow_b, int64_t flow_img_stride, void* cond,
+                                   int32_t cond_dtype, float* flows, void* flows8_bf16, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, void* stream) {
+    if (src_dtype == E2FGVI_F32)
+        return e2fgvi_prop_cond_x((const float*)feat_prop, fp_ld, (const float*)feat_n2, f2_ld, flow_a, flow_b, flow_img_stride, cond,
+                                  cond_dtype, flows, flows8_bf16, N, H, W, C, stream);
+    E2_REQUIRE(src_dtype == E2FGVI_BF16 && cond_dtype == E2FGVI_BF16, E2FGVI_EINVAL, "prop_cond: bf16 sources need a bf16 cond");
+    E2_REQUIRE(feat_prop && flow_a && cond && flows && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && fp_ld % 8 == 0 &&
+                   ((uintptr_t)feat_prop & 15) == 0,
+               E2FGVI_EINVAL, "prop_cond: bad arguments");
+    E2_REQUIRE(!flow_b || (feat_n2 && f2_ld % 8 == 0 && ((uintptr_t)feat_n2 & 15) == 0), E2FGVI_EINVAL, "prop_cond: flow_b needs feat_n2");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL((prop_cond_kernel<__bf16, __bf16>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream,
+                       (const __bf16*)feat_prop, fp_ld, (const __bf16*)feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride,
+                       (__bf16*)cond, flows, (__bf16*)flows8_bf16, N, H, W, C);
+    E2_LAUNCH_CHECK("prop_cond");
+    return 0;
+}
+
 extern "C" int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld,
                                   const float* flow_a, const float* flow_b, int64_t flow_img_stride, void* cond,
                                   int32_t cond_dtype, float* flows, void* flows8_bf16, int32_t N, int32_t H, int32_t W,
@@ -667,11 +693,11 @@ extern "C" int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const f
     E2_REQUIRE(C % nv == 0, E2FGVI_EINVAL, "prop_cond: C must be a multiple of %d", nv);
     const long long total = (long long)N * H * W * (C / nv);
     if (cond_dtype == E2FGVI_BF16)
-        hipLaunchKernelGGL(prop_cond_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
+        hipLaunchKernelGGL((prop_cond_kernel<__bf16, float>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
                            feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, (__bf16*)cond, flows,
                            (__bf16*)flows8_bf16, N, H, W, C);
     else
-        hipLaunchKernelGGL(prop_cond_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
+        hipLaunchKernelGGL((prop_cond_kernel<float, float>), dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, feat_prop, fp_ld,
                            feat_n2, f2_ld, flow_a, flow_b, (long long)flow_img_stride, (float*)cond, flows,
                            (__bf16*)flows8_bf16, N, H, W, C);
     E2_LAUNCH_CHECK("prop_cond");

@@ -6,9 +6,9 @@ bytes live and which pipe multiplies them:
   * activations are bf16 NHWC tensors in HBM (half the traffic of the fp32 path), every conv / linear runs in
     csrc/conv_bf16x.hip (bf16 operands by LDS-DMA, v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogue);
   * kept in fp32: the SPyNet flow pyramid and the flows (sub-pixel sampling positions), the DCN offsets / masks (output of
-    conv_offset.6 incl. its 10 tanh + flow post-processing), the recurrent propagation features the deformable conv
-    and the warps sample from (backbone.2 writes them as fp32 AND as the bf16 copy the next convs read), the token
-    residual stream between transformer blocks (LayerNorm input), the decoder's last two tensors and the output frames;
+    conv_offset.6 incl. its 10 tanh + flow post-processing), the token residual stream between transformer blocks
+    (LayerNorm input) and the output frames; the recurrent propagation features are ONE bf16 tensor per step (conv source,
+    flow-warp source, and -- re-laid out [group][pixel][16] -- the deformable conv's gather source);
   * LayerNorm, window pooling, fold / unfold + GELU, SoftComp fold and the x2 upsamples read / write bf16 and compute
     in fp32 (typed variants of the fp32 kernels, csrc/misc.hip).
 """
@@ -22,6 +22,8 @@ from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_TANH, PackedConvX, Packed
 BF16 = torch.bfloat16
 TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
 DCN_PLANAR = os.environ.get("E2FGVI_DCN_PLANAR", "1") != "0"    # deformable conv gathers from [group][pixel][16] copies
+# flow-warp sources of the conv_offset condition: the bf16 copies of the propagated features (1) or fp32 ones written beside (0)
+PROP_BF16SRC = os.environ.get("E2FGVI_PROP_BF16SRC", "1") != "0"
 FC2_CONV = os.environ.get("E2FGVI_FC2_CONV", "1") != "0"     # FFN second Linear as a conv of the folded tensor
 
 
@@ -175,8 +177,9 @@ class BF16Path:
                 if i > 0:
                     flow_a = flows[0, i - 1]
                     flow_b = flows[0, i - 2] if i > 1 else None
-                    feat_n2 = hist[-2] if i > 1 else None
-                    cond, fl, fl8 = ops.prop_cond(hist[-1], feat_n2, flow_a, flow_b, img_stride, cond_dtype=BF16, flows8=True)
+                    warp = hist16 if PROP_BF16SRC else hist
+                    feat_n2 = warp[-2] if i > 1 else None
+                    cond, fl, fl8 = ops.prop_cond(warp[-1], feat_n2, flow_a, flow_b, img_stride, cond_dtype=BF16, flows8=True)
                     x = off[0]([(cond, 0), cur, (cond, ch), fl8], **lk)
                     x = off[1]([x], **lk)
                     x = off[2]([x], **lk)
@@ -187,7 +190,10 @@ class BF16Path:
                         aligned = dcn([hist16[-1], hist16[-2] if i > 1 else zero16], offs, out_dtype=BF16)
                 srcs = [cur, stores["backward_"][idx], aligned] if name == "forward_" else [cur, aligned]
                 y = bb[0](srcs, **lk)
-                hist.append(bb[1]([y], out_dtype=torch.float32, residual=aligned, out2=store16[idx]))
+                if PROP_BF16SRC:           # one bf16 result: conv source, warp source and (re-laid out) DCN source of later steps
+                    bb[1]([y], out=store16[idx], residual=aligned)
+                else:
+                    hist.append(bb[1]([y], out_dtype=torch.float32, residual=aligned, out2=store16[idx]))
                 hist16.append(store16[idx])
                 if DCN_PLANAR and i + 1 < l_t:
                     planar16.append(ops.to_planar16(store16[idx]))

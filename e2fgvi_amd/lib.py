@@ -117,6 +117,7 @@ SYMBOLS = {
     "e2fgvi_nchw_to_nhwc_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
     "e2fgvi_resize_bilinear_bf16": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_prop_cond_x": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i64, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_prop_cond_xs": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _fp, _fp, _i64, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_spynet_level_input_x": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp]),
     "e2fgvi_layernorm_x": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i64, _i32, _fp]),
     "e2fgvi_window_pool_x": (C.c_int, [_fp, _i32, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),

@@ -868,9 +868,10 @@ def prop_cond(feat_prop, feat_n2, flow_a, flow_b, flow_img_stride, cond=None, fl
               flows8=False):
     """flow_a / flow_b: tensors whose data_ptr is image 0's [H,W,2] flow; image n is at +n*flow_img_stride floats.
     cond_dtype=torch.bfloat16 writes the warped features as bf16 (bf16 data path); flows8=True additionally returns the
-    four flow values as a bf16 [N,H,W,8] conv source (channels 4..7 zero)."""
+    four flow values as a bf16 [N,H,W,8] conv source (channels 4..7 zero).  bf16 feat_prop / feat_n2 (with a bf16 cond):
+    the warp reads the bf16 copies of the features -- half the gather bytes."""
     lib = _L.load()
-    _chk(feat_prop, "feat_prop")
+    _chk_any(feat_prop, "feat_prop")
     N, H, W, Cc = feat_prop.shape
     if cond is None:
         cond = torch.empty((N, H, W, 2 * Cc), dtype=cond_dtype, device=feat_prop.device)
@@ -879,9 +880,9 @@ def prop_cond(feat_prop, feat_n2, flow_a, flow_b, flow_img_stride, cond=None, fl
     fl8 = torch.empty((N, H, W, 8), dtype=torch.bfloat16, device=feat_prop.device) if flows8 else None
     f2_ld = 0
     if flow_b is not None:
-        _chk(feat_n2, "feat_n2")
+        _chk(feat_n2, "feat_n2", feat_prop.dtype)
         f2_ld = feat_n2.shape[3]
-    _L.check(lib.e2fgvi_prop_cond_x(_ptr(feat_prop), Cc, _ptr(feat_n2) if flow_b is not None else None, f2_ld,
+    _L.check(lib.e2fgvi_prop_cond_xs(_ptr(feat_prop), Cc, _ptr(feat_n2) if flow_b is not None else None, f2_ld, _dt(feat_prop),
                                     C.c_void_p(flow_a.data_ptr()),
                                     C.c_void_p(flow_b.data_ptr()) if flow_b is not None else None,
                                     flow_img_stride, _ptr(cond), _dt(cond), _ptr(flows), _ptr(fl8), N, H, W, Cc, _stream()),

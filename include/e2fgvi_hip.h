@@ -383,6 +383,11 @@ int e2fgvi_resize_bilinear_bf16(const void* src, int32_t src_ld, void* dst, int3
 int e2fgvi_prop_cond_x(const float* feat_prop, int32_t fp_ld, const float* feat_n2, int32_t f2_ld, const float* flow_a,
                        const float* flow_b, int64_t flow_img_stride, void* cond, int32_t cond_dtype, float* flows,
                        void* flows8_bf16, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* ... with the warp sources of src_dtype: E2FGVI_F32 (= e2fgvi_prop_cond_x) or E2FGVI_BF16 (bf16 NHWC features, bf16 cond:
+ * half the gather bytes; the bf16 path warps the bf16 copies of the propagated features) */
+int e2fgvi_prop_cond_xs(const void* feat_prop, int32_t fp_ld, const void* feat_n2, int32_t f2_ld, int32_t src_dtype,
+                        const float* flow_a, const float* flow_b, int64_t flow_img_stride, void* cond, int32_t cond_dtype,
+                        float* flows, void* flows8_bf16, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 /* out_bf16 (optional): the 8 input channels again as bf16 [Np,h,w,8], the source of the level's bf16 conv stack */
 int e2fgvi_spynet_level_input_x(const float* pyr, const int32_t* ref_idx, const int32_t* supp_idx, const float* flow_prev,
                                 float* out, void* out_bf16, int32_t Np, int32_t h, int32_t w, void* stream);

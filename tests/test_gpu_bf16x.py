@@ -230,6 +230,15 @@ def test_typed_helper_kernels(dev):
     c32, fl32 = ops.prop_cond(fp, f2, fa, fb, 12 * 20 * 2)
     c16, fl, fl8 = ops.prop_cond(fp, f2, fa, fb, 12 * 20 * 2, cond_dtype=torch.bfloat16, flows8=True)
     assert torch.equal(c16, c32.bfloat16()) and torch.equal(fl, fl32) and torch.equal(fl8[..., :4], fl32.bfloat16()) and float(fl8[..., 4:].abs().max()) == 0
+    # bf16 warp sources (what the bf16 path passes): the same arithmetic on the bf16-rounded features; first step (no feat_n2) too
+    s16, fl_s, _ = ops.prop_cond(fp.bfloat16(), f2.bfloat16(), fa, fb, 12 * 20 * 2, cond_dtype=torch.bfloat16, flows8=True)
+    r32, _ = ops.prop_cond(fp.bfloat16().float(), f2.bfloat16().float(), fa, fb, 12 * 20 * 2)
+    assert torch.equal(s16, r32.bfloat16()) and torch.equal(fl_s, fl32)
+    s1, _, _ = ops.prop_cond(fp.bfloat16(), None, fa, None, 12 * 20 * 2, cond_dtype=torch.bfloat16, flows8=True)
+    r1, _ = ops.prop_cond(fp.bfloat16().float(), None, fa, None, 12 * 20 * 2)
+    assert torch.equal(s1, r1.bfloat16())
+    with pytest.raises(Exception):
+        ops.prop_cond(fp.bfloat16(), f2.bfloat16(), fa, fb, 12 * 20 * 2)        # bf16 sources need a bf16 cond
 
 
 @pytest.mark.parametrize("model,hw,t,lt", [("e2fgvi_hq", (120, 216), 4, 3), ("e2fgvi", (240, 432), 3, 3), ("e2fgvi_hq", (60, 108), 3, 1)])
