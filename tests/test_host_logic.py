@@ -103,6 +103,31 @@ def test_abi_exports_every_declared_symbol():
     assert lib.load().e2fgvi_abi_version() == 4
 
 
+def test_packing_size_functions_and_argument_checks_run_without_a_gpu():
+    """host side of the C ABI: packed-weight sizes of the round-2 layouts and the error path (no launches involved)"""
+    from e2fgvi_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.skip("library not built yet (python -m e2fgvi_amd.build)")
+    L = lib.load()
+    # tap-packed K-steps: (tap, 8-channel chunk) pairs cut into steps of 8 chunks of 64 x Npad elements
+    assert L.e2fgvi_packed_conv_weight_bf16x_taps_size(512, 7, 7, 40) == 31 * 64 * 512       # FFN fc2 as a conv: 49 * 5 / 8 -> 31 steps
+    assert L.e2fgvi_packed_conv_weight_bf16x_taps_size(32, 7, 7, 8) == 7 * 64 * 32           # SPyNet .0: 8 taps per step
+    assert L.e2fgvi_packed_conv_weight_bf16x_taps_size(64, 3, 3, 24) == 4 * 64 * 64          # 9 taps x 3 chunks -> 4 steps
+    assert L.e2fgvi_packed_conv_weight_f32x_taps_size(512, 7, 7, 40) == 62 * 32 * 512        # fp32: chunks of 4 channels, steps of 32
+    assert L.e2fgvi_packed_conv_weight_bf16x_taps_size(64, 3, 3, 64) < 0                      # a full K-step per tap: nothing to pack
+    assert L.e2fgvi_packed_conv_weight_bf16x_taps_size(64, 1, 1, 16) < 0                      # one tap
+    assert b"56" in L.e2fgvi_last_error()
+    # decoder tail: only 64 -> 3 is built
+    assert L.e2fgvi_packed_tail_weight_size(3, 64) == 64 * 32
+    assert L.e2fgvi_packed_tail_weight_size(4, 64) < 0
+    assert b"64 -> 3" in L.e2fgvi_last_error()
+    # wide-tile Winograd: (fy + 2) * 6 positions, channels in chunks of 8, couts padded to 32
+    arr = (ctypes.c_int32 * 1)(128)
+    n2, n4 = L.e2fgvi_packed_winograd4_weight_size(256, 1, 1, arr, 2), L.e2fgvi_packed_winograd4_weight_size(256, 1, 1, arr, 4)
+    assert n2 == 24 * 128 * 256 and n4 == 36 * 128 * 256
+    assert L.e2fgvi_packed_winograd4_weight_size(256, 1, 1, arr, 3) < 0
+
+
 def test_desc_struct_sizes_are_plain_c():
     from e2fgvi_amd import lib
     # pointers 8 bytes, int32 fields: sizes must be multiples of 8 and stable
