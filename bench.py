@@ -98,6 +98,67 @@ def cpu_baseline(sd, model, H, W, t, lt):
                                      "one un-warmed forward (%.1f s)" % dt, ts)}
 
 
+def time_local(net, x, lt, steps, warmup, use_graph=True):
+    """`steps` forwards of this GPU's clips replayed from a HIP graph, no collective: (wall seconds, device ms, graphed)"""
+    from e2fgvi_amd import runner
+    step = runner.ShardedStep(net, x, lt, group_world=1, use_graph=use_graph)
+    for _ in range(max(warmup, 2)):                   # the second call captures the graph
+        step.run()
+    step.finish()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step.run()
+    step.finish()
+    ev1.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1), bool(step.graphed)
+
+
+SECONDARY = [   # (model, H, W, t, precision, steps, warmup): BASELINE.json configs[3] and [4] on ONE GPU
+    ("e2fgvi_hq", 720, 1296, 10, "bf16", 20, 3),
+    ("e2fgvi_hq", 1080, 1944, 20, "bf16", 5, 2),
+]
+
+
+def secondary_line(dev, model, H, W, t, precision, steps, warmup):
+    """One more configuration timed in the same process after the headline (inputs resident, HIP-graph replay, one clip
+    per forward, all frames local): BASELINE.json configs[3] / [4], which name e2fgvi_hq at 720p / 1080p with bf16 MFMA."""
+    import gc
+    import importlib
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(synth_state_dict(model, "default", 0))
+    net = net.to(dev).eval()
+    net.precision = precision
+    x = synth_clip(1, t, H, W, seed=0, smooth=False)[0].to(dev)
+    net(x, t)
+    torch.cuda.synchronize()
+    gflop_alg, gflop_issued, nlaunch = traced_work(net, x, t)
+    elapsed, dev_ms, graphed = time_local(net, x, t, steps, warmup)
+    secs = dev_ms * 1e-3 / steps
+    peak = PEAK_TFLOPS[precision]
+    line = {"config": {"workload": "BASELINE.json configs[%d]: %s %dx%d T=%d l_t=%d, 1 clip per forward on one GPU, random-init "
+                                   "weights, torch.rand frames + box mask (SURVEY.md 8d)" % (3 if t <= 10 else 4, model, W, H, t, t),
+                       "precision": precision, "hip_graph": graphed},
+            "metric": "inpainted frames/sec at %dx%d T=%d" % (W, H, t), "value": round(t * steps / elapsed, 3), "unit": "frames/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "dtype": "f32" if precision == "fp32" else "bf16",
+            "roofline": {"bound": "mfma", "achieved": round(gflop_issued / secs / 1e3, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(gflop_issued / secs / 1e3 / peak, 4),
+                         "achieved_algorithmic": round(gflop_alg / secs / 1e3, 2),
+                         "frac_algorithmic": round(gflop_alg / secs / 1e3 / peak, 4),
+                         "gflop_per_forward": {"algorithmic": round(gflop_alg, 1), "issued": round(gflop_issued, 1),
+                                               "mfma_launches": nlaunch}},
+            "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+    del net, x
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +175,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (self-test)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the BASELINE configs[3] / [4] lines (e2fgvi_hq 720x1296 T=10 and 1080x1944 T=20, bf16) that the "
+                         "default single-GPU invocation times after the headline and attaches as `secondary`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +213,16 @@ def main():
     net(x, lt)
     torch.cuda.synchronize()
     gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)      # per forward of b clips
+    same_work = None
+    if world > 1 or args.force_dist:
+        # the like-for-like single-GPU number of this job's per-GPU work: the same clips, the same HIP-graph replay, no
+        # collective, timed on this GPU before RCCL comes up (a scaling efficiency can then be read off ONE record)
+        sw_steps = max(3, min(args.steps, 10))
+        el, _, _ = time_local(net, x, lt, sw_steps, 2, use_graph=not args.no_graph)
+        same_work = {"value": round(b * t * sw_steps / el, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el / sw_steps, 3),
+                     "steps": sw_steps, "note": "rank 0's GPU alone on its own share of the job (%d clips per forward, graph "
+                                                "replay, no collective), timed before init_process_group: the N = 1 point of "
+                                                "this workload; efficiency at N = value / (N x this)" % b}
 
     dist = None
     if world > 1 or args.force_dist:
@@ -234,7 +308,7 @@ def main():
     elif b == 1 and (t, lt) == (10, 10) and hq and (H, W) == (720, 1296) and args.precision == "bf16":
         traffic_cfg = "_hq720_bf16"
     if traffic_cfg is not None:
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             tfile = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (tag, traffic_cfg))
             if os.path.exists(tfile):
                 try:
@@ -251,7 +325,7 @@ def main():
         if not hq and args.precision == "fp32":
             dom = runner.dominant_kernel_probe(net, dev)
             dom["traffic"] = None
-            for tag in ("r02", "r01"):
+            for tag in ("r03", "r02", "r01"):
                 dfile = os.path.join(ROOT, "profiles", "%s_dominant_kernel_traffic.json" % tag)
                 if os.path.exists(dfile):
                     try:
@@ -263,9 +337,22 @@ def main():
             out["roofline"]["dominant_kernel"] = dom
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.model, H, W, t, lt)
+    if same_work is not None:
+        out["single_gpu_same_work"] = same_work
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    default_headline = (world == 1 and not args.force_dist and not hq and args.precision == "fp32" and b == 1 and (t, lt) == (10, 10))
+    if rank == 0 and default_headline and not args.no_secondary:
+        del step, net, x
+        torch.cuda.empty_cache()
+        out["secondary"] = []
+        for cfg in SECONDARY:
+            try:
+                out["secondary"].append(secondary_line(dev, *cfg))
+            except Exception as e:                    # the headline line must survive a failure here
+                out["secondary"].append({"config": {"workload": "%s %dx%d T=%d %s" % (cfg[0], cfg[2], cfg[1], cfg[3], cfg[4])},
+                                         "error": str(e).splitlines()[0][:300]})
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)        # C stdio first (RCCL's banner), so that the JSON line is the last line on stdout

@@ -20,7 +20,7 @@ NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # words while the other waves of the SAME workgroup stream LDS-fed bf16 MFMA tiles -- with packed math the 64-row / two-K-group
 # tile returned wrong rows 24-31 (lanes 48-63 of the sampler wave) in a few launches per hundred.
 UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
-         ("conv_bf16.hip", "conv_bf16.o", []), ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", []),
+         ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", []),
          ("mdcn.hip", "mdcn.o", NOPK), ("attention.hip", "attention.o", []),
          ("attention_bf16.hip", "attention_bf16.o", []), ("misc.hip", "misc.o", NOPK),
          ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]

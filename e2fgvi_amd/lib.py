@@ -68,9 +68,6 @@ SYMBOLS = {
     "e2fgvi_conv2d_nhwc_nopk": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "e2fgvi_packed_conv_weight_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32]),
     "e2fgvi_pack_conv_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _fp]),
-    "e2fgvi_packed_conv_weight_bf16_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
-    "e2fgvi_pack_conv_weight_bf16": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
-    "e2fgvi_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "e2fgvi_conv2d_bf16x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
     "e2fgvi_packed_conv_weight_bf16x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_bf16x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),

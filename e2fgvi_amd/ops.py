@@ -56,23 +56,62 @@ _W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
 XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
 XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
-# E2FGVI_TUNE_FILE=<path>: the decisions are read from / appended to that file, so that a profiled run (rocprofv3) uses
-# exactly the tile choices of the benchmark run that wrote it and contains no tuning launches (tools/profile.sh)
+# The decisions are persisted: read from / appended to a per-library-build file under the user's cache directory, so that
+# a served model pays the ~20 tuning launches per layer and size class once per machine, every process (and every rank of
+# a sharded job) replays the same tiles, and a profiled run (rocprofv3, tools/profile.sh) contains no tuning launches.
+#   E2FGVI_TUNE_FILE=<path>   use that file instead          E2FGVI_TUNE_FILE=0 (or empty)   do not persist
+# The default file name carries the size and mtime of libe2fgvi_hip.so: a rebuilt library starts a new table.
+
+
+def _default_tune_file():
+    try:
+        st = os.stat(_L.LIB_PATH)
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        d = os.path.join(base, "e2fgvi_amd")
+        os.makedirs(d, exist_ok=True)
+        return os.path.join(d, "tiles_%x_%x.txt" % (st.st_size, int(st.st_mtime)))
+    except OSError:
+        return None
+
+
 _TUNE_FILE = os.environ.get("E2FGVI_TUNE_FILE")
+if _TUNE_FILE is None:
+    _TUNE_FILE = _default_tune_file()
+elif _TUNE_FILE in ("", "0"):
+    _TUNE_FILE = None
 if _TUNE_FILE and os.path.exists(_TUNE_FILE):
     import ast
     for _line in open(_TUNE_FILE):
-        if _line.strip():
+        try:
             _k, _v = ast.literal_eval(_line)
             _TUNED[_k] = _v
+        except Exception:           # a torn line of a concurrent writer: that geometry is simply tuned again
+            pass
 
 
 def _remember(key, tile):
     _TUNED[key] = tile
     if _TUNE_FILE:
-        with open(_TUNE_FILE, "a") as fh:
-            fh.write(repr((key, tile)) + "\n")
+        try:
+            with open(_TUNE_FILE, "a") as fh:
+                fh.write(repr((key, tile)) + "\n")
+        except OSError:
+            pass
     return tile
+
+
+def sync_tile_decisions(group=None, src=0):
+    """Sharded jobs: every rank adopts rank `src`'s tile table, so that all ranks run the same kernels in the same
+    accumulation order (tile choices are timed per process and the row-shift / LDS-DMA alternatives order their K loop
+    differently: without this the ranks' frames could differ in the last bits).  Call after the first (tuning) forward."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return False
+    box = [dict(_TUNED) if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    _TUNED.clear()
+    _TUNED.update(box[0])
+    return True
 
 
 class PackedConv:
@@ -83,8 +122,9 @@ class PackedConv:
     """
 
     def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32", algo="igemm"):
-        """precision: "fp32" (default: fp32 MFMA, bit-equivalent to an fp32 FMA chain) or "bf16" (optional mode for
-        the HQ configurations: bf16 MFMA, fp32 accumulate, fp32 tensors in HBM).
+        """precision: "fp32" only (fp32 MFMA, bit-equivalent to an fp32 FMA chain); the bf16 data path has its own layer
+        class, PackedConvX (round 1's "fp32 tensors, bf16 products" mode moved to tools/probe/ as the cross-stream
+        reproducer's aggressor).
         algo: "igemm" (implicit GEMM), "winograd" (fp32 F(2x2,3x3) only; 3x3 / stride 1 / pad 1, every cpg % 4 == 0,
         even H and W at call time, NHWC output) or "auto" (both packings; Winograd whenever a call qualifies)."""
         lib = _L.load()
@@ -96,8 +136,8 @@ class PackedConv:
         if sum(self.cpg) != cin_g:
             raise ValueError("sum(cpg)=%d != weight input channels %d" % (sum(self.cpg), cin_g))
         self.groups, self.stride, self.pad = groups, stride, pad
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision != "fp32":
+            raise ValueError("PackedConv is the fp32 layer; the bf16 data path uses PackedConvX")
         self.precision = precision
         self.tune = False          # time TUNE_CANDIDATES on the first call of every new input size and keep the fastest
         self.name = "conv"         # layer name for launch traces (the engine sets the checkpoint key)
@@ -126,17 +166,6 @@ class PackedConv:
                 self.wpacked = None
                 self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
                 return
-        if precision == "bf16":
-            self.bk = 32
-            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
-            n = lib.e2fgvi_packed_conv_weight_bf16_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
-            if n < 0:
-                _L.check(int(n), "packed_conv_weight_bf16_size")
-            self.wpacked = torch.empty(int(n), dtype=torch.bfloat16, device=w.device)
-            _L.check(lib.e2fgvi_pack_conv_weight_bf16(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
-                                                      len(self.cpg), arr, _stream()), "pack_conv_weight_bf16")
-            self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
-            return
         if bk is None:
             # K-chunk granule: 32 unless padding every source up to a multiple of 32 wastes more than ~8 % of K
             pad32 = sum((c + 31) // 32 * 32 for c in self.cpg)
@@ -246,10 +275,10 @@ class PackedConv:
             issued = pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * 4       # 16 positions per 4 pixels
             kern = "conv_wino<%d,%d>" % (mt, bn)
         else:
-            g = 32 if self.precision == "bf16" else self.bk
+            g = self.bk
             cin_p = sum(-(-c // g) * g for c in self.cpg)
             issued = N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2
-            kern = "conv_igemm_bf16" if self.precision == "bf16" else "conv_igemm/halo tile=%d" % tile
+            kern = "conv_igemm/halo tile=%d" % tile
         return dict(layer=self.name, kernel=kern, shape="N%d %dx%d %d->%d k%d s%d g%d" % (
             N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups), macs=macs, issued=issued)
 
@@ -351,8 +380,6 @@ class PackedConv:
             _L.check(lib.e2fgvi_conv3x3_winograd4(C.byref(d), w4[0], _stream()), "conv3x3_winograd4")
         elif use_wino:
             _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
-        elif self.precision == "bf16":
-            _L.check(lib.e2fgvi_conv2d_nhwc_bf16(C.byref(d), _stream()), "conv2d_nhwc_bf16")
         elif self.nopk:
             _L.check(lib.e2fgvi_conv2d_nhwc_nopk(C.byref(d), _stream()), "conv2d_nhwc_nopk")
         else:

@@ -127,15 +127,6 @@ int e2fgvi_pack_conv_weight(const float* w, float* wpacked, int32_t Cout, int32_
                             int32_t KH, int32_t KW, int32_t nsrc, const int32_t* src_cpg,
                             int32_t bk, void* stream);
 
-/* Optional bf16-MFMA precision mode of the same operator (BASELINE.json HQ configurations): fp32 activations are
- * rounded to bf16 on their way into LDS, weights are packed as bf16 (sources padded to 32 channels), products run on
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 epilogue and output.  Same descriptor (bk is ignored). */
-int64_t e2fgvi_packed_conv_weight_bf16_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
-                                            int32_t nsrc, const int32_t* src_cpg);   /* in bf16 elements */
-int e2fgvi_pack_conv_weight_bf16(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH,
-                                 int32_t KW, int32_t nsrc, const int32_t* src_cpg, void* stream);
-int e2fgvi_conv2d_nhwc_bf16(const e2fgvi_conv_desc* d, void* stream);
-
 /* Winograd F(2x2,3x3) form of the same operator for 3x3 / stride 1 / pad 1 layers with even H, W (the encoder's
  * stride-1 layers e2fgvi.py:77-93, the decoder convs :112-150, SoftComp's HQ bias conv e2fgvi_hq tfocal :67-79): fp32
  * arithmetic on the fp32 MFMA pipe, 16 instead of 36 multiplies per 2x2 outputs.  Also the propagation convs

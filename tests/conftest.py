@@ -1,5 +1,6 @@
 import os
 import sys
+import zlib
 
 import pytest
 
@@ -13,6 +14,36 @@ def pytest_configure(config):
     # the oracle runs on the host CPU: torch's intra-op pool collapses with hundreds of threads on small ops
     torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# Run order of the GPU suite: the north-star parity checks first (the whole forward against the oracle and the
+# real-reference fixtures at the BASELINE sizes, then the stages, then the fp32 kernels those are made of), the section-8(f)
+# rows after them, the bf16 data path and the tuning alternatives last -- so that `pytest -x` can never again stop in an
+# auxiliary kernel test before the fp32 1e-3 checks have run (round 2's driver record).
+_FILE_ORDER = ["test_gpu_model.py", "test_gpu_ops.py", "test_gpu_tail.py", "test_gpu_wino4.py", "test_gpu_fused.py",
+               "test_video_driver.py", "test_tennis.py", "test_gpu_bench_lines.py", "test_gpu_bf16x.py"]
+_FIRST = ["test_full_size_against_oracle", "test_hip_matches_reference_golden", "test_end_to_end", "test_stage_"]
+
+
+def _rank(item):
+    fname = os.path.basename(str(item.fspath))
+    f = _FILE_ORDER.index(fname) if fname in _FILE_ORDER else len(_FILE_ORDER)
+    n = next((i for i, p in enumerate(_FIRST) if item.name.startswith(p)), len(_FIRST))
+    return (f, n)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    items.sort(key=_rank)          # stable: the definition order inside a file is kept otherwise
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_global_rng(request):
+    """tests that draw from torch's global generators (module initialisers, `device=` randn) see the same numbers in every
+    process: seeded from the test's node id with crc32 (never Python's salted hash()), shifted by E2FGVI_TEST_SEED"""
+    import torch
+    from tests.util import SEED_SHIFT
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) % 100000 + 100003 * SEED_SHIFT)
+    yield
 
 
 @pytest.fixture(scope="session")

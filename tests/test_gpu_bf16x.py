@@ -8,15 +8,14 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import assert_close, assert_close_bf16, nchw, nhwc
+from tests.util import assert_bound, assert_close, assert_close_bf16, fp32_tol, gen as _gen, name_seed, nchw, nhwc
 
 pytestmark = pytest.mark.gpu
 
 
-def _gen(seed):
-    g = torch.Generator()
-    g.manual_seed(seed)
-    return g
+def conv64(x, w, b=None, **kw):
+    """reference convolution accumulated in fp64: the comparison then sees only the kernel's own fp32 rounding"""
+    return F.conv2d(x.double(), w.double(), None if b is None else b.double(), **kw)
 
 
 def _act(x, act, slope):
@@ -63,7 +62,7 @@ CASES = [
 def test_conv_bf16x(dev, case):
     from e2fgvi_amd import ops
     name, N, H, W, cpg, groups, Cout, k, stride, pad, tiles = case
-    g = _gen(abs(hash(name)) % 1000)
+    g = _gen(name_seed(name))
     cin = sum(cpg) * groups
     w = torch.randn(Cout, sum(cpg), k, k, generator=g) / math.sqrt(sum(cpg) * k * k)
     bias = torch.randn(Cout, generator=g) * 0.1
@@ -77,25 +76,26 @@ def test_conv_bf16x(dev, case):
     # virtual concat: group gi takes channels [gi*c, (gi+1)*c) of every source, in source order
     x = torch.cat([torch.cat([p_[..., gi * c:(gi + 1) * c] for p_, c in zip(parts, cpg)], -1) for gi in range(groups)], -1)
     wq = w.bfloat16().float()
-    ref0 = F.conv2d(nchw(x), wq, bias, stride=stride, padding=pad, groups=groups)
+    ref0 = conv64(nchw(x), wq, bias, stride=stride, padding=pad, groups=groups)
+    tol = fp32_tol(sum(cpg) * k * k, floor=3e-5)
     layer = ops.PackedConvX(w.to(dev), bias.to(dev), cpg, groups=groups, stride=stride, pad=pad)
     src_d = [(s.to(dev), 8) for s in srcs]
     res32 = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
     res16 = res32.bfloat16()
     for tile in tiles:
         out = layer(src_d, out_dtype=torch.float32, act=ops.ACT_LRELU, slope=0.1, tile=tile)
-        assert_close(nchw(out.cpu()), F.leaky_relu(ref0, 0.1), 3e-5, "%s tile %d fp32 out" % (name, tile))
+        assert_close(nchw(out.cpu()), F.leaky_relu(ref0, 0.1), tol, "%s tile %d fp32 out" % (name, tile))
     out2 = torch.empty(N, ref0.shape[2], ref0.shape[3], Cout, dtype=torch.bfloat16, device=dev)
     out = layer(src_d, out_dtype=torch.float32, residual=res32.to(dev), act=ops.ACT_NONE, out2=out2)
     ref = ref0 + nchw(res32)
-    assert_close(nchw(out.cpu()), ref, 3e-5, name + " fp32 residual")
+    assert_close(nchw(out.cpu()), ref, tol, name + " fp32 residual")
     assert torch.equal(out2.cpu(), out.cpu().bfloat16()), name + ": out2 is not the bf16 rounding of out"
     out = layer(src_d, residual=res16.to(dev), act=ops.ACT_RELU)
     assert out.dtype == torch.bfloat16
     assert_close_bf16(nchw(out.float().cpu()), F.relu(ref0 + nchw(res16.float())), name + " bf16 out, bf16 residual", abs_rms=1e-4)
     if groups == 1:                                     # fp32 NCHW store (the decoder's last layer)
         outn = layer(src_d, act=ops.ACT_TANH, out_nchw=True)
-        assert_close(outn.cpu(), torch.tanh(ref0), 3e-5, name + " NCHW fp32 out")
+        assert_close(outn.cpu(), torch.tanh(ref0), tol, name + " NCHW fp32 out")
     # into a channel slice of a wider destination
     wide = torch.zeros(N, ref0.shape[2], ref0.shape[3], Cout + 24, dtype=torch.bfloat16, device=dev)
     layer(src_d, out=wide, out_coff=8)
@@ -112,9 +112,9 @@ def test_linear_bf16x(dev):
         x = torch.randn(rows, cin, generator=g).bfloat16()
         res = torch.randn(rows, cout, generator=g)
         layer = ops.PackedLinearX(w.to(dev), b.to(dev))
-        ref = F.linear(x.float(), w.bfloat16().float(), b) + res
+        ref = F.linear(x.double(), w.bfloat16().double(), b.double()) + res
         out = layer(x.to(dev), out_dtype=torch.float32, residual=res.to(dev))
-        assert_close(out.cpu(), ref, 3e-5, "linear %dx%d->%d" % (rows, cin, cout))
+        assert_close(out.cpu(), ref, fp32_tol(cin, floor=3e-5), "linear %dx%d->%d" % (rows, cin, cout))
         out16 = layer(x.to(dev))
         assert_close_bf16(out16.float().cpu(), ref - res, "linear bf16 out", abs_rms=1e-4)
 
@@ -128,7 +128,7 @@ def test_conv_bf16x_dcn_postprocess(dev):
     w = torch.randn(27 * dg, 128, 3, 3, generator=g) * (0.3 / math.sqrt(128 * 9))
     b = torch.randn(27 * dg, generator=g) * 0.2
     fl = torch.randn(N, H, W, 4, generator=g) * 3
-    raw = F.conv2d(nchw(x.float()), w.bfloat16().float(), b, padding=1)
+    raw = conv64(nchw(x.float()), w.bfloat16().float(), b, padding=1)
     o1, o2, m = torch.chunk(raw, 3, 1)
     f1, f2 = nchw(fl)[:, :2], nchw(fl)[:, 2:]
     off = 10 * torch.tanh(torch.cat([o1, o2], 1))
@@ -181,8 +181,11 @@ def test_focal_attention_bf16(dev, B, T, fh, fw):
     rows = qkv.shape[0]
     out = ops.focal_attention_bf16(both[:rows], both[rows:], torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev), B, T, fh, fw)
     assert out.dtype == torch.bfloat16
-    # elementwise: the bf16 rounding of the output (2^-9 relative) + the bf16 rounding of the probabilities
-    assert_close_bf16(out, ref.reshape(-1, Cc), "bf16 attention %dx%d" % (fh, fw), ulps=1.0, abs_rms=6e-3)
+    # elementwise: the bf16 rounding of the output (<= 2^-8 relative) + the bf16 rounding of the probabilities: every p_j carries
+    # an independent relative error of rms 2^-9 / sqrt(3), so o = sum p_j v_j is off by rms 1.1e-3 x rms(o) (p spread over
+    # T*210 keys, v i.i.d.); the maximum over the 1e6 ... 2e7 outputs of a case sits 5-5.5 sigma out = 6e-3 x rms (measured
+    # 5.4-6.7e-3 over 4 data sets, tools/gpu_suite_soak.sh); allowed: twice that
+    assert_close_bf16(out, ref.reshape(-1, Cc), "bf16 attention %dx%d T=%d" % (fh, fw, T), ulps=1.0, abs_rms=1.2e-2)
 
 
 def test_typed_helper_kernels(dev):
@@ -244,8 +247,9 @@ def test_typed_helper_kernels(dev):
 @pytest.mark.parametrize("model,hw,t,lt", [("e2fgvi_hq", (120, 216), 4, 3), ("e2fgvi", (240, 432), 3, 3), ("e2fgvi_hq", (60, 108), 3, 1)])
 def test_bf16_path_end_to_end(dev, model, hw, t, lt):
     """bf16 data path against the fp32 CPU oracle.  Not the 1e-3 parity configuration: every activation tensor is rounded
-    to bf16 (2^-9 relative) ~45 times between the frames and the output.  Bound: max abs <= 2.5e-2
-    on frames in [-1,1] and <= 6 % of the output rms; the fp32-kept flows stay within the fp32 tolerance."""
+    to bf16 (2^-9 relative) ~45 times between the frames and the output.  Bound: max abs <= 1e-2
+    on frames in [-1,1] and rms of the difference <= 2 % of the output rms (sqrt(45) * 2^-9 = 1.3 % for independent
+    roundings; measured 0.9-1.1 %, max abs 3.8-4.6e-3); the fp32-kept flows stay within 5e-2 px."""
     import importlib
     from tests.test_gpu_model import _setup
     from tests.util import err
@@ -256,13 +260,16 @@ def test_bf16_path_end_to_end(dev, model, hw, t, lt):
     net.precision = "bf16"
     got, (ff, fb) = net(x.to(dev), lt)
     d, r = err(got, out)
-    print("bf16 path %s %s: max abs %.3e (%.2e x rms)" % (model, hw, d, r))
-    assert torch.isfinite(got).all() and d <= 2.5e-2 and r <= 6e-2
+    rd = ((got.cpu().double() - out.double()).pow(2).mean().sqrt() / out.double().pow(2).mean().sqrt()).item()
+    print("bf16 path %s %s: max abs %.3e (%.2e x rms), rms of the difference %.2e x rms" % (model, hw, d, r, rd))
+    assert torch.isfinite(got).all()
+    assert_bound(d, 1e-2, "bf16 e2e %s %s max abs" % (model, hw))
+    assert_bound(rd, 2e-2, "bf16 e2e %s %s rms of difference / rms" % (model, hw))
     if lt > 1:
         # SPyNet's conv stacks run on bf16 MFMA (warps, pyramid and the flow sums stay fp32): a few 1e-2 px
         df = max(err(ff, flows[0])[0], err(fb, flows[1])[0])
         print("          flows: max abs %.3e px (max |flow| %.2f)" % (df, flows[0].abs().max().item()))
-        assert df <= 5e-2 * max(1.0, flows[0].abs().max().item() / 4)
+        assert_bound(df, 5e-2 * max(1.0, flows[0].abs().max().item() / 4), "bf16 e2e %s %s flows px" % (model, hw))
     got2, _ = net(x.to(dev), lt)
     assert torch.equal(got, got2), "bf16 path is not deterministic (two streams)"
 
@@ -271,7 +278,8 @@ def test_bf16_path_end_to_end(dev, model, hw, t, lt):
 def test_bf16_path_against_reference_golden(dev, fixture):
     """The bf16 data path at the BASELINE HQ resolutions (720x1296: 12x12 window grid, 1080x1944: 18x18) against the
     sub-sampled outputs of the REAL reference (tests/golden/make_golden.py) -- the same bound as at the small sizes
-    (max abs <= 2.5e-2 on frames in [-1,1], <= 6 % of the reference's rms; flows <= 5e-2 px)."""
+    (DESIGN.md section 4: max abs <= 1e-2 on frames in [-1,1], rms of the difference <= 2 % of the reference's rms;
+    flows <= 5e-2 px; measured 4.3-4.6e-3 / 0.86 %)."""
     import importlib
     import os
     import numpy as np
@@ -290,10 +298,12 @@ def test_bf16_path_against_reference_golden(dev, fixture):
     d, rms = np.abs(diff).max(), float(z["out_stats"][2])
     print("bf16 path vs reference %s: max abs %.3e, rms of the difference %.2e x rms(reference)"
           % (fixture, d, np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms))
-    assert np.isfinite(out.numpy()).all() and d <= 2.5e-2 and np.sqrt((diff.astype(np.float64) ** 2).mean()) <= 6e-2 * rms
+    assert np.isfinite(out.numpy()).all()
+    assert_bound(d, 1e-2, "bf16 golden %s max abs" % fixture)
+    assert_bound(np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms, 2e-2, "bf16 golden %s rms of difference / rms" % fixture)
     fmax = max(1.0, float(z["flow_fwd_stats"][3]))
-    assert np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max() <= 5e-2 * max(1.0, fmax / 4)
-    assert np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max() <= 5e-2 * max(1.0, fmax / 4)
+    assert_bound(np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max(), 5e-2 * max(1.0, fmax / 4), "bf16 golden %s flow fwd" % fixture)
+    assert_bound(np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max(), 5e-2 * max(1.0, fmax / 4), "bf16 golden %s flow bwd" % fixture)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 101, 106])
@@ -334,7 +344,7 @@ def test_mdcn_bf16_mfma(dev, tile):
 
 @pytest.mark.parametrize("tile", [1, 4, 5, 6])
 def test_mdcn_reruns_are_bit_identical(dev, tile):
-    """20 launches of the same deformable conv must agree bit for bit.  Guards the packed-fp32 hazard of DESIGN.md "Stream
+    """200 launches of the same deformable conv must agree bit for bit (a 3 % per-launch event is missed with p < 1 %).  Guards the packed-fp32 hazard of DESIGN.md "Stream
     overlap" INSIDE one workgroup: mdcn.hip's sampler waves do arithmetic on freshly loaded offset / mask / flow words beside
     waves that stream LDS-fed bf16 MFMA tiles; built with packed-fp32 VALU the 64-row two-K-group tile (6) returned wrong rows
     24-31 (lanes 48-63 of the sampler wave) in a few launches per hundred -- the unit is built without them (build.py)."""
@@ -348,7 +358,7 @@ def test_mdcn_reruns_are_bit_identical(dev, tile):
     w = (torch.randn(Co, 256, 3, 3, generator=g) / 48).to(dev)
     layer = ops.PackedDcn(w, torch.randn(Co, generator=g).to(dev), dg, pad=1, mfma="bf16")
     ref = layer([a, c], raw, flows=fl, tile=tile)
-    for _ in range(20):
+    for _ in range(200):
         assert torch.equal(layer([a, c], raw, flows=fl, tile=tile), ref)
 
 
@@ -395,7 +405,7 @@ def test_conv_f32x(dev, case):
     layers) against torch fp32 conv2d: fp32 tolerance."""
     from e2fgvi_amd import ops
     name, N, H, W, cpg, groups, Cout, k, stride, pad, tiles = case
-    g = _gen(abs(hash(name)) % 1000 + 7)
+    g = _gen(name_seed(name, 7))
     w = torch.randn(Cout, sum(cpg), k, k, generator=g) / math.sqrt(sum(cpg) * k * k)
     bias = torch.randn(Cout, generator=g) * 0.1
     srcs, parts = [], []
@@ -404,14 +414,14 @@ def test_conv_f32x(dev, case):
         srcs.append(t)
         parts.append(t[..., 4:4 + c * groups])
     x = torch.cat([torch.cat([p_[..., gi * c:(gi + 1) * c] for p_, c in zip(parts, cpg)], -1) for gi in range(groups)], -1)
-    ref0 = F.conv2d(nchw(x), w, bias, stride=stride, padding=pad, groups=groups)
+    ref0 = conv64(nchw(x), w, bias, stride=stride, padding=pad, groups=groups)
     layer = ops.PackedConvX(w.to(dev), bias.to(dev), cpg, groups=groups, stride=stride, pad=pad, dtype=torch.float32)
     src_d = [(s.to(dev), 4) for s in srcs]
     res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
     for tile in [t for t in tiles if t < 10]:
         out = layer(src_d, residual=res.to(dev), act=ops.ACT_LRELU, slope=0.1, tile=tile)
         assert out.dtype == torch.float32
-        assert_close(nchw(out.cpu()), F.leaky_relu(ref0 + nchw(res), 0.1), 2e-5, "%s f32x tile %d" % (name, tile))
+        assert_close(nchw(out.cpu()), F.leaky_relu(ref0 + nchw(res), 0.1), fp32_tol(sum(cpg) * k * k), "%s f32x tile %d" % (name, tile))
 
 
 F32_TAP_CASES = [
@@ -427,11 +437,11 @@ def test_conv_f32x_tap_packed(dev, case):
     """tap-packed K-steps on fp32 operands (chunks of 4 channels) against torch fp32 conv2d, and against the unpacked layout"""
     from e2fgvi_amd import ops
     name, N, H, W, cin, Cout, k, stride, pad, tiles = case
-    g = _gen(abs(hash(name)) % 1000 + 11)
+    g = _gen(name_seed(name, 11))
     w = torch.randn(Cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
     bias = torch.randn(Cout, generator=g) * 0.1
     wide = torch.randn(N, H, W, cin + 8, generator=g)
-    ref0 = F.conv2d(nchw(wide[..., 4:4 + cin]), w, bias, stride=stride, padding=pad)
+    ref0 = conv64(nchw(wide[..., 4:4 + cin]), w, bias, stride=stride, padding=pad)
     layer = ops.PackedConvX(w.to(dev), bias.to(dev), [cin], stride=stride, pad=pad, dtype=torch.float32, taps=True)
     plain = ops.PackedConvX(w.to(dev), bias.to(dev), [cin], stride=stride, pad=pad, dtype=torch.float32)
     assert layer.taps and not plain.taps and layer.wpacked.numel() < plain.wpacked.numel()
@@ -439,8 +449,8 @@ def test_conv_f32x_tap_packed(dev, case):
     src = [(wide.to(dev), 4)]
     for tile in tiles:
         out = layer(src, residual=res.to(dev), tile=tile)
-        assert_close(nchw(out.cpu()), ref0 + nchw(res), 2e-5, "%s f32x taps tile %d" % (name, tile))
-    assert_close(layer(src, residual=res.to(dev)), plain(src, residual=res.to(dev)), 2e-5, name + ": packed vs unpacked")
+        assert_close(nchw(out.cpu()), ref0 + nchw(res), fp32_tol(cin * k * k), "%s f32x taps tile %d" % (name, tile))
+    assert_close(layer(src, residual=res.to(dev)), plain(src, residual=res.to(dev)), 1.5 * fp32_tol(cin * k * k), name + ": packed vs unpacked")
 
 
 def test_fp32_layers_may_pick_the_lds_dma_kernel(dev):
@@ -453,9 +463,9 @@ def test_fp32_layers_may_pick_the_lds_dma_kernel(dev):
     x = torch.randn(7360, 512, generator=g)
     lin = ops.PackedLinear(w.to(dev), b.to(dev))
     lin.tune = True
-    ref = F.linear(x, w, b)
+    ref = F.linear(x.double(), w.double(), b.double())
     for _ in range(2):                        # first call tunes, second replays the decision
-        assert_close(lin(x.to(dev)).cpu(), ref, 2e-5, "tuned linear")
+        assert_close(lin(x.to(dev)).cpu(), ref, fp32_tol(512), "tuned linear")
     key = [k for k in ops._TUNED if k[0] == 1536 and k[1] == (512,)]
     assert key, "no tuning decision recorded"
     print("qkv-shaped fp32 linear: tile code", ops._TUNED[key[0]])

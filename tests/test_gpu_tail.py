@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import assert_close, nhwc
+from tests.util import assert_close, gen, nhwc
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,7 @@ CASES = [
 def test_conv3x3_tail(dev, case, dtype):
     from e2fgvi_amd import ops
     N, H, W, ld, act, use_bias = case
-    g = torch.Generator().manual_seed(H * 1000 + W)
+    g = gen(H * 1000 + W)
     x = torch.randn(N, 64, H, W, generator=g)
     w = torch.randn(3, 64, 3, 3, generator=g) * (1.0 / 24.0)
     b = torch.randn(3, generator=g) * 0.1 if use_bias else None
@@ -46,19 +46,19 @@ def test_conv3x3_tail(dev, case, dtype):
     elif act == 2:
         ref = F.leaky_relu(ref, 0.2)
     assert got.dtype == torch.float32 and tuple(got.shape) == (N, 3, H, W)
-    assert_close(got, ref.float(), 2e-5, "conv3x3_tail %s" % (case,))
+    assert_close(got, ref, 2e-5, "conv3x3_tail %s %s" % (case, dtype))
 
 
 def test_conv3x3_tail_matches_the_implicit_gemm(dev):
     """same layer through the general fp32 kernel (conv.hip) and the tail kernel"""
     from e2fgvi_amd import ops
-    g = torch.Generator().manual_seed(5)
+    g = gen(5)
     x = nhwc(torch.randn(2, 64, 60, 108, generator=g)).to(dev)
     w = (torch.randn(3, 64, 3, 3, generator=g) / 24.0).to(dev)
     b = (torch.randn(3, generator=g) * 0.1).to(dev)
     a = ops.PackedConv(w, b, [64], pad=1)([x], act=ops.ACT_TANH, out_nchw=True)
     t = ops.PackedTailConv(w, b)([x], act=ops.ACT_TANH)
-    assert_close(t, a, 2e-5, "tail vs implicit GEMM")
+    assert_close(t, a, 3e-5, "tail vs implicit GEMM")
 
 
 def test_conv3x3_tail_rejects_other_shapes(dev):

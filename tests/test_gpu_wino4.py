@@ -8,12 +8,20 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import assert_close, nchw, nhwc
-from tests.test_gpu_ops import _gen, _act_ref
+from tests.util import assert_close, gen as _gen, nchw, nhwc
+from tests.test_gpu_ops import _act_ref, conv64
 
 pytestmark = pytest.mark.gpu
 
-TOL = {2464: 2e-5, 2432: 2e-5, 4432: 1e-4}
+# floors; above them the bound grows with sqrt(input channels): the transforms' own fp32 roundings are amplified by the
+# transform coefficients (F(2x4): up to 4, F(4x4): up to 8) before the channel sum.  Measured over 4 data sets
+# (tools/gpu_suite_soak.sh): F(2x4) 1.1e-6 x sqrt(cin), F(4x4) 4.9e-6 x sqrt(cin) (x rms of the output); allowed: twice that.
+TOL = {2464: 3e-5, 2432: 3e-5, 4432: 1e-4}
+SLOPE = {2464: 2.4e-6, 2432: 2.4e-6, 4432: 1e-5}
+
+
+def wtol(code, cin, floor_scale=1.0):
+    return max(floor_scale * TOL[code], SLOPE[code] * math.sqrt(cin))
 
 W4_CASES = [
     # N, H, W, cpg, groups, Cout, act, dst_ld, dst_coff
@@ -45,7 +53,7 @@ def test_conv3x3_winograd4(dev, case, code):
     w = torch.randn(Cout, cin_g, 3, 3, generator=g) / math.sqrt(cin_g * 9)
     b = torch.randn(Cout, generator=g)
     xcat = torch.cat([s.view(N, groups, c, H, W) for s, c in zip(srcs, cpg)], 2).view(N, groups * cin_g, H, W)
-    ref = _act_ref(F.conv2d(xcat, w, b, stride=1, padding=1, groups=groups), act, 0.2)
+    ref = _act_ref(conv64(xcat, w, b, stride=1, padding=1, groups=groups), act, 0.2)
     layer = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=1, pad=1, algo="winograd")
     if dst_ld is None:
         out = layer([nhwc(s).to(dev) for s in srcs], act=act, slope=0.2, tile=code)
@@ -55,7 +63,7 @@ def test_conv3x3_winograd4(dev, case, code):
         out = full[..., dst_coff:dst_coff + Cout]
         rest = torch.cat([full[..., :dst_coff], full[..., dst_coff + Cout:]], 3)
         assert (rest == 7.0).all(), "winograd4 conv wrote outside its channel slice"
-    assert_close(nchw(out.cpu()), ref, TOL[code], "winograd4 conv %d" % code)
+    assert_close(nchw(out.cpu()), ref, wtol(code, cin_g), "winograd4 conv %d %s" % (code, case))
 
 
 @pytest.mark.parametrize("code", [2464, 2432, 4432])
@@ -70,9 +78,9 @@ def test_conv3x3_winograd4_residual(dev, code):
     for res_ld, res_coff in ((128, 0), (136, 8), (131, 3)):
         resfull = torch.randn(2, 32, 56, res_ld, generator=g)
         res = resfull[..., res_coff:res_coff + 128]
-        ref = F.leaky_relu(F.conv2d(x, w, b, padding=1) + nchw(res), 0.1)
+        ref = F.leaky_relu(conv64(x, w, b, padding=1) + nchw(res), 0.1)
         out = layer([nhwc(x).to(dev)], residual=resfull.to(dev), res_coff=res_coff, act=2, slope=0.1, tile=code)
-        assert_close(nchw(out.cpu()), ref, TOL[code], "winograd4 conv + residual (ld %d coff %d)" % (res_ld, res_coff))
+        assert_close(nchw(out.cpu()), ref, wtol(code, 128), "winograd4 %d conv + residual (ld %d coff %d)" % (code, res_ld, res_coff))
 
 
 @pytest.mark.parametrize("code", [2464, 2432, 4432])
@@ -86,7 +94,7 @@ def test_conv3x3_winograd4_dcnpost(dev, code):
     w = torch.randn(432, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
     b = torch.randn(432, generator=g) * 0.1
     fl = torch.randn(N, H, W, 4, generator=g) * 3
-    raw = F.conv2d(x, w, b, padding=1)
+    raw = conv64(x, w, b, padding=1)
     o1, o2, m = torch.chunk(raw, 3, 1)
     off = 10 * torch.tanh(torch.cat([o1, o2], 1))
     f1 = fl[..., 0:2].permute(0, 3, 1, 2)
@@ -95,7 +103,7 @@ def test_conv3x3_winograd4_dcnpost(dev, code):
     ref = torch.cat([off1 + f1.flip(1).repeat(1, 72, 1, 1), off2 + f2.flip(1).repeat(1, 72, 1, 1), torch.sigmoid(m)], 1)
     wl = ops.PackedConv(w.to(dev), b.to(dev), [128], pad=1, algo="winograd")
     out = wl([nhwc(x).to(dev)], residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0, tile=code)
-    assert_close(nchw(out.cpu()), ref, max(3e-5, TOL[code]), "winograd4 DCNPOST vs torch")
+    assert_close(nchw(out.cpu()), ref, max(5e-5, 2 * wtol(code, 128)), "winograd4 %d DCNPOST vs torch" % code)
 
 
 def test_conv3x3_winograd4_argument_errors(dev):

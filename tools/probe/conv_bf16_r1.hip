@@ -6,12 +6,26 @@
 // activation, fp32 store) is the fp32 kernel's.  The default path of the library is fp32 -- this kernel is only used
 // when the caller asks for it (Engine(precision="bf16")).
 //
+// ROUND 3: no longer part of the product library (the bf16 data path is conv_bf16x.hip).  Kept here as the AGGRESSOR of
+// the cross-stream reproducer (overlap_probe.hip): its tiles with 2x2 MFMA accumulators are the ones beside which
+// packed-fp32 VALU on VMEM-fresh registers misbehaves.  Build:
+//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Ie2fgvi_amd/csrc -Iinclude tools/probe/conv_bf16_r1.hip \
+//           e2fgvi_amd/csrc/error.hip -o /tmp/libe2fgvi_r1_aggressor.so
+//
 // Structure: same as conv.hip's conv_igemm_kernel (buffer loads with hardware zeroing, register prefetch stages,
 // 2-deep LDS ring, XCD-aware tiles), with a 64-deep K-step = two 32-channel chunks per barrier.
 //   operands of v_mfma_f32_32x32x16_bf16: lane l holds 8 consecutive k of row/col (l & 31), k-block (l >> 5)
 //   LDS A: [BM][64 (+8 pad)] bf16 (144-byte rows: conflict-free 16-byte reads), LDS B: [8 k-octets][BN][8] bf16
 //   packed weights: [group][K/8][Npad][8] bf16, K = tap-major, sources padded to 32 channels
 #include "common.h"
+
+extern "C" {
+int64_t e2fgvi_packed_conv_weight_bf16_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
+                                            int32_t nsrc, const int32_t* src_cpg);   /* in bf16 elements */
+int e2fgvi_pack_conv_weight_bf16(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH,
+                                 int32_t KW, int32_t nsrc, const int32_t* src_cpg, void* stream);
+int e2fgvi_conv2d_nhwc_bf16(const e2fgvi_conv_desc* d, void* stream);
+}
 
 namespace {
 

@@ -2,7 +2,9 @@
 // stream returned wrong warped values in lanes 48-63 of single waves while the bf16 conv tiles with 2x2 MFMA accumulators
 // ran on another stream.  Standalone (no torch):
 //     hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe/overlap_probe.hip -o /tmp/overlap_probe -ldl
-//     /tmp/overlap_probe e2fgvi_amd/csrc/libe2fgvi_hip.so [trials]
+//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Ie2fgvi_amd/csrc -Iinclude tools/probe/conv_bf16_r1.hip \
+//           e2fgvi_amd/csrc/error.hip -o /tmp/libe2fgvi_r1_aggressor.so          (round 1's bf16 tiles: the aggressor)
+//     /tmp/overlap_probe e2fgvi_amd/csrc/libe2fgvi_hip.so [trials] [/tmp/libe2fgvi_r1_aggressor.so]
 // Victims   V0 the product kernel's body   V1 + s_waitcnt vmcnt(0) before the arithmetic   V2 + vmcnt(0) and 32 idle cycles
 //           V3 nontemporal (L1-bypassing) loads   V4 arithmetic without packed-f32 instructions (volatile scalar FMAs)
 // Aggressors (other stream, long-running, >= 1 workgroup per CU)
@@ -205,10 +207,13 @@ int main(int argc, char** argv) {
     const int trials = argc > 2 ? atoi(argv[2]) : 60;
     void* L = dlopen(libpath, RTLD_NOW);
     if (!L) { printf("dlopen failed: %s\n", dlerror()); return 1; }
-    conv_fn conv_bf16 = (conv_fn)dlsym(L, "e2fgvi_conv2d_nhwc_bf16");
+    const char* r1path = argc > 3 ? argv[3] : "/tmp/libe2fgvi_r1_aggressor.so";
+    void* L1 = dlopen(r1path, RTLD_NOW);
+    if (!L1) { printf("dlopen of the round-1 aggressor library failed: %s\n", dlerror()); return 1; }
+    conv_fn conv_bf16 = (conv_fn)dlsym(L1, "e2fgvi_conv2d_nhwc_bf16");
     conv_fn conv_f32 = (conv_fn)dlsym(L, "e2fgvi_conv2d_nhwc");
-    size_bf_fn size_bf = (size_bf_fn)dlsym(L, "e2fgvi_packed_conv_weight_bf16_size");
-    pack_bf_fn pack_bf = (pack_bf_fn)dlsym(L, "e2fgvi_pack_conv_weight_bf16");
+    size_bf_fn size_bf = (size_bf_fn)dlsym(L1, "e2fgvi_packed_conv_weight_bf16_size");
+    pack_bf_fn pack_bf = (pack_bf_fn)dlsym(L1, "e2fgvi_pack_conv_weight_bf16");
     size_fn size_f = (size_fn)dlsym(L, "e2fgvi_packed_conv_weight_size");
     pack_fn pack_f = (pack_fn)dlsym(L, "e2fgvi_pack_conv_weight");
     convx_fn conv_x = (convx_fn)dlsym(L, "e2fgvi_conv2d_bf16x");
