@@ -241,7 +241,7 @@ def main():
     # the forward replays from a HIP graph in every mode; the collective stays outside the graph (runner.ShardedStep)
     step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=not args.no_graph, force_gather=args.force_dist,
                               pack_u8=(dist is not None and args.gather == "u8"))
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):        # at least two untimed steps: the second one captures the HIP graph
         step.run()
     step.finish()
     torch.cuda.synchronize()

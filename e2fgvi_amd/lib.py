@@ -111,6 +111,7 @@ SYMBOLS = {
     "e2fgvi_psnr_ssim": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp, _fp, _fp]),
     "e2fgvi_softcomp_fold": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_focal_attention_bf16": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_focal_attention_bf16_variant": (C.c_int, [C.c_int]),
     "e2fgvi_nchw_to_nhwc_x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
     "e2fgvi_resize_bilinear_bf16": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_prop_cond_x": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i64, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _fp]),

@@ -56,7 +56,8 @@ _W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
 XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
 XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
-# The decisions are persisted: read from / appended to a per-library-build file under the user's cache directory, so that
+# The decisions are persisted: read from / appended to a per-library-build file next to the library (e2fgvi_amd/.tile_cache/,
+# or $E2FGVI_CACHE_DIR), so that
 # a served model pays the ~20 tuning launches per layer and size class once per machine, every process (and every rank of
 # a sharded job) replays the same tiles, and a profiled run (rocprofv3, tools/profile.sh) contains no tuning launches.
 #   E2FGVI_TUNE_FILE=<path>   use that file instead          E2FGVI_TUNE_FILE=0 (or empty)   do not persist
@@ -66,8 +67,7 @@ _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all laye
 def _default_tune_file():
     try:
         st = os.stat(_L.LIB_PATH)
-        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
-        d = os.path.join(base, "e2fgvi_amd")
+        d = os.environ.get("E2FGVI_CACHE_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), ".tile_cache")
         os.makedirs(d, exist_ok=True)
         return os.path.join(d, "tiles_%x_%x.txt" % (st.st_size, int(st.st_mtime)))
     except OSError:
@@ -775,9 +775,16 @@ def focal_attention(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, waves=
     return out
 
 
-def focal_attention_bf16(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None):
-    """bf16 data path: qkv [rows,1536] / kv_pool [B*T*nWin,1536] / out [rows,512] are bf16"""
+def focal_attention_bf16(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, variant=None):
+    """bf16 data path: qkv [rows,1536] / kv_pool [B*T*nWin,1536] / out [rows,512] are bf16.
+    variant (tests / A-B measurements): kernel variant for this call (see e2fgvi_focal_attention_bf16_variant)"""
     lib = _L.load()
+    if variant is not None:
+        prev = lib.e2fgvi_focal_attention_bf16_variant(int(variant))
+        try:
+            return focal_attention_bf16(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=out)
+        finally:
+            lib.e2fgvi_focal_attention_bf16_variant(prev)
     _chk(qkv, "qkv", torch.bfloat16); _chk(kv_pool, "kv_pool", torch.bfloat16)
     _chk(key_tab, "key_tab", torch.int32); _chk(nkeys, "nkeys", torch.int32)
     rows = B * T * fh * fw

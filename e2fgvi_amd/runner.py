@@ -63,6 +63,11 @@ class ShardedStep:
         self._gathered = None
         self._pending = None       # (work, gathered buffer) of the step whose gather is in flight
         self._last = None
+        if group_world > 1:
+            # every rank replays rank 0's tile choices (they are timed per process): same kernels, same accumulation order,
+            # bit-identical frames from every rank for identical clips -- before the graph capture freezes the choices
+            from . import ops
+            ops.sync_tile_decisions(group)
 
     def _forward(self):
         out, _ = self.net(self.x, self.lt)

@@ -363,6 +363,11 @@ int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int32_t Cout, i
 int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool, const int32_t* key_tab, int32_t tab_ld,
                                 const int32_t* nkeys, void* out, int32_t B, int32_t T, int32_t fh, int32_t fw,
                                 void* stream);
+/* Kernel variant of e2fgvi_focal_attention_bf16 for the following calls of this process (A/B measurements and the tests of
+ * every instantiation): 0 = automatic, 1 = round 2's register-staged kernel, 10 * QB + NW = the LDS-DMA kernel with NW
+ * (2 / 4 / 8) waves of QB (1 / 2) x 32 queries per workgroup.  Returns the previous setting (-1: environment default,
+ * E2FGVI_ATT_VARIANT).  Same operator and results up to fp32 summation order in every variant. */
+int e2fgvi_focal_attention_bf16_variant(int variant);
 
 /* Typed variants of the HBM-bound helpers for the bf16 data path: same operators and reference call sites as the fp32
  * entry points above, tensors marked `void*` are fp32 or bf16 as the dtype argument says; all arithmetic is fp32. */

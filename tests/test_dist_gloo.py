@@ -108,6 +108,12 @@ def _step_worker(rank, world, port, q):
         g = outs[k]
         ok = ok and bool((g[:2] == float(k)).all()) and bool((g[2:] == 100.0 + k).all())
     ok = ok and step.finish() is not None and bool((step.finish()[:2] == 4.0).all())       # idempotent
+    # tile decisions: the ranks tuned differently (per-process timing) -> after constructing a step all hold rank 0's table
+    from e2fgvi_amd import ops
+    ops._TUNED.clear()
+    ops._TUNED.update({("geom", 1): 100 + rank, ("only-rank-%d" % rank,): 7})
+    ShardedStep(_StepNet(rank), torch.zeros(1, 2, 3, 4, 4), 2, group_world=world, use_graph=False)
+    ok = ok and ops._TUNED == {("geom", 1): 100, ("only-rank-0",): 7}
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

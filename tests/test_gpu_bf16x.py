@@ -179,7 +179,13 @@ def test_focal_attention_bf16(dev, B, T, fh, fw):
     tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
     both = torch.cat([qkv, kvp], 0).to(dev)
     rows = qkv.shape[0]
-    out = ops.focal_attention_bf16(both[:rows], both[rows:], torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev), B, T, fh, fw)
+    tab_d, nk_d = torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev)
+    # every kernel variant: 0 = what the engine runs, 1 = round 2's register-staged kernel, 10 QB + NW = the LDS-DMA kernel
+    # (NW waves of QB x 32 queries per workgroup; V transposed by ds_read_b64_tr_b16)
+    for variant in (1, 12, 14, 18, 22, 24, 28):
+        o = ops.focal_attention_bf16(both[:rows], both[rows:], tab_d, nk_d, B, T, fh, fw, variant=variant)
+        assert_close_bf16(o, ref.reshape(-1, Cc), "bf16 attention %dx%d T=%d variant %d" % (fh, fw, T, variant), ulps=1.0, abs_rms=1.2e-2)
+    out = ops.focal_attention_bf16(both[:rows], both[rows:], tab_d, nk_d, B, T, fh, fw)
     assert out.dtype == torch.bfloat16
     # elementwise: the bf16 rounding of the output (<= 2^-8 relative) + the bf16 rounding of the probabilities: every p_j carries
     # an independent relative error of rms 2^-9 / sqrt(3), so o = sum p_j v_j is off by rms 1.1e-3 x rms(o) (p spread over
