@@ -260,10 +260,19 @@ def test_focal_attention(dev, B, T, fh, fw):
     qkv = F.linear(xn.reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
     kvp = F.linear(xp.permute(0, 3, 1, 2, 4).reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
     tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
-    for waves in (0, 2, 4, 12, 14):
-        out = ops.focal_attention(qkv.to(dev), kvp.to(dev), torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev),
+    outs = {}
+    both = torch.cat([qkv, kvp], 0).to(dev)          # back to back: one buffer resource covers both (the LDS-DMA kernel needs it)
+    q_d, p_d = both[:qkv.shape[0]], both[qkv.shape[0]:]
+    # 0 = what the engine runs; 2 / 4 (+10: two key groups) = round 2's register-staged kernel; +20 / +30 = the LDS-DMA kernel
+    for waves in (0, 2, 4, 12, 14, 22, 24, 32, 34):
+        out = ops.focal_attention(q_d, p_d, torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev),
                                   B, T, fh, fw, waves=waves)
         assert_close(out.cpu(), ref, ATT_TOL, "attention waves=%d" % waves)
+        outs[waves] = out
+    # same arithmetic in the same key order (34 / 32 vs 14 / 12: two key groups each; on a small grid the launcher gives
+    # 4 / 2 two key groups as well, 24 / 22 always one: another summation order): agreement to fp32 summation noise
+    for a, b_ in ((24, 4), (22, 2), (34, 14), (32, 12)):
+        assert_close(outs[a], outs[b_], 2e-5, "LDS-DMA kernel (waves=%d) vs the register-staged one (waves=%d)" % (a, b_))
 
 
 @pytest.mark.parametrize("B,T,fh,fw,far", [(1, 4, 60, 108, False), (1, 4, 90, 162, False), (1, 4, 60, 108, True)])
@@ -299,7 +308,7 @@ def test_focal_attention_large_grids(dev, B, T, fh, fw, far):
         assert abs(q_d.data_ptr() - p_d.data_ptr()) >= (1 << 32)
     else:
         q_d, p_d = qkv.to(dev), kvp.to(dev)
-    for waves in (0, 14):
+    for waves in (0, 14) + (() if far else (24, 34)):
         out = ops.focal_attention(q_d, p_d, torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev), B, T, fh, fw,
                                   waves=waves)
         assert_close(out.cpu(), ref, ATT_TOL, "attention %dx%d far=%s waves=%d" % (fh, fw, far, waves))

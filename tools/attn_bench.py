@@ -15,7 +15,7 @@ tab, nk = torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev)
 out = torch.empty(rows, 512, device=dev)
 ref = ops.focal_attention(qkv, kvp, tab, nk, B, T, fh, fw, waves=4).clone()
 gflop = B * nwin * 4 * (45 * T) * (int(nk.float().mean().item()) * T) * 128 * 2 * 2 * 1e-9
-for waves in (0, 2, 4, 12, 14):
+for waves in (0, 2, 4, 12, 14, 22, 24, 32, 34):
     o = ops.focal_attention(qkv, kvp, tab, nk, B, T, fh, fw, out=out, waves=waves)
     diff = (o - ref).abs().max().item()
     iters = 10
