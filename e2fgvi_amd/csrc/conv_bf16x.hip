@@ -32,6 +32,9 @@ struct ConvXParams {
     unsigned src_bytes[E2FGVI_MAX_SRC];
     int nsrc;
     int N, H, W, Ho, Wo, KH, KW, stride, pad;
+    int padx;                             // left padding (= pad unless the descriptor gives an explicit output grid)
+    int osy, osx, opy, opx, oH, oW;       // osy > 0: output pixel (img, oy, ox) lives at (img, oy*osy + opy, ox*osx + opx) of [N,oH,oW]
+    int res_bcast;                        // the residual is ONE [oH*oW] (or [Ho*Wo]) image added to every image of the batch
     int Cout, Cout_g, Npad;
     int M;
     int tilesM, tilesN;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         const int rem = mm - img * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         const int by = oy * p.stride - p.pad;
-        const int bx = S3 ? ox : ox * p.stride - p.pad;         // S3 stages the centre column; the tap shifts the READ
+        const int bx = S3 ? ox : ox * p.stride - p.padx;        // S3 stages the centre column; the tap shifts the READ
         unsigned msk = 0;
         for (int k = 0; k < p.KH; ++k) msk |= ((unsigned)(by + k) < (unsigned)p.H ? 1u : 0u) << k;
         for (int k = 0; k < (S3 ? 1 : p.KW); ++k) msk |= ((unsigned)(bx + k) < (unsigned)p.W ? 1u : 0u) << (8 + k);
@@ -409,6 +412,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         return;
     }
     // ---- epilogue through LDS
+    // where output row m lives: row m of dst (default), or -- with an output scatter (osy > 0: the phase convolutions of the
+    // gather-form SoftComp write every third pixel of the folded image) -- pixel (oy*osy + opy, ox*osx + opx) of its image;
+    // mr: the residual's row (the same, or the pixel alone when one residual image is broadcast over the batch)
+    auto out_row = [&](long long m, long long& mr) -> long long {
+        long long mo = m;
+        mr = m;
+        if (p.osy | p.res_bcast) {
+            const int img = (int)(m / HoWo);
+            const int rem = (int)(m - (long long)img * HoWo);
+            if (p.osy) {
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int pix = (oy * p.osy + p.opy) * p.oW + ox * p.osx + p.opx;
+                mo = (long long)img * p.oH * p.oW + pix;
+                mr = p.res_bcast ? pix : mo;
+            } else {
+                mr = rem;
+            }
+        }
+        return mo;
+    };
     float* E = reinterpret_cast<float*>(smem) + wave * (R * LDE);
     constexpr int LPR = CNH / 8;           // lanes per row (8 channels each)
     constexpr int RPP = 64 / LPR;          // rows per pass
@@ -440,11 +463,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 #pragma unroll 1
         for (int ps = 0; ps < R / RPP; ++ps) {
             const int row = ps * RPP + lane / LPR;
-            const long long m = m0 + wm * R + row;
+            long long mr;
+            const long long m = out_row(m0 + wm * R + row, mr);
             f32x4 v0 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0) + b0;
             f32x4 v1 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0 + 4) + b1;
             if (p.res) {
-                const long long ro = m * p.res_ld + p.res_coff + co;
+                const long long ro = mr * p.res_ld + p.res_coff + co;
                 if (p.res_bf16) {
                     const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.res) + ro);
                     v0[0] += __builtin_bit_cast(float, q[0] << 16); v0[1] += __builtin_bit_cast(float, q[0] & 0xFFFF0000u);
@@ -490,20 +514,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 #pragma unroll 1
         for (int ps = 0; ps < R / RPP; ++ps) {
             const int row = ps * RPP + lane / LPR;
-            const int m = m0 + wm * R + row;
-            if (m >= p.M) continue;
+            const int m_in = m0 + wm * R + row;
+            if (m_in >= p.M) continue;
+            long long mr;
+            const long long m = out_row(m_in, mr);
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(E + row * LDE + col0 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] += bv[c];
             if (p.act == E2FGVI_ACT_DCNPOST) {
-                const f32x4 fl = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (long long)m * 4);
+                const f32x4 fl = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (long long)m_in * 4);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = dcn_post(v[c], co + c, p.Cout, fl, p.slope);
             } else {
                 if (p.res) {
-                    const long long ro = (long long)m * p.res_ld + p.res_coff + co;
+                    const long long ro = mr * p.res_ld + p.res_coff + co;
                     if (p.res_bf16) {
                         const unsigned short* rp = reinterpret_cast<const unsigned short*>(p.res) + ro;
                         if (vec_r) {
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             const long long dof = (long long)m * p.dst_ld + p.dst_coff + co;
             if ((p.dbg_noload & 8) && v[0] != 123.456f) continue;          // measurement aid: everything but the global stores
             if (p.dst_nchw) {                      // plain fp32 NCHW [N,Cout,Ho,Wo] (the decoder's last layer: 3 channels)
-                const int img = m / HoWo, rem = m - img * HoWo;
+                const int img = m_in / HoWo, rem = m_in - img * HoWo;
                 float* o = reinterpret_cast<float*>(p.dst) + ((long long)img * p.Cout + co) * HoWo + rem;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) o[(long long)c * HoWo] = v[c];
@@ -762,8 +788,23 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
                "conv2d_bf16x: bad geometry (channels per source must be multiples of 8 bf16 / 4 fp32)");
     E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->stride > 0 && d->pad >= 0, E2FGVI_EINVAL,
                "conv2d_bf16x: bad sizes");
-    E2_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
-               E2FGVI_EINVAL, "conv2d_bf16x: Ho/Wo inconsistent with H/W/k/stride/pad");
+    if (d->out_grid) {
+        // explicit output grid: `pad` rows above / `pad_left` columns left of the image, whatever the kernel reaches below /
+        // right of it reads as zeros; Ho x Wo as given (the phase convolutions of SoftComp: 2-tap kernels with the zero row
+        // on one side only); optionally scattered into a larger image
+        E2_REQUIRE(d->pad_left >= 0 && d->act != E2FGVI_ACT_DCNPOST && !d->dst_nchw && !d->tap_packed && (d->tile < 10 || d->tile > 20),
+                   E2FGVI_EINVAL, "conv2d_bf16x: explicit output grids take plain NHWC tiles only");
+        if (d->out_sy || d->out_sx)
+            E2_REQUIRE(d->out_sy > 0 && d->out_sx > 0 && d->out_py >= 0 && d->out_px >= 0 && d->out_H > 0 && d->out_W > 0 &&
+                       (d->Ho - 1) * d->out_sy + d->out_py < d->out_H && (d->Wo - 1) * d->out_sx + d->out_px < d->out_W &&
+                       (long long)d->N * d->out_H * d->out_W < 2147483647LL,
+                       E2FGVI_EINVAL, "conv2d_bf16x: the output scatter leaves the [N, out_H, out_W] image");
+    } else {
+        E2_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                   E2FGVI_EINVAL, "conv2d_bf16x: Ho/Wo inconsistent with H/W/k/stride/pad");
+        E2_REQUIRE(!d->out_sy && !d->out_sx && !d->pad_left, E2FGVI_EINVAL, "conv2d_bf16x: pad_left / out_s* need out_grid = 1");
+    }
+    E2_REQUIRE(!d->res_bcast || (d->residual && d->act != E2FGVI_ACT_DCNPOST), E2FGVI_EINVAL, "conv2d_bf16x: res_bcast without a residual");
     E2_REQUIRE((long long)d->N * d->Ho * d->Wo < 2147483647LL, E2FGVI_EUNSUP, "conv2d_bf16x: more than 2^31 output pixels");
     E2_REQUIRE(d->KH <= 8 && d->KW <= 8, E2FGVI_EUNSUP, "conv2d_bf16x: kernels larger than 8x8 are not supported");
     E2_REQUIRE(d->wpacked && d->dst, E2FGVI_EINVAL, "conv2d_bf16x: null weight/dst");
@@ -797,6 +838,9 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
     p.nsrc = d->nsrc;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+    p.padx = d->out_grid ? d->pad_left : d->pad;
+    p.osy = d->out_grid ? d->out_sy : 0; p.osx = d->out_sx; p.opy = d->out_py; p.opx = d->out_px; p.oH = d->out_H; p.oW = d->out_W;
+    p.res_bcast = d->res_bcast;
     p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
     p.M = d->N * d->Ho * d->Wo;
     p.nsteps = d->KH * d->KW * q.steps_per_tap;

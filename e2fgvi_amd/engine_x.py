@@ -76,6 +76,10 @@ class BF16Path:
         if self.hq:
             self.xsc_bias_conv = PackedConvX(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1)
             self.xsc_bias_conv.name = "sc.bias_conv"
+            # SoftComp in gather form (nine phase convolutions writing the folded image directly: no [tokens, 6272] tensor,
+            # 813 MB at 720p T=10, and no fold kernel); E2FGVI_SC_GATHER=0: the Linear + fold kernel pair (A/B measurements)
+            self.xsc_gather = (ops.SoftCompGather(f("sc.embedding.weight"), f("sc.embedding.bias"), 128)
+                               if os.environ.get("E2FGVI_SC_GATHER", "1") != "0" else None)
         # SPyNet: the conv stacks of the six pyramid levels on bf16 MFMA (they are 15 % of the 720p forward in fp32); the
         # geometry stays fp32 -- pyramid images, warps, the flow itself and the residual sum flow = up(flow) + net(...)
         # (the last conv of a level adds the fp32 upsampled flow and stores fp32).
@@ -232,6 +236,9 @@ class BF16Path:
     def compose_x(self, tok16, enc, b, t, fh, fw):
         """SoftComp + residual with the encoder features (tfocal_transformer.py:65-72, e2fgvi.py:258), bf16."""
         _, h, w, ch = enc.shape
+        if self.hq and self.xsc_gather is not None and (h, w) == (3 * fh, 3 * fw):
+            folded = self.xsc_gather(tok16.view(b * t, fh, fw, 512))
+            return self.xsc_bias_conv([folded], residual=enc)
         emb = self.xsc(tok16)
         if self.hq:
             folded = ops.softcomp_fold(emb, b * t, fh, fw, h, w, ch)

@@ -41,6 +41,10 @@ class ConvXDesc(C.Structure):
         ("dst", _fp), ("dst_ld", C.c_int32), ("dst_coff", C.c_int32), ("dst_dtype", C.c_int32),
         ("dst2", _fp), ("dst2_ld", C.c_int32), ("dst2_coff", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("tile", C.c_int32), ("dst_nchw", C.c_int32), ("tap_packed", C.c_int32),
+        # ABI version 6: explicit output grid / output scatter / broadcast residual (SoftComp in gather form)
+        ("out_grid", C.c_int32), ("pad_left", C.c_int32),
+        ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_py", C.c_int32), ("out_px", C.c_int32),
+        ("out_H", C.c_int32), ("out_W", C.c_int32), ("res_bcast", C.c_int32),
     ]
 
 

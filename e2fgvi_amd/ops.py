@@ -573,6 +573,84 @@ class PackedConvX:
         return res
 
 
+class SoftCompGather:
+    """SoftComp's Linear(512 -> 49 C) + nn.Fold(7x7, stride 3, padding 3) (tfocal_transformer.py:49-72,
+    tfocal_transformer_hq.py:49-79) in GATHER form: pixel (Y, X) of the folded image receives the taps (ki, kj) with
+    ki = Y + 3 - 3 ly, kj = X + 3 - 3 lx of the tokens (ly, lx) around it, so the pixels of phase (py, px) = (Y % 3, X % 3)
+    are a small convolution over the token grid -- 3 taps per axis for phase 0 (token rows ty-1, ty, ty+1 with ki = 6, 3, 0),
+    2 for phases 1 and 2 (rows ty, ty+1 with ki = p+3, p) -- written to every third pixel.  Nine launches of the LDS-DMA
+    conv kernel (explicit output grid + output scatter), 49 x 512 x C MACs per token as before, but no [tokens, 49 C]
+    tensor between the Linear and the Fold (813 MB at 720x1296 T=10 in bf16) and no fold kernel.  The Linear's bias folds
+    to a per-pixel image (fewer taps reach the border pixels), added as a residual broadcast over the frames."""
+
+    def __init__(self, weight, bias, channels=128, dtype=torch.bfloat16):
+        w = _chk(weight.detach().float().contiguous(), "weight")            # [49 C, 512], row c*49 + ki*7 + kj
+        if w.dim() != 2 or w.shape[0] != 49 * channels:
+            raise ValueError("SoftComp embedding weight must be [%d, hidden]" % (49 * channels))
+        self.C, self.hidden, self.dtype = channels, w.shape[1], dtype
+        w4 = w.view(channels, 7, 7, self.hidden)
+        self.phases = []
+        for py in range(3):
+            ky_taps = [6, 3, 0] if py == 0 else [py + 3, py]                 # kernel row -> ki; input row = ty - pad + ky
+            for px in range(3):
+                kx_taps = [6, 3, 0] if px == 0 else [px + 3, px]
+                wp = w4[:, ky_taps][:, :, kx_taps].permute(0, 3, 1, 2).contiguous()          # [C, hidden, kh, kw]
+                layer = PackedConvX(wp, None, [self.hidden], dtype=dtype)
+                layer.name = "sc.embedding phase (%d,%d)" % (py, px)
+                self.phases.append((py, px, 1 if py == 0 else 0, 1 if px == 0 else 0, layer))
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        self._bias_img = {}
+        self.tile = int(os.environ.get("E2FGVI_SCG_TILE", "0") or 0)
+
+    def bias_image(self, fh, fw):
+        """fold of the Linear's bias: [3 fh, 3 fw, C] fp32 (computed once per token grid with the fold kernel)"""
+        key = (fh, fw)
+        if key not in self._bias_img and self.bias is not None:
+            rows = self.bias.view(self.C, 49).t().reshape(1, 49 * self.C).expand(fh * fw, 49 * self.C).contiguous()
+            self._bias_img[key] = softcomp_fold(rows, 1, fh, fw, 3 * fh, 3 * fw, self.C)[0].contiguous()
+        return self._bias_img.get(key)
+
+    def __call__(self, tokens, out=None, out_dtype=None):
+        """tokens [F, fh, fw, hidden] -> folded [F, 3 fh, 3 fw, C]"""
+        _chk(tokens, "tokens", self.dtype)
+        F_, fh, fw, hid = tokens.shape
+        if hid != self.hidden:
+            raise ValueError("tokens must be [F, fh, fw, %d]" % self.hidden)
+        H, W = 3 * fh, 3 * fw
+        if out is None:
+            out = torch.empty((F_, H, W, self.C), dtype=out_dtype or self.dtype, device=tokens.device)
+        if tuple(out.shape) != (F_, H, W, self.C):
+            raise ValueError("out must be [%d,%d,%d,%d]" % (F_, H, W, self.C))
+        per_img = fh * fw * hid * tokens.element_size()
+        if F_ > 1 and F_ * per_img >= (1 << 32) - 1:                           # 32-bit buffer resources: frame chunks
+            step = max(1, ((1 << 32) - 2) // per_img)
+            for n0 in range(0, F_, step):
+                self(tokens[n0:n0 + step], out=out[n0:n0 + step])
+            return out
+        bimg = self.bias_image(fh, fw)
+        for py, px, pad_y, pad_x, layer in self.phases:
+            d = _L.ConvXDesc()
+            d.src[0], d.src_ld[0], d.src_coff[0], d.src_cpg[0], d.nsrc = tokens.data_ptr(), hid, 0, hid, 1
+            d.N, d.H, d.W, d.Ho, d.Wo = F_, fh, fw, fh, fw
+            d.KH, d.KW, d.stride, d.pad = layer.KH, layer.KW, 1, pad_y
+            d.groups, d.Cout = 1, self.C
+            d.wpacked = layer.wpacked.data_ptr()
+            d.dst, d.dst_ld, d.dst_coff, d.dst_dtype = out.data_ptr(), self.C, 0, _dt(out)
+            if bimg is not None:
+                d.residual, d.res_ld, d.res_coff, d.res_dtype, d.res_bcast = bimg.data_ptr(), self.C, 0, _L.DT_F32, 1
+            d.out_grid, d.pad_left = 1, pad_x
+            d.out_sy, d.out_sx, d.out_py, d.out_px, d.out_H, d.out_W = 3, 3, py, px, H, W
+            d.act, d.slope, d.tile = ACT_NONE, 0.0, self.tile
+            if _L.TRACE is not None:
+                kc = 32 if layer.f32 else 64
+                macs = F_ * fh * fw * self.C * hid * layer.KH * layer.KW
+                _L.annotate(layer=layer.name, kernel="conv_%s (gather-form SoftComp)" % ("f32x" if layer.f32 else "bf16x"),
+                            shape="N%d %dx%d %d->%d k%dx%d scatter s3" % (F_, fh, fw, hid, self.C, layer.KH, layer.KW),
+                            macs=macs, issued=macs // hid * (-(-hid // kc) * kc))
+            _L.check(layer._fn(C.byref(d), _stream()), "conv2d_x (SoftComp phase)")
+        return out
+
+
 class PackedLinearX(PackedConvX):
     """y[rows, Cout] = x[rows, Cin] @ W^T + b (+ residual) on the bf16 data path, rows treated as 1x1 images."""
 

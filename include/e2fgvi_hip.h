@@ -323,6 +323,16 @@ typedef struct {
     int32_t tile;                      /* 0 = auto                                                          */
     int32_t dst_nchw;                  /* 1: dst is plain fp32 NCHW [N,Cout,Ho,Wo] (dst_ld / dst_coff ignored)  */
     int32_t tap_packed;                /* 1: wpacked comes from e2fgvi_pack_conv_weight_bf16x_taps (ABI version 3)  */
+    /* ABI version 6 (zero = the behaviour of version 5).  out_grid = 1: Ho x Wo are taken as given, `pad` rows lie above and
+     * `pad_left` columns left of the image and whatever else the KH x KW kernel reaches reads as zeros; with out_sy / out_sx > 0
+     * output pixel (n, oy, ox) is stored -- and the residual read -- at pixel (oy*out_sy + out_py, ox*out_sx + out_px) of image n
+     * of an [N, out_H, out_W] tensor.  res_bcast = 1: `residual` is ONE image ([out_H*out_W] or [Ho*Wo] rows) added to every
+     * image of the batch.  Together: SoftComp in gather form -- nn.Fold(7x7, stride 3, pad 3) of Linear(512 -> 49*128)
+     * (tfocal_transformer.py:49-72, tfocal_transformer_hq.py:49-79) as nine phase convolutions over the token grid, phase
+     * (py, px) owning the pixels (3 ty + py, 3 tx + px): no [tokens, 6272] tensor (813 MB at 720p T=10 in bf16). */
+    int32_t out_grid, pad_left;
+    int32_t out_sy, out_sx, out_py, out_px, out_H, out_W;
+    int32_t res_bcast;
 } e2fgvi_convx_desc;
 
 int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream);

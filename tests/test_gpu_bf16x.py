@@ -475,3 +475,41 @@ def test_fp32_layers_may_pick_the_lds_dma_kernel(dev):
     key = [k for k in ops._TUNED if k[0] == 1536 and k[1] == (512,)]
     assert key, "no tuning decision recorded"
     print("qkv-shaped fp32 linear: tile code", ops._TUNED[key[0]])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("F_,fh,fw", [(2, 5, 9), (1, 20, 36), (3, 10, 18)])
+def test_softcomp_gather(dev, F_, fh, fw, dtype):
+    """SoftComp in gather form (ops.SoftCompGather: nine phase convolutions over the token grid, output scatter, the Linear's
+    bias as a folded per-pixel image) against the reference's Linear(512 -> 49*128) + nn.Fold(7x7, stride 3, padding 3)
+    (tfocal_transformer.py:49-72, tfocal_transformer_hq.py:49-79).  fp32 operands: fp32 tolerance (K <= 9 * 512);
+    bf16 operands: the reference takes the SAME bf16-rounded tokens and weights, the result is rounded to bf16 once."""
+    from e2fgvi_amd import ops
+    g = _gen(70 + fh)
+    C_, hid = 128, 512
+    w = torch.randn(49 * C_, hid, generator=g) / math.sqrt(hid * 9)
+    b = torch.randn(49 * C_, generator=g) * 0.1
+    tok = torch.randn(F_, fh, fw, hid, generator=g)
+    if dtype == torch.bfloat16:
+        tok_r, w_r = tok.bfloat16().double(), w.bfloat16().double()
+    else:
+        tok_r, w_r = tok.double(), w.double()
+    emb = F.linear(tok_r.view(F_, fh * fw, hid), w_r, b.double())                       # [F, n, c*49 + tap]
+    ref = F.fold(emb.permute(0, 2, 1), output_size=(3 * fh, 3 * fw), kernel_size=(7, 7), stride=(3, 3), padding=(3, 3))
+    layer = ops.SoftCompGather(w.to(dev), b.to(dev), C_, dtype=dtype)
+    out = layer(tok.to(dev).to(dtype))
+    assert out.dtype == dtype and tuple(out.shape) == (F_, 3 * fh, 3 * fw, C_)
+    if dtype == torch.bfloat16:
+        assert_close_bf16(nchw(out.float().cpu()), ref, "gather-form SoftComp %dx%d bf16" % (fh, fw), abs_rms=1e-4)
+        o32 = layer(tok.to(dev).to(dtype), out_dtype=torch.float32)
+        assert_close(nchw(o32.cpu()), ref, fp32_tol(9 * hid, floor=3e-5), "gather-form SoftComp %dx%d bf16 operands, fp32 out" % (fh, fw))
+    else:
+        assert_close(nchw(out.cpu()), ref, fp32_tol(9 * hid), "gather-form SoftComp %dx%d fp32" % (fh, fw))
+    # and against the library's own Linear + fold kernel pair (the path it replaces)
+    if dtype == torch.bfloat16:
+        wp = w.view(C_, 49, hid).permute(1, 0, 2).reshape(49 * C_, hid).contiguous()
+        bp = b.view(C_, 49).t().reshape(49 * C_).contiguous()
+        lin = ops.PackedLinearX(wp.to(dev), bp.to(dev))
+        old = ops.softcomp_fold(lin(tok.to(dev).bfloat16().view(-1, hid)), F_, fh, fw, 3 * fh, 3 * fw, C_)
+        # the old path rounds the [tokens, 6272] tensor to bf16 before the fold: up to 9 extra roundings per pixel
+        assert_close(out.float(), old.float(), 8e-2, "gather form vs Linear + fold kernels")
