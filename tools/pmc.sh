@@ -11,9 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 # the tile choices of the benchmark (written by a first un-profiled run), no tuning launches inside the counted forwards
 export E2FGVI_TUNE_FILE=$OUT/tune.txt
 rm -f $E2FGVI_TUNE_FILE
-python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $OUT/tune_run.log 2>&1
+python $REPO/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 2 "$@" > $OUT/tune_run.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 "$@" > $OUT/$C.log 2>&1 || true
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-graph --steps 2 --warmup 2 "$@" > $OUT/$C.log 2>&1 || true
 done
 python - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
@@ -33,12 +33,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res[c] = tot
     per_kernel[c] = pk.most_common(8)
     res[c + "_dispatches"] = n
-forwards = 5   # engine-building forward + FLOP-trace forward + 1 warm-up + 2 timed (plus the one-off weight packing, negligible)
+forwards = 6   # engine-building forward + FLOP-trace forward + 2 warm-ups + 2 timed (plus the one-off weight packing, negligible)
 fetch_b = res["FETCH_SIZE"] * 1024 * 2 / forwards     # gfx950: x2 on the read side
 write_b = res["WRITE_SIZE"] * 1024 / forwards
 js = {"fetch_bytes_per_forward": fetch_b, "write_bytes_per_forward": write_b, "hbm_bytes_per_forward": fetch_b + write_b,
       "raw_kib": res, "forwards": forwards,
-      "note": "FETCH_SIZE/WRITE_SIZE (KiB) summed over all dispatches of bench.py --steps 2 --warmup 1, / 5 forwards; "
+      "note": "FETCH_SIZE/WRITE_SIZE (KiB) summed over all dispatches of bench.py --no-graph --steps 2 --warmup 2, / 6 forwards; "
               "read side doubled per the gfx950 calibration in MI355X_MICROARCH.md",
       "top_fetch_kernels_kib": per_kernel["FETCH_SIZE"], "top_write_kernels_kib": per_kernel["WRITE_SIZE"]}
 json.dump(js, open(out + "/traffic.json", "w"), indent=1)
