@@ -341,9 +341,15 @@ __global__ __launch_bounds__(64 * NW * KS) void focal_attn_v2_kernel(const float
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int nWw = fw / WS1, nWh = fh / WS0, nWin = nWh * nWw;
-    const int win = blockIdx.y / NH, head = blockIdx.y - win * NH;
+    // 1-D grid, query chunk fastest (an XCD-aware order that keeps the chunks of one (window, head) on one L2 measured
+    // neutral here and slower in the bf16 kernel, attention_bf16.hip)
+    const int nqc = (T * WTOK + 32 * NW - 1) / (32 * NW);
+    const int logical = (int)blockIdx.x;
+    const int qchunk = logical % nqc;
+    const int wh = (logical / nqc) % (nWin * NH);
+    const int b = logical / (nqc * nWin * NH);
+    const int win = wh / NH, head = wh - win * NH;
     const int wy = win / nWw, wx = win - wy * nWw;
-    const int b = blockIdx.z;
     const int NQ = T * WTOK;
     const int ntok = fh * fw;
     const a2_i32x4 rsrc = a2_rsrc_words(lo_base, lo_bytes);
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(64 * NW * KS) void focal_attn_v2_kernel(const float
     __syncthreads();
 
     // ---- this wave's 32 queries
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int q0 = (qchunk * NW + wave) * 32;
     const bool wave_active = q0 < NQ;              // wave-uniform
     auto query_row = [&](bool& ok) -> long long {
         const int qi = q0 + i;
@@ -600,7 +606,7 @@ extern "C" int e2fgvi_focal_attention(const float* qkv, const float* kv_pool, co
                     E2_REQUIRE(ea == hipSuccess, (int)ea, "focal_attention: cannot reserve %zu bytes of dynamic LDS", dyn2);       \
                     reserved = dyn2;                                                                                               \
                 }                                                                                                                  \
-                hipLaunchKernelGGL((focal_attn_v2_kernel<NW_, KS_>), grid, block, dyn2, st, qkv, key_tab, tab_ld, nkeys, out, B, T, \
+                hipLaunchKernelGGL((focal_attn_v2_kernel<NW_, KS_>), dim3(grid.x * grid.y * grid.z), block, dyn2, st, qkv, key_tab, tab_ld, nkeys, out, B, T, \
                                    fh, fw, lo, lo_bytes, q_rel, p_rel);                                                            \
             } while (0)
             if (waves == 2) { if (ks == 2) E2_ATT2(2, 2); else E2_ATT2(2, 1); }

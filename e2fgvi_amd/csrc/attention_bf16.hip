@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
                                                                      int tab_ld, const int* __restrict__ nkeys,
                                                                      __bf16* __restrict__ out, int B, int T, int fh, int fw,
                                                                      const char* lo_base, unsigned lo_bytes, unsigned q_rel,
-                                                                     unsigned p_rel) {
+                                                                     unsigned p_rel, int xcd) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 64 * NW;
     constexpr int PIECES = 8 / NW;                 // 1-KiB DMA pieces of a K (and of a V) tile per wave
@@ -321,9 +321,19 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int nWw = fw / WS1, nWh = fh / WS0, nWin = nWh * nWw;
-    const int win = blockIdx.y / NH, head = blockIdx.y - win * NH;
+    // 1-D grid, query chunk fastest.  Block b runs on XCD b % 8, so the query chunks of one (window, head) -- which read the
+    // same K / V rows -- land on DIFFERENT XCDs and each fetches the rows into its own L2 (PMC FETCH_SIZE of this kernel: 8.7 GB
+    // per 720p forward against 3.6 for round 2's 256-query workgroups).  Making them neighbours on one XCD (xcd_remap, `xcd` =
+    // 1, E2FGVI_ATT_XCD=1) removes the re-fetch but measured SLOWER: 329 -> 366 us per block at 720p T=10, 2634 -> 2737 at
+    // 1080p T=20 (profiles/r03_attention_variants.txt) -- four workgroups streaming the same rows at the same time queue on
+    // the same L2 channels, and the re-fetches are Infinity-Cache hits anyway (the block's qkv tensor is 199 MB).  Default off.
+    const int nqc = (T * WTOK + 32 * QB * NW - 1) / (32 * QB * NW);
+    const int logical = xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int qchunk = logical % nqc;
+    const int wh = (logical / nqc) % (nWin * NH);
+    const int b = logical / (nqc * nWin * NH);
+    const int win = wh / NH, head = wh - win * NH;
     const int wy = win / nWw, wx = win - wy * nWw;
-    const int b = blockIdx.z;
     const int NQ = T * WTOK;
     const int ntok = fh * fw;
     const v2_i32x4 rsrc = v2_rsrc_words(lo_base, lo_bytes);
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
     __syncthreads();                               // the table is read by every wave's DMA address arithmetic
 
     // ---- this wave's QB x 32 queries: 128 d as 8 operand octets per k-step
-    const int q0 = (blockIdx.x * NW + wave) * (32 * QB);
+    const int q0 = (qchunk * NW + wave) * (32 * QB);
     const bool wave_active = q0 < NQ;
     auto query_row = [&](int j, bool& ok) -> long long {      // token row of this lane's query of block j (recomputed in the
         const int qi = q0 + 32 * j + i;                        // epilogue rather than kept in registers through the tile loop)
@@ -576,7 +586,8 @@ extern "C" int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool,
                "focal_attention_bf16: qkv and kv_pool must lie within one 4 GiB window (allocate them back to back / split the batch)");
     // Variant: E2FGVI_ATT_VARIANT = 10 * QB + NW selects the round-3 kernel with NW waves of QB x 32 queries per workgroup
     // (12, 14, 18, 22, 24); 1 = round 2's kernel (E2FGVI_ATT_NW = its waves per workgroup); unset / 0 = automatic.
-    static int nw_env = -1;
+    static int nw_env = -1, xcd_env = -1;
+    if (xcd_env < 0) { const char* e = getenv("E2FGVI_ATT_XCD"); xcd_env = (e && atoi(e)) ? 1 : 0; }
     if (g_att_variant < 0) { const char* e = getenv("E2FGVI_ATT_VARIANT"); g_att_variant = e ? atoi(e) : 0; }
     if (nw_env < 0) { const char* e = getenv("E2FGVI_ATT_NW"); nw_env = e ? atoi(e) : 0; }
     int variant = g_att_variant;
@@ -593,7 +604,9 @@ extern "C" int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool,
     if (variant != 1) {
         const int nw = variant % 10, qb = variant / 10;
         E2_REQUIRE((nw == 2 || nw == 4 || nw == 8) && (qb == 1 || qb == 2), E2FGVI_EINVAL, "focal_attention_bf16: unknown variant %d", variant);
-        dim3 grid(cdiv(T * WTOK, 32 * qb * nw), nWin * NH, B), block(64 * nw);
+        const long long nblk = (long long)cdiv(T * WTOK, 32 * qb * nw) * nWin * NH * B;
+        E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "focal_attention_bf16: more than 2^31 workgroups");
+        dim3 grid((unsigned)nblk), block(64 * nw);
 #define E2_ATT_V2(NW_, QB_)                                                                                                       \
         do {                                                                                                                      \
             if (dyn + 2 * V2_KB + 2 * V2_VB + 1024 > 64 * 1024) {                                                                 \
@@ -603,7 +616,7 @@ extern "C" int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool,
             }                                                                                                                     \
             hipLaunchKernelGGL((focal_attn_bf16_v2_kernel<NW_, QB_>), grid, block, dyn, (hipStream_t)stream, (const __bf16*)qkv, \
                                key_tab, tab_ld, nkeys, (__bf16*)out, B, T, fh, fw, lo, (unsigned)hi_end, (unsigned)(cq - lo),      \
-                               (unsigned)(cp - lo));                                                                              \
+                               (unsigned)(cp - lo), xcd_env);                                                                     \
         } while (0)
         if (qb == 1 && nw == 2) E2_ATT_V2(2, 1);
         else if (qb == 1 && nw == 4) E2_ATT_V2(4, 1);
