@@ -595,10 +595,11 @@ extern "C" int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool,
     const bool v2_fits = dyn + 2 * V2_KB + 2 * V2_VB + 1024 + 256 <= 160 * 1024;
     if (variant == 0) {
         // measured (profiles/r03_attention_variants.txt): four waves of 32 queries (three workgroups per CU) win on short windows
-        // and small grids; two query blocks per wave (each K / V operand read from LDS feeds two MFMAs) win once a window has
-        // >= 600 queries and the grid still fills the chip twice (1080p T=20: 2634 vs 2777 us; 720p T=10: a tie)
+        // and small grids; two query blocks per wave (each K / V operand read from LDS feeds two MFMAs, and a (window, head)'s
+        // K / V rows are fetched by half as many workgroups) win once the grid still fills the chip twice: 1080p T=20 2634 vs
+        // 2777 us; 720p T=10 a tie in time at half the K / V fetch traffic
         const long long wgs24 = (long long)cdiv(T * WTOK, 256) * nWin * NH * B;
-        variant = !v2_fits ? 1 : (T * WTOK >= 600 && wgs24 >= 1024) ? 24 : 14;
+        variant = !v2_fits ? 1 : (T * WTOK >= 400 && wgs24 >= 1024) ? 24 : 14;
     }
     if (variant != 1 && !v2_fits) variant = 1;                            // very long windows (T > 150): round 2's kernel
     if (variant != 1) {
