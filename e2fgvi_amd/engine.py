@@ -75,6 +75,16 @@ def build_key_table(fh, fw, valid_ind_rolled):
     return tab, nk
 
 
+class _NotBuilt:
+    """stands in for an fp32 layer in the bf16 mode (names / flags may be set on it; calling it is a bug)"""
+
+    def __init__(self, *a, **k):
+        self.name = "not built"
+
+    def __call__(self, *a, **k):
+        raise RuntimeError("fp32 layer %r was not built: this engine runs the bf16 data path" % self.name)
+
+
 class Engine(BF16Path):
     def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32", winograd=True, autotune=True):
         """precision="fp32": every contraction on fp32 MFMA (the default and the parity configuration).
@@ -90,6 +100,11 @@ class Engine(BF16Path):
         self.sd = sd
         f = lambda k: sd[k].float().contiguous()
         self.bf16 = precision == "bf16"
+        # bf16 mode: the fp32 layers are never called (forward_x reads only the LayerNorm / pooling parameters, the key
+        # tables and sc.bias from this constructor) -- do not pack their weights: several hundred MB of device memory (both
+        # the implicit-GEMM and the Winograd packings) and the start-up time of ~150 pack launches
+        PackedConv, PackedLinear, PackedDcn, PackedConvX, PackedTail = (
+            (_NotBuilt,) * 5 if self.bf16 else (ops.PackedConv, ops.PackedLinear, ops.PackedDcn, ops.PackedConvX, ops.PackedTailConv))
         pw = dict(precision="fp32")
         # wide 3x3 / stride-1 layers: fp32 Winograd F(2x2,3x3) whenever the call qualifies (even H, W), else implicit GEMM
         ww = dict(precision="fp32", algo="auto" if winograd else "igemm")
@@ -109,7 +124,7 @@ class Engine(BF16Path):
         self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1, **ww),
                     PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1, **ww),
                     PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1, **ww),
-                    (ops.PackedTailConv(f("decoder.6.weight"), f("decoder.6.bias")) if TAIL_KERNEL else
+                    (PackedTail(f("decoder.6.weight"), f("decoder.6.bias")) if TAIL_KERNEL else
                      PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1))]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)

@@ -238,10 +238,14 @@ class _InpaintGeneratorBase(nn.Module):
         return self.load_state_dict(sd, strict=strict)
 
     def train(self, mode=True):
-        if mode:
-            raise RuntimeError("this InpaintGenerator is the MI355X INFERENCE forward (SURVEY.md 8): the parameter "
-                               "containers have no autograd path; train with the reference implementation and load the "
-                               "checkpoint here (load_state_dict / load_checkpoint)")
+        """nn.Module.train() for generic tooling (wrappers that restore the training flag after an eval pass, Lightning ...):
+        this module is the INFERENCE forward -- the parameter containers have no autograd path -- so the flag
+        stays False; asking for training mode warns once instead of raising."""
+        if mode and not getattr(self, "_warned_train", False):
+            import warnings
+            warnings.warn("this InpaintGenerator is the MI355X inference forward: .train() keeps it in eval mode (train with "
+                          "the reference implementation and load the checkpoint here: load_state_dict / load_checkpoint)")
+            self._warned_train = True
         return super().train(False)
 
     def _fingerprint(self):

@@ -193,8 +193,10 @@ def test_init_weights_variants_and_inference_only_guards():
     assert torch.equal(net.feat_prop_module.deform_align["forward_"].weight, dcn_w)
     with pytest.raises(NotImplementedError):
         net.init_weights("bogus")
-    with pytest.raises(RuntimeError):
-        net.train()
+    with pytest.warns(UserWarning):                        # generic tooling may call .train(): the inference module stays in eval mode
+        assert net.train() is net
+    assert not net.training and all(not m.training for m in net.modules())
+    assert net.train(True) is net and not net.training     # ... and says so only once
     assert net.eval() is net and not net.training
     with pytest.raises(NotImplementedError):
         mod.Discriminator()
