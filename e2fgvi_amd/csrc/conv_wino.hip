@@ -24,6 +24,7 @@
 // to 8 -- a source may be 4 (mod 8) wide, its last half chunk is zero; kq = channel quad; Npad = Cout_g rounded up to
 // 32), produced by e2fgvi_pack_winograd_weight.
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef E2_WINO_VARIANT
 #define E2_WINO_VARIANT 0      // experiment switches (tools only): 1 = mid-stage prefetch of the upper waves, 2 = static s_setprio by SIMD partner, 4 = s_setprio around the MFMA block
@@ -113,8 +114,27 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One LDS-DMA piece of the raw patch (DMA variant below): 64 lanes x 16 bytes of the buffer `rsrc` at the lanes' byte offsets
+// (out-of-range offsets land as zeros) -> LDS bytes [lds_dst, lds_dst + 1024), lds_dst wave-uniform.  Inline asm like the
+// weight loads: hipcc counts neither the load nor any wait for it, the kernel's explicit vmcnt waits cover it, and
+// build.verify_wino_waits() counts it in the disassembly like every other vector-memory instruction.  M0 is written in the
+// statement that reads it and restored (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma_piece(i32x4 rsrc, unsigned lds_dst, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+typedef __attribute__((address_space(3))) void wino_lds_void;
+
 // MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
-template <int MT, int BN, int SC>
+// DMA (round 3): the raw patch goes global -> LDS by LDS-DMA instead of through staging registers + a parking pass of
+// ds_writes.  Each lane fetches the 16-byte unit that belongs at its LDS position (planes [kq][column parity], rows of 12
+// units, 9 used: the rest and the plane padding fetch out of range = zeros), the chunk areas are 1 KiB aligned so that a
+// piece never straddles two chunks (two sources); wave w issues the pieces w, w + 8 of a chunk.  Three LDS stages (they fit
+// under the epilogue's footprint): the pieces of stage st + 2 are issued during stage st, chunk by chunk, right in front of
+// the next chunk's weight loads, so every explicit weight wait is `vmcnt(2 TN + pieces of this wave)` and -- loads return in
+// order -- also retires the wave's pieces of the stage after next; the stage barrier then orders them for the other waves.
+template <int MT, int BN, int SC, bool DMA>
 __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
     static_assert(SC == 2, "chunks per LDS stage (the explicit vmcnt counts of k_loop assume two)");
     constexpr int NT = 512;
@@ -125,15 +145,19 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
     // distinct bank quads; with a pitch of 0 (mod 128) the planes collided 4-way (SQ_LDS_BANK_CONFLICT was 32 % of the LDS
     // cycles, profiles/r02_wino4_pmc_enc10.txt)
     constexpr int PLANE_BYTES = PLANE_RAW + ((16 - PLANE_RAW % 128) + 128) % 128;
-    constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;              // planes of one 8-channel chunk: [kq][column parity]
+    constexpr int CHUNK_USED = 4 * PLANE_BYTES;               // planes of one 8-channel chunk: [kq][column parity]
+    constexpr int CHUNK_BYTES = DMA ? (CHUNK_USED + 1023) / 1024 * 1024 : CHUNK_USED;      // DMA: whole 1-KiB pieces
     constexpr int STAGE_BYTES = SC * CHUNK_BYTES;             // an LDS stage holds SC chunks (one barrier per 8 SC channels)
+    constexpr int NSTAGE = DMA ? 3 : 2;
     constexpr int TILES = 32 * MT;
     constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
-    constexpr int SMEM = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int SMEM = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
+    constexpr int PIECES = CHUNK_BYTES / 1024;                // DMA pieces per chunk; wave w issues w, w + 8, ...
+    constexpr int NPMAX = (PIECES + 7) / 8;
     constexpr int RAW_ITEMS = RAW_H * RAW_W * 2;          // (pixel, kq) of one chunk
     constexpr int RAW_IT = (RAW_ITEMS + NT - 1) / NT;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -164,6 +188,23 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         raw_dst[it] = have ? (kq * 2 + (pxx & 1)) * PLANE_BYTES + (py * PLANE_ROW + (pxx >> 1)) * 16 : -1;
     }
     const unsigned raw_kq16 = (unsigned)(tid & 1) * 16u;            // NT is even: the kq of an item is the thread's parity
+    // ---- DMA variant: the 16-byte LDS unit this lane fills in piece j of its wave (unit U of the chunk area = plane,
+    // patch row, column pair), as the source pixel to fetch it from (OOB: padding / outside the image) and its channel quad
+    unsigned dma_pix[NPMAX], dma_kq16[NPMAX];
+    if constexpr (DMA) {
+        constexpr int UP = PLANE_BYTES / 16;
+#pragma unroll
+        for (int j = 0; j < NPMAX; ++j) {
+            const int U = ((tid >> 6) + 8 * j) * 64 + lane;
+            const int plane = U / UP, r2 = U - plane * UP;
+            const int py = r2 / PLANE_ROW, c = r2 - py * PLANE_ROW;
+            const int pxx = 2 * c + (plane & 1);
+            const int gy = y0 + py, gx = x0 + pxx;
+            const bool in = plane < 4 && py < RAW_H && c < RAW_W / 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            dma_pix[j] = in ? (unsigned)((img * p.H + gy) * p.W + gx) : OOB;
+            dma_kq16[j] = (unsigned)(plane >> 1) * 16u;
+        }
+    }
 
     // Chunks past the end (odd chunk count, prefetch overrun) need no guards: their weight loads fall outside the
     // group's buffer range and return zeros, so whatever patch data is re-read contributes nothing.
@@ -207,6 +248,56 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
 #pragma unroll
             for (int it = 0; it < RAW_IT; ++it)
                 if (raw_dst[it] >= 0) *reinterpret_cast<f32x4*>(base + q * CHUNK_BYTES + raw_dst[it]) = rraw[q][it];
+    };
+
+    const unsigned smem_lds = (unsigned)(unsigned long long)(wino_lds_void*)smem;
+    const float* const dsp0 = p.src[0]; const float* const dsp1 = p.src[1]; const float* const dsp2 = p.src[2]; const float* const dsp3 = p.src[3];
+    const unsigned dsb0 = p.src_bytes[0], dsb1 = p.src_bytes[1], dsb2 = p.src_bytes[2], dsb3 = p.src_bytes[3];
+    const unsigned dsl0 = (unsigned)p.ld[0] * 4u, dsl1 = (unsigned)p.ld[1] * 4u, dsl2 = (unsigned)p.ld[2] * 4u, dsl3 = (unsigned)p.ld[3] * 4u;
+    const unsigned dsc0 = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u, dsc1 = (unsigned)(p.coff[1] + g * p.cpg[1]) * 4u,
+                   dsc2 = (unsigned)(p.coff[2] + g * p.cpg[2]) * 4u, dsc3 = (unsigned)(p.coff[3] + g * p.cpg[3]) * 4u;
+    const int dsg0 = p.cpg[0], dsg1 = p.cpg[1], dsg2 = p.cpg[2], dsg3 = p.cpg[3];
+    // DMA variant: the pieces of this wave (W_ = its index, NPW_ = how many) of the NEXT chunk of the source walk into the
+    // chunk area at LDS byte address lds_chunk.  Exactly NPW vector-memory instructions on every path (the explicit waits).
+    // The chunk -> (source, channel) map is STATELESS here (chunk index -> source by comparing with the per-source chunk
+    // prefixes, everything captured by value): with the running (source, channel) state of load_raw, mutated inside this
+    // lambda from 48 inlined call sites, hipcc left the closure -- and with it the whole parameter block -- in scratch
+    // memory (hundreds of scratch loads + its own vmcnt waits in the K loop).  Chunks past the end re-read the last chunk:
+    // their weights are zeros.
+    const int dpre1 = (dsg0 + 7) / 8, dpre2 = dpre1 + (p.nsrc > 1 ? (dsg1 + 7) / 8 : 0), dpre3 = dpre2 + (p.nsrc > 2 ? (dsg2 + 7) / 8 : 0);
+    const int dnsrc = p.nsrc, dlast = p.nchunks - 1;
+    auto dma_chunk = [=, &dma_pix, &dma_kq16](auto W_, auto NPW_, int chunk, unsigned lds_chunk) __attribute__((always_inline)) {
+        constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
+        const int k = chunk < dlast ? chunk : dlast;
+        const int sidx = (dnsrc > 1 && k >= dpre1 ? 1 : 0) + (dnsrc > 2 && k >= dpre2 ? 1 : 0) + (dnsrc > 3 && k >= dpre3 ? 1 : 0);
+        // a select of four values as arithmetic: hipcc turns `sidx == 0 ? a : sidx == 1 ? b : ...` over adjacent closure fields
+        // into an indexed load from the closure, which then has to live in scratch memory
+        // (one source: nothing to select -- the common case, kept free of the 64-bit select arithmetic)
+        const unsigned long long m1 = dnsrc > 1 && sidx == 1, m2 = dnsrc > 2 && sidx == 2, m3 = dnsrc > 3 && sidx == 3;
+        auto sel = [=](unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long d) {
+            return a + m1 * (b - a) + m2 * (c - a) + m3 * (d - a);
+        };
+        const float* csrc = dsp0;
+        unsigned cbytes = dsb0, cld4 = dsl0, cchan = dsc0;
+        int ccpg = dsg0, cc0 = k * 8;
+        if (dnsrc > 1) {                           // wave-uniform
+            csrc = reinterpret_cast<const float*>(sel((unsigned long long)dsp0, (unsigned long long)dsp1, (unsigned long long)dsp2,
+                                                      (unsigned long long)dsp3));
+            cbytes = (unsigned)sel(dsb0, dsb1, dsb2, dsb3);
+            cld4 = (unsigned)sel(dsl0, dsl1, dsl2, dsl3);
+            cchan = (unsigned)sel(dsc0, dsc1, dsc2, dsc3);
+            ccpg = (int)sel((unsigned)dsg0, (unsigned)dsg1, (unsigned)dsg2, (unsigned)dsg3);
+            cc0 = (k - (int)sel(0u, (unsigned)dpre1, (unsigned)dpre2, (unsigned)dpre3)) * 8;
+        }
+        const i32x4 rs = rsrc_words(csrc, cbytes);
+        const unsigned chan = cchan + (unsigned)cc0 * 4u;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const bool cvalid = cc0 + (int)(dma_kq16[j] >> 2) < ccpg;       // a source may end in the middle of a chunk
+            unsigned off = (cvalid && dma_pix[j] != OOB) ? dma_pix[j] * cld4 + chan + dma_kq16[j] : OOB;
+            asm volatile("" : "+v"(off));
+            dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
+        }
     };
 
     // ---- this wave's transform positions: xi = wave >> 1, nu in {0,1} (pair A) or {2,3} (pair B)
@@ -269,17 +360,19 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
                 for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
 
     const int nstages = (p.nchunks + SC - 1) / SC;
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
-    load_b(0, bq[0]);
-    store_raw(0);
+        for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
+        load_b(0, bq[0]);
+        store_raw(0);
 #pragma unroll
-    for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
-    __syncthreads();
+        for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
+        __syncthreads();
+    }
 
     E2T(unsigned long long tsum[5]; for (int k_ = 0; k_ < 5; ++k_) tsum[k_] = 0; const unsigned long long t_k0 = E2T_NOW();)
     // the K loop, specialised on the wave's role so that the input transform is plain adds / subtracts
-    auto k_loop = [&](auto XI_, auto PB_) {
+    auto k_loop = [&](auto XI_, auto PB_) __attribute__((always_inline)) {
         constexpr int XI = decltype(XI_)::value;
         constexpr bool PB = decltype(PB_)::value != 0;
         // Waves w and w + 4 share a SIMD.  Measured with tools/wino_timing.py (profiles/r02_wino_timing.txt): per stage a wave
@@ -289,6 +382,58 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         // buffer is free for the whole stage (its readers passed the previous barrier) and the stage barrier still follows
         // every wave's stores.
         constexpr bool LATE = XI >= 2 && (E2_WINO_VARIANT & 1);
+        if constexpr (DMA) {
+            constexpr int WV = 2 * XI + (PB ? 1 : 0);                  // this wave
+            constexpr int NPW = (PIECES - WV + 7) / 8;                 // its pieces per chunk
+            // prologue: stages 0 and 1 (chunks 0 .. 3) and the first chunk's weights, waited for in full
+#pragma unroll
+            for (int c4 = 0; c4 < 2 * SC; ++c4)
+                dma_chunk(IC<WV>{}, IC<NPW>{}, c4, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
+            load_b(0, bq[0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int slot = 0;
+            for (int st = 0; st < nstages; ++st) {
+                const unsigned char* stage = smem + slot * STAGE_BYTES;
+                const unsigned ahead = smem_lds + (unsigned)((slot == 0 ? 2 : slot - 1) * STAGE_BYTES);   // stage st + 2's slot
+#pragma unroll
+                for (int q = 0; q < SC; ++q) {
+                    dma_chunk(IC<WV>{}, IC<NPW>{}, SC * (st + 2) + q, ahead + (unsigned)(q * CHUNK_BYTES));   // its readers passed the last barrier
+                    load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);            // next chunk's weights land during this chunk
+                    // issued since this chunk's weights: the NPW pieces above and the next chunk's 2 TN weight loads; loads
+                    // return in order, so the wait also retires this wave's pieces of stage st + 1 (issued a stage ago)
+                    claim_b(IC<2 * TN + NPW>{}, bq[q & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned char* raw = stage + q * CHUNK_BYTES;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const unsigned char* rm = raw + m * (8 * PLANE_ROW * 16);
+                        f32x4 e[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(rm + a_off[0][j]);
+                            const f32x4 d1 = *reinterpret_cast<const f32x4*>(rm + a_off[1][j]);
+                            e[j] = XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
+                        }
+                        const f32x4 va = PB ? e[1] - e[0] : e[0] - e[2];
+                        const f32x4 vb = PB ? e[0] - e[2] : e[1] + e[2];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n) {
+                                acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[k], bq[q & 1][0][n][k], acc[0][m][n], 0, 0, 0);
+                                acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q & 1][1][n][k], acc[1][m][n], 0, 0, 0);
+                            }
+                    }
+                }
+                __syncthreads();        // everybody's pieces of stage st + 1 have landed (each wave waited for its own above)
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            // pieces issued for stages past the end are still in flight and target LDS the epilogue is about to reuse
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return;
+        }
         if (E2_WINO_VARIANT & 2) __builtin_amdgcn_s_setprio(XI >= 2 ? 1 : 2);      // static priority by SIMD partner
         for (int st = 0; st < nstages; ++st) {
             const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
@@ -523,7 +668,7 @@ extern "C" int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32
     return 0;
 }
 
-template <int MT, int BN, int SC>
+template <int MT, int BN, int SC, bool DMA>
 static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     p.blocksY = cdiv(p.H, 8 * MT);
     p.blocksX = cdiv(p.W, 16);
@@ -531,7 +676,7 @@ static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC, DMA>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd");
     return 0;
 }
@@ -590,11 +735,19 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
         const long long big = (long long)d->N * cdiv(d->H, 16) * cdiv(d->W, 16) * cdiv(q.Cout_g, 64) * d->groups;
         tile = (q.Cout_g >= 256 && big >= 128) ? 64 : 132;
     }
+    // + 1000: the same block shape with the raw patch staged by LDS-DMA (round 3); E2FGVI_WINO_DMA=1 makes it the default
+    static int dma_env = -1;
+    if (dma_env < 0) { const char* e = getenv("E2FGVI_WINO_DMA"); dma_env = e ? atoi(e) : 0; }
+    if (tile < 1000 && dma_env) tile += 1000;
     switch (tile) {
-        case 64: return launch_wino<2, 64, 2>(p, d->groups, st);
-        case 32: return launch_wino<2, 32, 2>(p, d->groups, st);
-        case 164: return launch_wino<1, 64, 2>(p, d->groups, st);
-        case 132: return launch_wino<1, 32, 2>(p, d->groups, st);
+        case 64: return launch_wino<2, 64, 2, false>(p, d->groups, st);
+        case 32: return launch_wino<2, 32, 2, false>(p, d->groups, st);
+        case 164: return launch_wino<1, 64, 2, false>(p, d->groups, st);
+        case 132: return launch_wino<1, 32, 2, false>(p, d->groups, st);
+        case 1064: return launch_wino<2, 64, 2, true>(p, d->groups, st);
+        case 1032: return launch_wino<2, 32, 2, true>(p, d->groups, st);
+        case 1164: return launch_wino<1, 64, 2, true>(p, d->groups, st);
+        case 1132: return launch_wino<1, 32, 2, true>(p, d->groups, st);
         // (four chunks per LDS stage -- half the barriers -- measured 1-6 % slower on every layer, profiles/r02_wino_sc4.txt)
         default: break;
     }
