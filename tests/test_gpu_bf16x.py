@@ -154,7 +154,9 @@ def test_conv_bf16x_argument_errors(dev):
 
 
 @pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 4, 60, 108),
-                                       (1, 10, 10, 18)])     # T = 10: 15 query tiles per window -> 8 query waves per workgroup (8 + 7)
+                                       (1, 10, 10, 18),     # T = 10: 15 query tiles per window -> 8 query waves per workgroup (8 + 7)
+                                       (1, 40, 5, 9)])      # a long window (test.py with many reference frames): 8400 keys, the
+                                                            # key-row table pushes the LDS-DMA kernel past 64 KiB of LDS
 def test_focal_attention_bf16(dev, B, T, fh, fw):
     """bf16 fused attention vs the oracle's roll / partition / cat / softmax chain evaluated in fp32 on the SAME
     bf16-rounded qkv rows.  What differs is the kernel's own rounding: the probabilities P are rounded to bf16 before the

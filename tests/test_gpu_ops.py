@@ -240,7 +240,7 @@ def test_mdcn_argument_errors(dev):
         layer([torch.randn(1, 8, 8, 16, device=dev)], torch.randn(1, 8, 8, 54, device=dev))
 
 
-@pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 2, 15, 45)])
+@pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 2, 15, 45), (1, 40, 5, 9)])
 def test_focal_attention(dev, B, T, fh, fw):
     """fused attention vs the oracle's roll/partition/cat/softmax chain (pre-projection output)."""
     from e2fgvi_amd import ops
