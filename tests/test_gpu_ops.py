@@ -271,8 +271,9 @@ def test_focal_attention(dev, B, T, fh, fw):
         outs[waves] = out
     # same arithmetic in the same key order (34 / 32 vs 14 / 12: two key groups each; on a small grid the launcher gives
     # 4 / 2 two key groups as well, 24 / 22 always one: another summation order): agreement to fp32 summation noise
+    agree = 2e-5 * max(1.0, (T * 210 / 840.0) ** 0.5)          # summation noise grows with the square root of the key count
     for a, b_ in ((24, 4), (22, 2), (34, 14), (32, 12)):
-        assert_close(outs[a], outs[b_], 2e-5, "LDS-DMA kernel (waves=%d) vs the register-staged one (waves=%d)" % (a, b_))
+        assert_close(outs[a], outs[b_], agree, "LDS-DMA kernel (waves=%d) vs the register-staged one (waves=%d)" % (a, b_))
 
 
 @pytest.mark.parametrize("B,T,fh,fw,far", [(1, 4, 60, 108, False), (1, 4, 90, 162, False), (1, 4, 60, 108, True)])
