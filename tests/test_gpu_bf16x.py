@@ -515,3 +515,28 @@ def test_softcomp_gather(dev, F_, fh, fw, dtype):
         old = ops.softcomp_fold(lin(tok.to(dev).bfloat16().view(-1, hid)), F_, fh, fw, 3 * fh, 3 * fw, C_)
         # the old path rounds the [tokens, 6272] tensor to bf16 before the fold: up to 9 extra roundings per pixel
         assert_close(out.float(), old.float(), 8e-2, "gather form vs Linear + fold kernels")
+
+
+def test_bf16_attention_and_tail_reruns_are_bit_identical(dev):
+    """200 launches each of the bf16 attention kernel (both default variants) and of the decoder tail kernel on bf16 sources
+    must agree bit for bit: both units hold LDS-fed bf16 MFMA streams beside fp32 VALU work and are built without packed-fp32
+    VALU (build.py); a 3 % per-launch event is missed with p < 1 %."""
+    from e2fgvi_amd import ops
+    from e2fgvi_amd.engine import build_key_table
+    from e2fgvi_amd.synth import rolled_valid_index
+    g = _gen(17)
+    B, T, fh, fw = 1, 4, 20, 36
+    rows, nwin = B * T * fh * fw, (fh // 5) * (fw // 9)
+    both = (torch.randn(rows + B * T * nwin, 1536, generator=g) * 0.5).bfloat16().to(dev)
+    tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
+    tab, nk = torch.from_numpy(tab).to(dev), torch.from_numpy(nk).to(dev)
+    for variant in (14, 24):
+        ref = ops.focal_attention_bf16(both[:rows], both[rows:], tab, nk, B, T, fh, fw, variant=variant)
+        for _ in range(200):
+            assert torch.equal(ops.focal_attention_bf16(both[:rows], both[rows:], tab, nk, B, T, fh, fw, variant=variant), ref), variant
+    x = torch.randn(2, 40, 72, 64, generator=g).bfloat16().to(dev)
+    tail = ops.PackedTailConv((torch.randn(3, 64, 3, 3, generator=g) / 24).to(dev), (torch.randn(3, generator=g) * 0.1).to(dev),
+                              dtype=torch.bfloat16)
+    ref = tail([x], act=ops.ACT_TANH)
+    for _ in range(200):
+        assert torch.equal(tail([x], act=ops.ACT_TANH), ref)
