@@ -60,3 +60,32 @@ def test_planar16_layout_is_a_permutation_of_nhwc():
     g, n, yy, xx, c = 1, 1, 2, 4, 7
     assert p[g, n, yy, xx, c] == x[n, yy, xx, g * 16 + c]
     assert torch.equal(p.permute(1, 2, 3, 0, 4).reshape(2, 3, 5, 32), x)
+
+
+def test_softcomp_fold_is_nine_phase_convolutions_of_the_token_grid():
+    """Round 3 (ops.SoftCompGather): nn.Fold(7x7, stride 3, padding 3) of Linear(hidden -> 49 C) -- SoftComp,
+    model/modules/tfocal_transformer.py:49-72 -- equals nine small convolutions over the token grid, phase (py, px) writing the
+    pixels (3 ty + py, 3 tx + px): kernel rows ky read token rows ty - pad + ky with pad = 1 (py = 0: taps ki = 6, 3, 0) or
+    pad = 0 (py = 1, 2: taps ki = py + 3, py), zero rows outside the grid; the Linear's bias folds to a per-pixel image."""
+    g = _gen(3)
+    F_, fh, fw, hid, C = 2, 5, 7, 24, 6
+    w = torch.randn(49 * C, hid, generator=g, dtype=torch.float64) / 8            # row c*49 + ki*7 + kj
+    b = torch.randn(49 * C, generator=g, dtype=torch.float64)
+    tok = torch.randn(F_, fh, fw, hid, generator=g, dtype=torch.float64)
+    emb = F.linear(tok.view(F_, fh * fw, hid), w, b)
+    ref = F.fold(emb.permute(0, 2, 1), output_size=(3 * fh, 3 * fw), kernel_size=(7, 7), stride=(3, 3), padding=(3, 3))
+    bias_img = F.fold(b.view(1, 49 * C, 1).expand(1, 49 * C, fh * fw), output_size=(3 * fh, 3 * fw), kernel_size=(7, 7),
+                      stride=(3, 3), padding=(3, 3))
+    out = bias_img.expand(F_, C, 3 * fh, 3 * fw).clone()
+    w4 = w.view(C, 7, 7, hid)
+    x = tok.permute(0, 3, 1, 2)                                                    # [F, hid, fh, fw]
+    for py in range(3):
+        ky_taps, pad_y = ([6, 3, 0], 1) if py == 0 else ([py + 3, py], 0)
+        for px in range(3):
+            kx_taps, pad_x = ([6, 3, 0], 1) if px == 0 else ([px + 3, px], 0)
+            wp = w4[:, ky_taps][:, :, kx_taps].permute(0, 3, 1, 2)                 # [C, hid, kh, kw]
+            kh, kw = len(ky_taps), len(kx_taps)
+            # explicit output grid fh x fw: pad_y rows above / pad_x columns left, whatever else the kernel reaches is zero
+            xp = F.pad(x, (pad_x, kw - 1 - pad_x, pad_y, kh - 1 - pad_y))
+            out[:, :, py::3, px::3] += F.conv2d(xp, wp)
+    assert torch.allclose(out, ref, rtol=0, atol=1e-11)
