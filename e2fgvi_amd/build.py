@@ -23,11 +23,11 @@ NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # units hold bf16 MFMA streams, so they are kept free of packed fp32 as well (measured neutral) -- a later epilogue edit that
 # touches VMEM-fresh registers then cannot re-enter the hazard silently; 200-launch bit-identity reruns in the GPU tests.
 UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
-         ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", NOPK),
+         ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino.hip", "conv_wino_x3.o", NOPK + ["-DE2_WINO_X3=1"]), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", NOPK),
          ("mdcn.hip", "mdcn.o", NOPK), ("attention.hip", "attention.o", []),
          ("attention_bf16.hip", "attention_bf16.o", NOPK), ("misc.hip", "misc.o", NOPK),
          ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]
-NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "conv_tail.o", "mdcn.o", "attention_bf16.o", "misc.o", "video.o", "metrics.o")
+NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "conv_wino_x3.o", "conv_tail.o", "mdcn.o", "attention_bf16.o", "misc.o", "video.o", "metrics.o")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
@@ -166,7 +166,7 @@ def check_kernel_waits(obj, name, ins):
     return loops
 
 
-def verify_wino_waits(objdir=None, objects=("conv_wino.o", "conv_wino4.o")):
+def verify_wino_waits(objdir=None, objects=("conv_wino.o", "conv_wino_x3.o", "conv_wino4.o")):
     """The Winograd kernels issue their weight loads through pinned inline asm and wait for them with an explicit
     ``s_waitcnt vmcnt(N)`` whose N is the number of vector-memory instructions issued since (conv_wino.hip): a count the
     compiler does not maintain.  This check re-derives it from the generated code on every build.  The explicit waits are

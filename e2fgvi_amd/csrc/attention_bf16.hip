@@ -270,6 +270,9 @@ __global__ __launch_bounds__(64 * NW) void focal_attn_bf16_kernel(const __bf16* 
 //   * small workgroups (NW waves x 32 QB queries) of which several are resident per CU: the waves of different workgroups
 //     are not tied to each other's barriers, so one's softmax overlaps another's MFMAs;
 //   * softmax per element: max, fma (scale and shift folded), exp2, add; the out-of-range mask only in the last tile.
+#ifndef E2_ATT_SETPRIO
+#define E2_ATT_SETPRIO 0      // experiment switch (tools): s_setprio(1) around the MFMA clusters of the tile loop
+#endif
 constexpr int V2_KB = TK * HD * 2;                // 8 KB: K tile, [32 keys][16 slots of 16 bytes]
 constexpr int V2_VB = TK * HD * 2;                // 8 KB: V tile, row-major, slots permuted per row
 typedef __attribute__((address_space(3))) void v2_lds_void;
@@ -463,12 +466,14 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
             for (int j = 0; j < QB; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+            if (E2_ATT_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(cK + (k_base ^ (32 * kk)));
 #pragma unroll
                 for (int j = 0; j < QB; ++j) s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q[j][kk], s[j], 0, 0, 0);
             }
+            if (E2_ATT_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (kt == ntiles - 1) {                             // rows past the last key: out of the softmax
 #pragma unroll
                 for (int j = 0; j < QB; ++j)
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pk[j][kk][e] = (__bf16)s[j][kk * 8 + e];
             }
+            if (E2_ATT_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -524,6 +530,7 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
 #pragma unroll
                     for (int j = 0; j < QB; ++j) acc[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pk[j][kk], acc[j][dt], 0, 0, 0);
                 }
+            if (E2_ATT_SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt + 1 have landed
         __syncthreads();

@@ -70,6 +70,32 @@ __device__ __forceinline__ float dcn_post(float v, int co, int C, const f32x4& f
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
+// x = hi + mid + lo with bf16 pieces: hi / mid by clearing the low 16 bits (so x - hi and (x - hi) - mid are exact fp32
+// differences), lo = the rest (<= 8 significant bits: its bf16 conversion is exact too).  Non-finite inputs give NaN.
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    unsigned x[8], rb[8];
+    float r2[8];
+    const u32x4 b0 = __builtin_bit_cast(u32x4, v0), b1 = __builtin_bit_cast(u32x4, v1);   // (whole vectors: a bit_cast of one
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = b0[j]; x[4 + j] = b1[j]; }                       //  ELEMENT of a vector reference reads element 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = __builtin_bit_cast(float, x[j]) - __builtin_bit_cast(float, x[j] & 0xFFFF0000u);
+        rb[j] = __builtin_bit_cast(unsigned, r);
+        r2[j] = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
+    }
+    u32x4 H, M, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                // element 2j in the low half of dword j
+        H[j] = __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], 0x07060302u);
+        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
+        L[j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2[2 * j + 1]), __builtin_bit_cast(unsigned, r2[2 * j]), 0x07060302u);
+    }
+    hi = __builtin_bit_cast(bf16x8, H);
+    mid = __builtin_bit_cast(bf16x8, M);
+    lo = __builtin_bit_cast(bf16x8, L);
+}
+
 // Two LDS stages: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.
 // (A third stage with counted vmcnt waits was measured slower on every layer -- it costs the second resident workgroup --
 // and was removed, profiles/r02_bf16x_conv_microbench.txt.)
@@ -79,21 +105,33 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __b
 // m0 + BM, vertical offset ky - 1 applied), tap kx reads rows r + kx, and the two lanes whose neighbour would wrap into
 // another image row (x = 0 with kx = 0, x = W - 1 with kx = 2) zero their operand instead.  A DMA per 9 taps: 3 stages of
 // BM + 2 rows instead of 9 of BM; the weights are fetched per tap as before.  K walk: ky -> source -> block -> kx.
-// F32 = true: the same kernel on fp32 operands (fp32 NHWC sources, fp32 packed weights, v_mfma_f32_32x32x2_f32 -- exact fp32):
+// MODE 1 (F32): the same kernel on fp32 operands (fp32 NHWC sources, fp32 packed weights, v_mfma_f32_32x32x2_f32 -- exact fp32):
 // a K-step is then 32 channels (the same 128-byte rows, 16-byte chunks of 4 channels), everything else -- DMA, swizzle,
 // stages, epilogue -- is shared.  Used by the fp32 path for its GEMM-shaped layers (token Linears, SoftSplit / SoftComp).
-template <int BM, int BN, int WGM, int WGN, bool S3, bool F32>
+// MODE 2 (X3): fp32 operands on the bf16 matrix pipe by EXACT three-way splitting.  An fp32 number is the sum of three bf16
+// numbers (8 + 8 + 8 significand bits: hi = x with its low 16 bits cleared, mid = (x - hi) likewise, lo = x - hi - mid, each
+// difference exact in fp32), so a product a*b is the sum of nine bf16 products, each of them exact in the MFMA's fp32
+// accumulator; the three smallest (mid*lo, lo*mid, lo*lo: <= 2^-22 of |a*b| together) are dropped, the other six are
+// issued -- 6 bf16 MFMAs of 32 cycles for the work of 8 fp32 MFMAs of 64: 2.7x the matrix rate at fp32-level rounding
+// (the measured error against an fp64 reference is that of the exact-fp32 kernel, tests/test_gpu_x3.py).  The A stage is
+// MODE 1's (fp32 rows, same DMA, same swizzle): a lane reads its 8 consecutive channels as two 16-byte chunks and splits
+// them in registers (44 VALU per fragment, shared by the 6 x TN MFMAs it feeds); the weights are split once, at packing
+// time, into three bf16 planes: a B stage is [3 planes][4 k-octets][BN][8 bf16].
+template <int BM, int BN, int WGM, int WGN, bool S3, int MODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
+    constexpr bool F32 = MODE == 1, X3 = MODE == 2;
     constexpr int NT = 64 * WGM * WGN;
-    constexpr int ESZ = F32 ? 4 : 2;                            // operand element size
+    constexpr int ESZ = MODE ? 4 : 2;                           // activation element size
     constexpr int CH = 16 / ESZ;                                // channels per 16-byte chunk
     constexpr int KC = 8 * CH;                                  // channels per K-step (128-byte rows)
     constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
     constexpr int AR = S3 ? BM + 2 : BM;                        // rows of an A stage
-    constexpr int A_BYTES = AR * 128, B_BYTES = BN * 128;       // one K-step stage of each operand
-    constexpr int A_IT = (AR * 8 + NT - 1) / NT, B_IT = BN * 8 / NT;   // 16-byte DMA items per thread
+    constexpr int B_CH = X3 ? 12 : 8;                           // 16-byte chunks per output column in a B stage
+    constexpr int A_BYTES = AR * 128, B_BYTES = BN * B_CH * 16; // one K-step stage of each operand
+    constexpr int A_IT = (AR * 8 + NT - 1) / NT, B_IT = (BN * B_CH + NT - 1) / NT;   // 16-byte DMA items per thread
     constexpr bool A_PART = (AR * 8) % NT != 0;                 // the last A iteration is partial (S3: 16 extra items)
+    constexpr bool B_PART = (BN * B_CH) % NT != 0;              // (X3, 32-column tile: whole waves drop out)
     constexpr int R = TM * 32, CN = TN * 32;                    // a wave's output block
     // the epilogue parks the accumulators in LDS, the whole block at once or (256x256 tile) in two column halves
     constexpr int ES = (WGM * WGN * R * (CN + 4) * 4 > 150 * 1024) ? 2 : 1;
@@ -102,7 +140,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     static_assert(TN % ES == 0 && EPI <= 160 * 1024, "epilogue region");
     constexpr int SMEM = 2 * (A_BYTES + B_BYTES) > EPI ? 2 * (A_BYTES + B_BYTES) : EPI;   // A stages first, then B stages
     constexpr unsigned OOB = 0xFFFFFFFFu;
-    static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile");
+    static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * B_CH) % 64 == 0 && SMEM <= 160 * 1024, "tile");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
@@ -148,10 +186,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     for (int it = 0; it < B_IT; ++it) {
         const int item = tid + it * NT;
         const int koct = item / BN, n = item - koct * BN;
-        b_off[it] = (n0 + n) < p.Npad ? (unsigned)((koct * p.Npad + n0 + n) * 16) : OOB;
+        b_off[it] = ((n0 + n) < p.Npad && koct < B_CH) ? (unsigned)((koct * p.Npad + n0 + n) * 16) : OOB;
     }
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_elems * ESZ, p.wgroup_bytes);
-    const unsigned b_step = 8u * (unsigned)p.Npad * 16u;          // packed-weight bytes per K-step
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes, p.wgroup_bytes);
+    const unsigned b_step = (unsigned)B_CH * (unsigned)p.Npad * 16u;   // packed-weight bytes per K-step
 
     // walk of the K-steps: tap (ky, kx) -> source s -> 64-channel block c0.  The per-source parameters are read from the
     // kernel arguments ONCE (indexing the argument arrays per step costs dependent scalar loads and a wait in the loop).
@@ -213,7 +251,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         const unsigned soff = (unsigned)step * b_step;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(sb + it * NT * 16), 16, b_off[it], soff, 0, 0);
+            if (!B_PART || it + 1 < B_IT || tid + it * NT < BN * B_CH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void*)(sb + it * NT * 16), 16, b_off[it], soff, 0, 0);
     };
     auto advance = [&]() -> bool {                                // next (source, block); past the last one: next tap / kernel row
         c0 += KC;
@@ -262,6 +301,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
             a_key[tm] = (row >> 1) & 7;
             zero[tm] = S3 && ((kxs == 0 && !okl[tm]) || (kxs == 2 && !okr[tm]));
         }
+        if constexpr (X3) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int q = 2 * kk + h;                        // this half-wave's k-octet of the step (8 channels = chunks 2q, 2q + 1)
+                bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    split8(*reinterpret_cast<const f32x4*>(st + a_rd[tm] + (((2 * q) ^ a_key[tm]) << 4)),
+                           *reinterpret_cast<const f32x4*>(st + a_rd[tm] + (((2 * q + 1) ^ a_key[tm]) << 4)), ah[tm], am[tm], al[tm]);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + q * (BN * 16));
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + (4 + q) * (BN * 16));
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + (8 + q) * (BN * 16));
+                    // smallest terms first; the TM accumulators of a term are independent
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bm, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tm], bh, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bm, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh, acc[tm][tn], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if constexpr (F32) {
@@ -301,6 +370,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
             }
+        }
         }
     };
     const bool tap_packed = !S3 && p.tp_cq != 0;          // its first A stage is issued by the packed branch below
@@ -631,6 +701,26 @@ bool geometry_x(int Cout, int groups, int KH, int KW, int nsrc, const int32_t* c
     return true;
 }
 
+// the weight that multiplies element e of 16-byte activation chunk koct of K-step `step` (group g, output column n)
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, const PackX& p, int g, int step, int koct, int n, int e) {
+    if (p.tp_cq) {                        // tap-packed: chunk L = 8 step + koct of the stream = tap L / cq, channels (L % cq) * 8 ...
+        const int L = 8 * step + koct;
+        const int tapk = L / p.tp_cq;
+        const int chk = (L - tapk * p.tp_cq) * p.ch + e;
+        if (tapk < p.KH * p.KW && chk < p.cpg[0] && n < p.Cout_g)
+            return w[((long long)n * p.Cin_g + chk) * (p.KH * p.KW) + tapk];
+        return 0.f;
+    }
+    const int tap = step / p.steps_per_tap;
+    int blk = step - tap * p.steps_per_tap;
+    int s = 0, prefix = 0;
+    while (blk >= (p.cpg[s] + p.kc - 1) / p.kc) { blk -= (p.cpg[s] + p.kc - 1) / p.kc; prefix += p.cpg[s]; ++s; }
+    const int c = blk * p.kc + koct * p.ch + e;
+    if (c < p.cpg[s] && n < p.Cout_g)
+        return w[((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + c) * (p.KH * p.KW) + tap];
+    return 0.f;
+}
+
 // packed layout [group][K-step][8 chunks][Npad][ch elements]
 template <typename T>
 __global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __restrict__ wp, const PackX p) {
@@ -644,42 +734,56 @@ __global__ void pack_conv_weight_x_kernel(const float* __restrict__ w, T* __rest
     rem /= p.Npad;
     const int koct = (int)(rem & 7);
     const int step = (int)(rem >> 3);
-    if (p.tp_cq) {                        // tap-packed: chunk L = 8 step + koct of the stream = tap L / cq, channels (L % cq) * 8 ...
-        const int L = 8 * step + koct;
-        const int tapk = L / p.tp_cq;
-        const int chk = (L - tapk * p.tp_cq) * p.ch + e;
-        float vk = 0.f;
-        if (tapk < p.KH * p.KW && chk < p.cpg[0] && n < p.Cout_g)
-            vk = w[((long long)n * p.Cin_g + chk) * (p.KH * p.KW) + tapk];
-        wp[idx] = (T)vk;
-        return;
-    }
-    const int tap = step / p.steps_per_tap;
-    int blk = step - tap * p.steps_per_tap;
-    int s = 0, prefix = 0;
-    while (blk >= (p.cpg[s] + p.kc - 1) / p.kc) { blk -= (p.cpg[s] + p.kc - 1) / p.kc; prefix += p.cpg[s]; ++s; }
-    const int c = blk * p.kc + koct * p.ch + e;
-    float v = 0.f;
-    if (c < p.cpg[s] && n < p.Cout_g)
-        v = w[((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + c) * (p.KH * p.KW) + tap];
-    wp[idx] = (T)v;
+    wp[idx] = (T)pack_value(w, p, g, step, koct, n, e);
+}
+
+// X3 packing: the fp32 geometry (32 channels per K-step, 4 per activation chunk), every weight split into three bf16 pieces
+// (hi / mid by clearing the low 16 bits of the value / of the exact remainder, lo = what is left: the sum is the weight,
+// bit for bit).  Layout [group][K-step][plane hi, mid, lo][4 k-octets][Npad][8 bf16]; one thread per fp32 weight.
+__global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const PackX p) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.total) return;
+    const int g = (int)(idx / p.wgroup_elems);
+    long long rem = idx - (long long)g * p.wgroup_elems;
+    const int e = (int)(rem & 3);
+    rem >>= 2;
+    const int n = (int)(rem % p.Npad);
+    rem /= p.Npad;
+    const int koct = (int)(rem & 7);
+    const int step = (int)(rem >> 3);
+    const float v = pack_value(w, p, g, step, koct, n, e);
+    const unsigned xb = __builtin_bit_cast(unsigned, v);
+    const float r = v - __builtin_bit_cast(float, xb & 0xFFFF0000u);
+    const unsigned rb = __builtin_bit_cast(unsigned, r);
+    const float r2 = r - __builtin_bit_cast(float, rb & 0xFFFF0000u);
+    const long long plane = 4LL * p.Npad * 8;
+    unsigned short* o = wp + (long long)g * p.wgroup_elems * 3 + (long long)step * 3 * plane +
+                        ((long long)(koct >> 1) * p.Npad + n) * 8 + (koct & 1) * 4 + e;
+    o[0] = (unsigned short)(xb >> 16);
+    o[plane] = (unsigned short)(rb >> 16);
+    o[2 * plane] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool S3>
-int launch_x(ConvXParams& p, int groups, hipStream_t st, bool f32 = false) {
+int launch_x(ConvXParams& p, int groups, hipStream_t st, int mode = 0) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout_g, BN);
     if (S3 && !(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1)) {
         e2fgvi_set_error("conv2d_bf16x: the row-shift tiles (11..17) are for 3x3 stride-1 pad-1 layers");
         return E2FGVI_EINVAL;
     }
-    if (f32) {
-        if constexpr (!S3)
-            hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, true>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
-        else
+    if (mode) {
+        if constexpr (!S3) {
+            if (mode == 2)
+                hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, 2>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+            else
+                hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, 1>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+        } else {
+            e2fgvi_set_error("conv2d_f32x: the row-shift tiles (11..18) take bf16 operands only");
             return E2FGVI_EUNSUP;
+        }
     } else {
-        hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, S3, false>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+        hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, S3, 0>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
     }
     E2_LAUNCH_CHECK("conv2d_x");
     return 0;
@@ -726,6 +830,28 @@ extern "C" int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int3
     hipLaunchKernelGGL(pack_conv_weight_x_kernel<float>, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
                        w, wpacked, q);
     E2_LAUNCH_CHECK("pack_conv_weight_f32x");
+    return 0;
+}
+
+/* X3 (fp32 on the bf16 matrix pipe): the fp32 geometry, three bf16 planes per weight -> 3 x the element count, in bf16 */
+extern "C" int64_t e2fgvi_packed_conv_weight_f32x3_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW, int32_t nsrc,
+                                                        const int32_t* src_cpg) {
+    PackX q;
+    if (!src_cpg || !geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q, true)) {
+        e2fgvi_set_error("packed_conv_weight_f32x3_size: bad geometry (channels per source must be multiples of 4)");
+        return E2FGVI_EINVAL;
+    }
+    return 3 * q.total;
+}
+
+extern "C" int e2fgvi_pack_conv_weight_f32x3(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH,
+                                             int32_t KW, int32_t nsrc, const int32_t* src_cpg, void* stream) {
+    PackX q;
+    E2_REQUIRE(w && wpacked && src_cpg, E2FGVI_EINVAL, "pack_conv_weight_f32x3: null pointer");
+    E2_REQUIRE(geometry_x(Cout, groups, KH, KW, nsrc, src_cpg, &q, true), E2FGVI_EINVAL, "pack_conv_weight_f32x3: bad geometry");
+    hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (unsigned short*)wpacked, q);
+    E2_LAUNCH_CHECK("pack_conv_weight_f32x3");
     return 0;
 }
 
@@ -780,10 +906,32 @@ extern "C" int e2fgvi_pack_conv_weight_f32x_taps(const float* w, float* wpacked,
     return 0;
 }
 
-static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
+extern "C" int64_t e2fgvi_packed_conv_weight_f32x3_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin) {
+    PackX q;
+    if (!geometry_taps(Cout, KH, KW, cin, &q, true)) {
+        e2fgvi_set_error("packed_conv_weight_f32x3_taps_size: one source of 4 ... 56 channels (multiple of 4), KW >= 2");
+        return E2FGVI_EINVAL;
+    }
+    return 3 * q.total;
+}
+
+extern "C" int e2fgvi_pack_conv_weight_f32x3_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
+                                                  void* stream) {
+    PackX q;
+    E2_REQUIRE(w && wpacked, E2FGVI_EINVAL, "pack_conv_weight_f32x3_taps: null pointer");
+    E2_REQUIRE(geometry_taps(Cout, KH, KW, cin, &q, true), E2FGVI_EINVAL, "pack_conv_weight_f32x3_taps: bad geometry");
+    hipLaunchKernelGGL(pack_conv_weight_x3_kernel, dim3((unsigned)cdiv64(q.total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, (unsigned short*)wpacked, q);
+    E2_LAUNCH_CHECK("pack_conv_weight_f32x3_taps");
+    return 0;
+}
+
+static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
+    const bool f32 = mode != 0;           // fp32 activations (MODE 1: fp32 weights too; MODE 2: three bf16 planes per weight)
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv2d_bf16x: null descriptor");
     PackX q;
     const int esz = f32 ? 4 : 2;
+    const int wbytes_num = mode == 2 ? 6 : esz;       // packed bytes per weight
     E2_REQUIRE(geometry_x(d->Cout, d->groups, d->KH, d->KW, d->nsrc, d->src_cpg, &q, f32), E2FGVI_EINVAL,
                "conv2d_bf16x: bad geometry (channels per source must be multiples of 8 bf16 / 4 fp32)");
     E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->stride > 0 && d->pad >= 0, E2FGVI_EINVAL,
@@ -823,7 +971,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
         p.src[s] = d->src[s]; p.ld[s] = d->src_ld[s]; p.coff[s] = d->src_coff[s]; p.cpg[s] = d->src_cpg[s];
         p.src_bytes[s] = (unsigned)bytes;
     }
-    E2_REQUIRE(q.wgroup_elems * esz < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: packed weight group >= 4 GiB");
+    E2_REQUIRE(q.wgroup_elems * wbytes_num < 4294967295LL, E2FGVI_EUNSUP, "conv2d_bf16x: packed weight group >= 4 GiB");
     E2_REQUIRE(((uintptr_t)d->wpacked & 15) == 0, E2FGVI_EINVAL, "conv2d_bf16x: packed weight not 16-byte aligned");
     if (d->dst_nchw)
         E2_REQUIRE(d->dst_dtype == E2FGVI_F32 && !d->dst2, E2FGVI_EINVAL, "conv2d_bf16x: the NCHW destination is fp32, without a second copy");
@@ -856,7 +1004,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
         p.tp_magic_cq = qt.tp_cq > 1 ? 0xFFFFFFFFu / (unsigned)qt.tp_cq + 1u : 0u;
         p.nsteps = cdiv(d->KH * d->KW * qt.tp_cq, 8);
     }
-    p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * esz);
+    p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * wbytes_num);
     p.w = d->wpacked; p.bias = d->bias;
     p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff; p.res_bf16 = d->res_dtype == E2FGVI_BF16;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_bf16 = d->dst_dtype == E2FGVI_BF16;
@@ -878,27 +1026,29 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, bool f32) {
         else tile = ((long long)cdiv(p.M, 128) * cdiv(p.Cout_g, 128) * d->groups >= 384) ? 1 : 4;
     }
     switch (tile) {
-        case 1: return launch_x<128, 128, 2, 2, false>(p, d->groups, st, f32);
-        case 2: return launch_x<128, 64, 2, 2, false>(p, d->groups, st, f32);
-        case 3: return launch_x<128, 32, 4, 1, false>(p, d->groups, st, f32);
-        case 4: return launch_x<64, 128, 2, 2, false>(p, d->groups, st, f32);
-        case 5: return launch_x<64, 64, 2, 2, false>(p, d->groups, st, f32);
-        case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, f32);
-        case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, f32);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
+        case 1: return launch_x<128, 128, 2, 2, false>(p, d->groups, st, mode);
+        case 2: return launch_x<128, 64, 2, 2, false>(p, d->groups, st, mode);
+        case 3: return launch_x<128, 32, 4, 1, false>(p, d->groups, st, mode);
+        case 4: return launch_x<64, 128, 2, 2, false>(p, d->groups, st, mode);
+        case 5: return launch_x<64, 64, 2, 2, false>(p, d->groups, st, mode);
+        case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, mode);
+        case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
         // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
-        case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, f32);
-        case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, f32);
-        case 13: return launch_x<128, 32, 4, 1, true>(p, d->groups, st, f32);      // narrow layers (decoder tail): the A stream is
-        case 14: return launch_x<64, 128, 2, 2, true>(p, d->groups, st, f32);
-        case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, f32);
-        case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, f32);
-        case 18: return launch_x<256, 64, 4, 2, true>(p, d->groups, st, f32);       // all of their traffic, a third of it here
+        case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, mode);
+        case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, mode);
+        case 13: return launch_x<128, 32, 4, 1, true>(p, d->groups, st, mode);      // narrow layers (decoder tail): the A stream is
+        case 14: return launch_x<64, 128, 2, 2, true>(p, d->groups, st, mode);
+        case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, mode);
+        case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, mode);
+        case 18: return launch_x<256, 64, 4, 2, true>(p, d->groups, st, mode);       // all of their traffic, a third of it here
         default: break;
     }
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }
 
-extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, false); }
+extern "C" int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, 0); }
 /* the same kernel on fp32 operands (fp32 NHWC sources, e2fgvi_pack_conv_weight_f32x weights, exact fp32 MFMA) */
-extern "C" int e2fgvi_conv2d_f32x(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, true); }
+extern "C" int e2fgvi_conv2d_f32x(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, 1); }
+/* fp32 NHWC sources, e2fgvi_pack_conv_weight_f32x3 weights: fp32 products as six exact bf16 MFMA terms (kernel MODE 2) */
+extern "C" int e2fgvi_conv2d_f32x3(const e2fgvi_convx_desc* d, void* stream) { return conv2d_x(d, stream, 2); }

@@ -23,8 +23,22 @@
 // Packed weights: [group][chunk][a = 16][kq = 2][Npad][4]  (chunk = 8 input channels in concat order, sources padded
 // to 8 -- a source may be 4 (mod 8) wide, its last half chunk is zero; kq = channel quad; Npad = Cout_g rounded up to
 // 32), produced by e2fgvi_pack_winograd_weight.
+//
+// X3 = true (round 3; built as a second object, conv_wino_x3.o, without packed-fp32 VALU): the 16 GEMMs run on the bf16
+// matrix pipe with EXACTLY split operands, as conv_bf16x.hip's MODE 2 does for the implicit GEMM.  The transformed input V
+// (fp32, built in registers as before) is split into three bf16 numbers per value (8 + 8 + 8 significand bits, their sum is
+// V bit for bit), the transformed weights U are split the same way at packing time, and of the nine bf16 products of a
+// V * U pair the six largest are accumulated by v_mfma_f32_32x32x16_bf16 (the dropped ones are < 2^-22 of the product):
+// fp32-level rounding for 6 x 32 MFMA cycles per 16 input channels instead of 8 x 64.  A lane then covers 8 channels of its
+// tile (both channel quads of chunk h of the 16-channel LDS stage) instead of 4, one K iteration = one LDS stage;
+// staging, epilogue and tile shapes are shared with the fp32 kernel.
+//   X3 packed weights: [group][stage = 16 channels][a = 16][plane hi, mid, lo][h = chunk of the stage][Npad][8 bf16]
 #include "common.h"
 #include <stdlib.h>
+
+#ifndef E2_WINO_X3
+#define E2_WINO_X3 0           // 1: the split-bf16 build of this file (conv_wino_x3.o): only the X3 kernels and their entry points
+#endif
 
 #ifndef E2_WINO_VARIANT
 #define E2_WINO_VARIANT 0      // experiment switches (tools only): 1 = mid-stage prefetch of the upper waves, 2 = static s_setprio by SIMD partner, 4 = s_setprio around the MFMA block
@@ -42,6 +56,35 @@ __device__ unsigned long long e2_wino_dbg[64 * 8 * 8];
 #endif
 
 namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + mid + lo with bf16 pieces (conv_bf16x.hip::split8): hi / mid by clearing the low 16 bits of the value / of the
+// exact remainder, lo = what is left (<= 8 significant bits)
+__device__ __forceinline__ void wino_split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    unsigned x[8], rb[8], r2b[8];
+    const u32x4 b0 = __builtin_bit_cast(u32x4, v0), b1 = __builtin_bit_cast(u32x4, v1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = b0[j]; x[4 + j] = b1[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float r = __builtin_bit_cast(float, x[j]) - __builtin_bit_cast(float, x[j] & 0xFFFF0000u);
+        rb[j] = __builtin_bit_cast(unsigned, r);
+        const float r2 = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
+        r2b[j] = __builtin_bit_cast(unsigned, r2);
+    }
+    u32x4 H, M, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        H[j] = __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], 0x07060302u);
+        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
+        L[j] = __builtin_amdgcn_perm(r2b[2 * j + 1], r2b[2 * j], 0x07060302u);
+    }
+    hi = __builtin_bit_cast(bf16x8, H);
+    mid = __builtin_bit_cast(bf16x8, M);
+    lo = __builtin_bit_cast(bf16x8, L);
+}
 
 struct WinoParams {
     const float* src[E2FGVI_MAX_SRC];
@@ -134,9 +177,10 @@ typedef __attribute__((address_space(3))) void wino_lds_void;
 // under the epilogue's footprint): the pieces of stage st + 2 are issued during stage st, chunk by chunk, right in front of
 // the next chunk's weight loads, so every explicit weight wait is `vmcnt(2 TN + pieces of this wave)` and -- loads return in
 // order -- also retires the wave's pieces of the stage after next; the stage barrier then orders them for the other waves.
-template <int MT, int BN, int SC, bool DMA>
-__global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
+template <int MT, int BN, int SC, bool DMA, bool X3>
+__global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
     static_assert(SC == 2, "chunks per LDS stage (the explicit vmcnt counts of k_loop assume two)");
+    static_assert(!(X3 && DMA), "the split-bf16 variant stages the patch through registers");
     constexpr int NT = 512;
     constexpr int TN = BN / 32;
     constexpr int RAW_H = 8 * MT + 2;
@@ -317,13 +361,15 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         for (int j = 0; j < 3; ++j) {
             const int prow = 2 * ty + (r ? ra1 : ra0);
             const int col = cb + j;                                  // patch column 0..3 -> pixel column 2*tx + col
-            a_off[r][j] = (h * 2 + (col & 1)) * PLANE_BYTES + (prow * PLANE_ROW + tx + (col >> 1)) * 16;
+            // fp32: the lane's channel quad kq = h of every chunk.  X3: both quads (+ 2 PLANE_BYTES for kq = 1) of chunk h
+            a_off[r][j] = X3 ? h * CHUNK_BYTES + (col & 1) * PLANE_BYTES + (prow * PLANE_ROW + tx + (col >> 1)) * 16
+                             : (h * 2 + (col & 1)) * PLANE_BYTES + (prow * PLANE_ROW + tx + (col >> 1)) * 16;
         }
 
     // ---- B operands (pre-transformed weights) go global -> registers, no LDS: lane (i, h) of position a, column
     // tile n needs U[chunk][2*wave + a][kq = h][n0 + 32 n + i][0..3] = one 16-byte load
-    const i32x4 wrsrc = rsrc_words(p.w + (long long)g * p.wgroup_elems, p.wgroup_bytes);
-    const unsigned u_step = 32u * (unsigned)p.Npad * 16u;          // bytes per chunk
+    const i32x4 wrsrc = rsrc_words(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes, p.wgroup_bytes);
+    const unsigned u_step = (X3 ? 96u : 32u) * (unsigned)p.Npad * 16u;   // bytes per chunk (X3: per 16-channel stage, 3 planes)
     unsigned u_off[2][TN];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -331,14 +377,28 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         for (int n = 0; n < TN; ++n) {
             const int col = n0 + n * 32 + i;
             // columns past Npad: an offset that stays out of range for every chunk (group size is < 0x70000000 bytes)
-            u_off[a][n] = col < p.Npad ? (unsigned)((((2 * wave + a) * 2 + h) * p.Npad + col) * 16) : 0x80000000u;
+            // X3: plane pl adds 2 Npad 16-byte units ([a][plane][h][Npad])
+            u_off[a][n] = col < p.Npad ? (unsigned)(((X3 ? (2 * wave + a) * 6 + h : (2 * wave + a) * 2 + h) * p.Npad + col) * 16)
+                                       : 0x80000000u;
         }
+    const unsigned u_plane = 2u * (unsigned)p.Npad * 16u;
     f32x4 bq[2][2][TN];
     auto load_b = [&](int chunk, f32x4 (&q)[2][TN]) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < TN; ++n) buf_load4_pinned(q[a][n], wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
+    };
+    // X3: the weights of a 16-channel stage, 3 planes per (position, column tile)
+    f32x4 bw[2][2][X3 ? TN : 1][3];
+    auto load_b3 = [&](int st, f32x4 (&q)[2][X3 ? TN : 1][3]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < (X3 ? TN : 1); ++n)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    buf_load4_pinned(q[a][n][pl], wrsrc, u_off[a][n] + (unsigned)pl * u_plane + (unsigned)st * u_step);
     };
     // the chunk's weights were issued one chunk ago; LATER is the number of vector loads issued since then
     auto claim_b = [&](auto LATER_, f32x4 (&q)[2][TN]) {
@@ -363,7 +423,8 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
     if constexpr (!DMA) {
 #pragma unroll
         for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
-        load_b(0, bq[0]);
+        if constexpr (X3) load_b3(0, bw[0]);
+        else load_b(0, bq[0]);
         store_raw(0);
 #pragma unroll
         for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
@@ -382,6 +443,76 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32) ? 4 : 2)) void conv_win
         // buffer is free for the whole stage (its readers passed the previous barrier) and the stage barrier still follows
         // every wave's stores.
         constexpr bool LATE = XI >= 2 && (E2_WINO_VARIANT & 1);
+        if constexpr (X3) {
+            // one iteration per LDS stage (16 channels): the stage's weights (2 positions x TN column tiles x 3 planes) were
+            // issued a stage ago; since then: the patch prefetch of the stage after (SC * RAW_IT loads) and the next weights
+            // (stage 0's weights were issued by the prologue, between the two patch loads -- like the fp32 kernel's)
+            // (two stages per trip with compile-time buffer indices: `bw[st & 1]` would put the weight registers in scratch; an odd
+            //  stage count runs one stage past the end -- zero weights, like the fp32 kernel's chunk overrun)
+            auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
+                constexpr int CUR = decltype(CUR_)::value;
+                const unsigned char* stage = smem + CUR * STAGE_BYTES;
+                load_b3(st + 1, bw[CUR ^ 1]);
+                wait_vmcnt<6 * TN + SC * RAW_IT>();
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[CUR][a][n][pl]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const unsigned char* rm = stage + m * (8 * PLANE_ROW * 16);
+                    f32x4 va[2], vb[2];
+#pragma unroll
+                    for (int kq = 0; kq < 2; ++kq) {
+                        f32x4 e[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(rm + kq * (2 * PLANE_BYTES) + a_off[0][j]);
+                            const f32x4 d1 = *reinterpret_cast<const f32x4*>(rm + kq * (2 * PLANE_BYTES) + a_off[1][j]);
+                            e[j] = XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
+                        }
+                        va[kq] = PB ? e[1] - e[0] : e[0] - e[2];
+                        vb[kq] = PB ? e[0] - e[2] : e[1] + e[2];
+                    }
+                    bf16x8 ah, am, al, bh, bm, bl;
+                    wino_split8(va[0], va[1], ah, am, al);
+                    wino_split8(vb[0], vb[1], bh, bm, bl);
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        const bf16x8 u0h = __builtin_bit_cast(bf16x8, bw[CUR][0][n][0]), u0m = __builtin_bit_cast(bf16x8, bw[CUR][0][n][1]),
+                                     u0l = __builtin_bit_cast(bf16x8, bw[CUR][0][n][2]);
+                        const bf16x8 u1h = __builtin_bit_cast(bf16x8, bw[CUR][1][n][0]), u1m = __builtin_bit_cast(bf16x8, bw[CUR][1][n][1]),
+                                     u1l = __builtin_bit_cast(bf16x8, bw[CUR][1][n][2]);
+                        // smallest terms first, the two positions interleaved (independent accumulators)
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, u0h, acc[0][m][n], 0, 0, 0);
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, u1h, acc[1][m][n], 0, 0, 0);
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, u0l, acc[0][m][n], 0, 0, 0);
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, u1l, acc[1][m][n], 0, 0, 0);
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, u0m, acc[0][m][n], 0, 0, 0);
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, u1m, acc[1][m][n], 0, 0, 0);
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, u0h, acc[0][m][n], 0, 0, 0);
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, u1h, acc[1][m][n], 0, 0, 0);
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, u0m, acc[0][m][n], 0, 0, 0);
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, u1m, acc[1][m][n], 0, 0, 0);
+                        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, u0h, acc[0][m][n], 0, 0, 0);
+                        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, u1h, acc[1][m][n], 0, 0, 0);
+                    }
+                }
+                // the registers hold stage st + 1: park it in the other buffer (its readers passed the previous barrier)
+                store_raw(CUR ^ 1);
+#pragma unroll
+                for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
+                __syncthreads();
+            };
+            for (int st = 0; st < nstages; st += 2) {
+                stage_body(IC<0>{}, st);
+                stage_body(IC<1>{}, st + 1);
+            }
+            return;
+        }
         if constexpr (DMA) {
             constexpr int WV = 2 * XI + (PB ? 1 : 0);                  // this wave
             constexpr int NPW = (PIECES - WV + 7) / 8;                 // its pieces per chunk
@@ -646,8 +777,80 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
     wp[idx] = v;
 }
 
+// the transformed weight U[a] of (group g, output column n, input channel `ch` of source s) -- pack_wino_weight_kernel's formula
+__device__ __forceinline__ float wino_u(const float* __restrict__ w, const WinoPack& p, int g, int n, int prefix, int ch, int a) {
+    const float* f = w + ((long long)(g * p.Cout_g + n) * p.Cin_g + prefix + ch) * 9;
+    const int xi = a >> 2, nu = a & 3;
+    float col[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float f0 = f[0 * 3 + j], f1 = f[1 * 3 + j], f2 = f[2 * 3 + j];
+        col[j] = xi == 0 ? f0 : xi == 1 ? 0.5f * (f0 + f1 + f2) : xi == 2 ? 0.5f * (f0 - f1 + f2) : f2;
+    }
+    return nu == 0 ? col[0] : nu == 1 ? 0.5f * (col[0] + col[1] + col[2]) : nu == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2];
+}
+
+// X3 packing: [group][stage][a = 16][plane][h][Npad][8 bf16], stage = chunks 2 stage + h, element j = channel j of the chunk;
+// one thread per fp32 value, which it splits into its three bf16 pieces (their sum is the value, bit for bit)
+__global__ void pack_wino_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const WinoPack p, int nstages) {
+    const long long per_group = (long long)nstages * 16 * 2 * p.Npad * 8;          // values (not planes) per group
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_group * p.groups) return;
+    const int g = (int)(idx / per_group);
+    long long rem = idx - (long long)g * per_group;
+    const int j = (int)(rem & 7);
+    rem >>= 3;
+    const int n = (int)(rem % p.Npad);
+    rem /= p.Npad;
+    const int h = (int)(rem & 1);
+    rem >>= 1;
+    const int a = (int)(rem & 15);
+    const int stage = (int)(rem >> 4);
+    const int chunk = 2 * stage + h;
+    float v = 0.f;
+    if (chunk < p.nchunks && n < p.Cout_g) {
+        int s = 0, prefix = 0, lc = chunk;
+        while (lc >= (p.cpg[s] + 7) / 8) { lc -= (p.cpg[s] + 7) / 8; prefix += p.cpg[s]; ++s; }
+        const int ch = lc * 8 + j;
+        if (ch < p.cpg[s]) v = wino_u(w, p, g, n, prefix, ch, a);
+    }
+    const unsigned xb = __builtin_bit_cast(unsigned, v);
+    const float r = v - __builtin_bit_cast(float, xb & 0xFFFF0000u);
+    const unsigned rb = __builtin_bit_cast(unsigned, r);
+    const float r2 = r - __builtin_bit_cast(float, rb & 0xFFFF0000u);
+    const long long plane = 2LL * p.Npad * 8;
+    unsigned short* o = wp + (long long)g * per_group * 3 + ((long long)(stage * 16 + a) * 3) * plane + ((long long)h * p.Npad + n) * 8 + j;
+    o[0] = (unsigned short)(xb >> 16);
+    o[plane] = (unsigned short)(rb >> 16);
+    o[2 * plane] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+}
+
 }  // namespace
 
+#if E2_WINO_X3
+/* split-bf16 Winograd (ABI version 7): weights as three bf16 planes of the transformed fp32 weights; returns bf16 ELEMENTS */
+extern "C" int64_t e2fgvi_packed_winograd_weight_x3_size(int32_t Cout, int32_t groups, int32_t nsrc, const int32_t* src_cpg) {
+    WinoPack q;
+    if (!src_cpg || !wino_geometry(Cout, groups, nsrc, src_cpg, &q)) {
+        e2fgvi_set_error("packed_winograd_weight_x3_size: bad geometry (channels per source must be multiples of 4)");
+        return E2FGVI_EINVAL;
+    }
+    return (long long)((q.nchunks + 1) / 2) * 16 * 3 * 2 * q.Npad * 8 * groups;
+}
+
+extern "C" int e2fgvi_pack_winograd_weight_x3(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t nsrc,
+                                              const int32_t* src_cpg, void* stream) {
+    WinoPack q;
+    E2_REQUIRE(w && wpacked && src_cpg, E2FGVI_EINVAL, "pack_winograd_weight_x3: null pointer");
+    E2_REQUIRE(wino_geometry(Cout, groups, nsrc, src_cpg, &q), E2FGVI_EINVAL, "pack_winograd_weight_x3: bad geometry");
+    const int nstages = (q.nchunks + 1) / 2;
+    const long long values = (long long)nstages * 16 * 2 * q.Npad * 8 * groups;
+    hipLaunchKernelGGL(pack_wino_weight_x3_kernel, dim3((unsigned)cdiv64(values, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short*)wpacked, q, nstages);
+    E2_LAUNCH_CHECK("pack_winograd_weight_x3");
+    return 0;
+}
+#else
 extern "C" int64_t e2fgvi_packed_winograd_weight_size(int32_t Cout, int32_t groups, int32_t nsrc, const int32_t* src_cpg) {
     WinoPack q;
     if (!src_cpg || !wino_geometry(Cout, groups, nsrc, src_cpg, &q)) {
@@ -667,8 +870,9 @@ extern "C" int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32
     E2_LAUNCH_CHECK("pack_winograd_weight");
     return 0;
 }
+#endif
 
-template <int MT, int BN, int SC, bool DMA>
+template <int MT, int BN, int SC, bool DMA, bool X3 = false>
 static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     p.blocksY = cdiv(p.H, 8 * MT);
     p.blocksX = cdiv(p.W, 16);
@@ -676,12 +880,12 @@ static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC, DMA>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC, DMA, X3>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd");
     return 0;
 }
 
-extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) {
+static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv3x3_winograd: null descriptor");
     WinoPack q;
     E2_REQUIRE(wino_geometry(d->Cout, d->groups, d->nsrc, d->src_cpg, &q), E2FGVI_EINVAL,
@@ -717,6 +921,7 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
     p.Cout = d->Cout; p.Cout_g = q.Cout_g; p.Npad = q.Npad;
     p.nchunks = q.nchunks;
     p.wgroup_elems = q.wgroup_elems; p.wgroup_bytes = (unsigned)(q.wgroup_elems * 4);
+    if (x3) p.wgroup_bytes = (unsigned)((long long)((q.nchunks + 1) / 2) * 16 * 3 * 2 * q.Npad * 16);   // [stage][a][plane][h][Npad] x 16 bytes
     p.w = (const float*)d->wpacked; p.bias = d->bias;
     p.res = d->residual; p.res_ld = d->res_ld; p.res_coff = d->res_coff;
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff;
@@ -735,6 +940,19 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
         const long long big = (long long)d->N * cdiv(d->H, 16) * cdiv(d->W, 16) * cdiv(q.Cout_g, 64) * d->groups;
         tile = (q.Cout_g >= 256 && big >= 128) ? 64 : 132;
     }
+#if E2_WINO_X3
+    (void)x3;
+    if (tile == 64) tile = 164;
+    switch (tile) {
+        // (no 16x16-pixel x 64-cout shape: 128 accumulator + 96 weight registers per lane do not fit beside the split)
+        case 32: return launch_wino<2, 32, 2, false, true>(p, d->groups, st);
+        case 164: return launch_wino<1, 64, 2, false, true>(p, d->groups, st);
+        case 132: return launch_wino<1, 32, 2, false, true>(p, d->groups, st);
+        default: break;
+    }
+    e2fgvi_set_error("conv3x3_winograd_x3: tile must be 0 (auto), 32 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");
+    return E2FGVI_EINVAL;
+#else
     // + 1000: the same block shape with the raw patch staged by LDS-DMA (round 3); E2FGVI_WINO_DMA=1 makes it the default
     static int dma_env = -1;
     if (dma_env < 0) { const char* e = getenv("E2FGVI_WINO_DMA"); dma_env = e ? atoi(e) : 0; }
@@ -753,7 +971,15 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
     }
     e2fgvi_set_error("conv3x3_winograd: tile must be 0 (auto), 32, 64 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");
     return E2FGVI_EINVAL;
+#endif
 }
+
+#if E2_WINO_X3
+/* e2fgvi_conv3x3_winograd on the bf16 matrix pipe: same descriptor, wpacked from e2fgvi_pack_winograd_weight_x3 */
+extern "C" int e2fgvi_conv3x3_winograd_x3(const e2fgvi_conv_desc* d, void* stream) { return wino_run(d, stream, true); }
+#else
+extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) { return wino_run(d, stream, false); }
+#endif
 
 #ifdef E2_WINO_TIMING
 extern "C" int e2fgvi_wino_timing_read(unsigned long long* host_dst, int32_t n) {

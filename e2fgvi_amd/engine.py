@@ -227,6 +227,20 @@ class Engine(BF16Path):
             # (Winograd block shapes are NOT tuned at run time: measured in round 2, the timing-based choice between the
             # 16x16 / 8x16-pixel blocks moved the forward by -1 ... -2 % and added run-to-run variance; the static rule of
             # e2fgvi_conv3x3_winograd stays.)
+        if precision == "fp32" and ops.X3_ENABLED:
+            # Every fp32 conv / linear of the MAIN stream may run on the bf16 matrix pipe instead (ops.PackedConvX x3: operands
+            # split exactly into three bf16 pieces, six bf16 MFMA terms per product, fp32-level rounding): timed against the
+            # layer's fp32 kernel on the first eager call of each size class, kept where it is faster (the GEMM-shaped layers:
+            # token Linears, soft split / composite, the stride-2 and 1x1 convs; the Winograd layers mostly keep Winograd).
+            # SPyNet stays on its packed-math-free fp32 kernels: it shares the chip with these LDS-fed bf16 MFMA waves.
+            for layer in self.enc + self.dec[:3] + [self.fusion, self.ss, self.sc] + ([self.sc_bias_conv] if self.hq else []):
+                layer.try_x3 = True
+            for off, _dcn, bb in self.prop.values():
+                for layer in off + bb:
+                    layer.try_x3 = True
+            for blk in self.blocks:
+                for k in ("qkv", "proj", "fc1", "fc2"):
+                    blk[k].try_x3 = True
         # SPyNet runs on a side stream next to the encoder, in both precision modes.  Round 1 found the side stream's
         # kernels corrupted beside bf16 MFMA tiles; round 2 traced it to packed-fp32 VALU instructions consuming freshly
         # loaded registers (tools/probe/overlap_probe.hip, DESIGN.md "Stream overlap"): every kernel that can run on the

@@ -82,9 +82,17 @@ SYMBOLS = {
     "e2fgvi_conv2d_f32x": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
     "e2fgvi_packed_conv_weight_f32x_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_conv_weight_f32x": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
+    "e2fgvi_conv2d_f32x3": (C.c_int, [C.POINTER(ConvXDesc), _fp]),
+    "e2fgvi_packed_conv_weight_f32x3_size": (_i64, [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    "e2fgvi_pack_conv_weight_f32x3": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
+    "e2fgvi_packed_conv_weight_f32x3_taps_size": (_i64, [_i32, _i32, _i32, _i32]),
+    "e2fgvi_pack_conv_weight_f32x3_taps": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_packed_winograd_weight_size": (_i64, [_i32, _i32, _i32, C.POINTER(_i32)]),
     "e2fgvi_pack_winograd_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
     "e2fgvi_conv3x3_winograd": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "e2fgvi_packed_winograd_weight_x3_size": (_i64, [_i32, _i32, _i32, C.POINTER(_i32)]),
+    "e2fgvi_pack_winograd_weight_x3": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.POINTER(_i32), _fp]),
+    "e2fgvi_conv3x3_winograd_x3": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "e2fgvi_packed_winograd4_weight_size": (_i64, [_i32, _i32, _i32, C.POINTER(_i32), _i32]),
     "e2fgvi_pack_winograd4_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.POINTER(_i32), _i32, _fp]),
     "e2fgvi_conv3x3_winograd4": (C.c_int, [C.POINTER(ConvDesc), _i32, _fp]),

@@ -55,6 +55,16 @@ _W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
 # are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
 XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
 XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
+# fp32 layers on the bf16 matrix pipe by exact operand splitting (conv_bf16x.hip MODE 2, PackedConvX(x3=True)): a tuning
+# alternative of every fp32 layer that asks for it (PackedConv.try_x3 / PackedConvX.try_x3); taken when its best tile beats
+# the fp32 kernel of the call by more than X3_MARGIN.  Tile codes X3_BASE + tile in the decision table (clear of the Winograd
+# codes 2432 / 2464 / 4432 and of the 2000 + tile codes of the LDS-DMA fp32 kernel).  E2FGVI_X3=0: never.
+X3_ENABLED = os.environ.get("E2FGVI_X3", "1") != "0"
+X3_MARGIN = 0.97
+X3_BASE = 30000
+# ... and the Winograd F(2x2,3x3) kernel with split operands (conv_wino.hip, X3 build): codes W3_BASE + its block shape
+W3_BASE = 40000
+W3_CANDIDATES = (132, 164, 32)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # The decisions are persisted: read from / appended to a per-library-build file next to the library (e2fgvi_amd/.tile_cache/,
 # or $E2FGVI_CACHE_DIR), so that
@@ -142,6 +152,9 @@ class PackedConv:
         self.tune = False          # time TUNE_CANDIDATES on the first call of every new input size and keep the fastest
         self.name = "conv"         # layer name for launch traces (the engine sets the checkpoint key)
         self.nopk = False          # True: the build without packed-fp32 VALU (side-stream launches beside bf16 MFMA tiles)
+        self.try_x3 = False        # True: time the split-bf16 kernel (PackedConvX x3) against this layer's fp32 kernel, keep the faster
+        self.alt = self.alt3 = None
+        self._w_raw = w            # for the alternative LDS-DMA kernels (built on the first tuned call)
         if algo not in ("igemm", "winograd", "auto"):
             raise ValueError("algo must be 'igemm', 'winograd' or 'auto'")
         wino_ok = precision == "fp32" and (self.KH, self.KW, stride, pad) == (3, 3, 1, 1) and not any(c % 4 for c in self.cpg)
@@ -180,8 +193,6 @@ class PackedConv:
         _L.check(lib.e2fgvi_pack_conv_weight(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
                                              len(self.cpg), arr, bk, _stream()), "pack_conv_weight")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
-        self._w_raw = w            # for the alternative LDS-DMA kernel (built on the first tuned call)
-        self.alt = None
 
     def _wino4(self, fy):
         """packed weights of the wide-tile Winograd kernel (conv_wino4.hip), built on first use"""
@@ -220,8 +231,28 @@ class PackedConv:
             self.alt = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
                                    dtype=torch.float32)
             self.alt.name = self.name
-            self._w_raw = None
         return self.alt
+
+    def _wino_x3(self):
+        """packed weights of the split-bf16 Winograd kernel (three bf16 planes of the transformed weights), built on first use"""
+        if getattr(self, "_w3", None) is None and self._w_oihw is not None:
+            lib = _L.load()
+            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+            n = lib.e2fgvi_packed_winograd_weight_x3_size(self.Cout, self.groups, len(self.cpg), arr)
+            if n < 0:
+                _L.check(int(n), "packed_winograd_weight_x3_size")
+            self._w3 = torch.empty(int(n), dtype=torch.bfloat16, device=self._w_oihw.device)
+            _L.check(lib.e2fgvi_pack_winograd_weight_x3(_ptr(self._w_oihw), _ptr(self._w3), self.Cout, self.groups, len(self.cpg), arr,
+                                                        _stream()), "pack_winograd_weight_x3")
+        return getattr(self, "_w3", None)
+
+    def _alt3(self):
+        """the same layer on the bf16 matrix pipe (three-way split operands, six exact bf16 MFMA terms per product)"""
+        if self.alt3 is None and getattr(self, "_w_raw", None) is not None and not any(c % 4 for c in self.cpg):
+            self.alt3 = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
+                                    dtype=torch.float32, x3=True)
+            self.alt3.name = self.name
+        return self.alt3
 
     def _autotune(self, lib, d, wino=False):
         """Device time of every candidate tile code on this exact call (2 launches each, hip events); the launches
@@ -265,6 +296,14 @@ class PackedConv:
             # (fy+2)*6 positions per fy x 4 pixels
             issued = pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * (fy + 2) * 6 // (fy * 4)
             kern = "conv_wino4<F(%dx4),%d>" % (fy, bn)
+        elif use_wino and tile >= W3_BASE:
+            shape = tile - W3_BASE
+            mt, bn = (2, shape) if shape < 100 else (1, shape - 100)
+            pix = N * (-(-H // (8 * mt)) * 8 * mt) * (-(-W // 16) * 16)
+            cin_p = -(-sum(-(-c // 8) for c in self.cpg) // 2) * 16           # 16-channel stages
+            # 16 positions per 4 pixels, six bf16 MACs per product, in fp32-pipe equivalents (see PackedConvX's trace record)
+            issued = int(pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * 4 * 6 * 157.3 / 2500.0)
+            kern = "conv_wino_x3<%d,%d>" % (mt, bn)
         elif use_wino:
             if not tile:
                 big = N * -(-H // 16) * -(-W // 16) * -(-cout_g // 64) * self.groups
@@ -320,7 +359,12 @@ class PackedConv:
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
         use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and not out_nchw
-                                               and (tile in (0, 32, 64, 132, 164) or tile in W4_CODES or tile > 1000))
+                                               and (tile in (0, 32, 64, 132, 164) or tile in W4_CODES or 1000 < tile < 2000
+                                                    or tile >= W3_BASE))
+        w3_tile = None                         # block shape of the split-bf16 Winograd kernel, when that is what runs
+        if use_wino and tile >= W3_BASE:
+            w3_tile, tile = tile - W3_BASE, 0
+        auto_tile = tile == 0 and w3_tile is None      # the caller leaves the kernel choice to the layer
         if use_wino and tile == 0:
             tile = self._wino4_rule(N, H, W)
         w4 = W4_CODES.get(tile) if use_wino else None
@@ -346,44 +390,95 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
-        if tile == 0 and self.tune and self.precision == "fp32" and N * Ho * Wo >= 2048:
+        w4c = W4_CODES.get(tile) if use_wino else None
+
+        def launch_w3(shape):
+            t0, w0 = d.tile, d.wpacked
+            d.tile, d.wpacked = shape, self._wino_x3().data_ptr()
+            rc = lib.e2fgvi_conv3x3_winograd_x3(C.byref(d), _stream())
+            d.tile, d.wpacked = t0, w0
+            return rc, "conv3x3_winograd_x3"
+
+        def launch():
+            if w3_tile is not None:
+                return launch_w3(w3_tile)
+            if w4c:
+                t0 = d.tile
+                d.tile = w4c[1]
+                rc = lib.e2fgvi_conv3x3_winograd4(C.byref(d), w4c[0], _stream())
+                d.tile = t0
+                return rc, "conv3x3_winograd4"
+            if use_wino:
+                return lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd"
+            if self.nopk:
+                return lib.e2fgvi_conv2d_nhwc_nopk(C.byref(d), _stream()), "conv2d_nhwc_nopk"
+            return lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc"
+
+        x3 = self.try_x3 and X3_ENABLED and not self.nopk
+        if auto_tile and (tile == 0 or not self.tune) and (self.tune or x3) and self.precision == "fp32" and N * Ho * Wo >= 2048:
             # one decision per (layer geometry, size class): row counts within a quarter octave share the tile, so the
             # slightly different window lengths of a video (t = 17 ... 21 frames) do not each pay for a tuning pass
             key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk,
-                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino)
+                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino) + (("x3",) if x3 else ())
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
-                best = self._autotune(lib, d, use_wino)
-                if not use_wino and not self.nopk and self._alt() is not None:
-                    # the LDS-DMA fp32 kernel on the very same call: codes 2000 + its tile
+                best = self._autotune(lib, d, use_wino) if self.tune else d.tile
+                mine = None
+
+                def time_mine():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    d.tile = best
+                    launch()
                     e0.record()
                     for _ in range(3):
-                        lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream())
+                        launch()
                     e1.record()
                     e1.synchronize()
-                    mine = e0.elapsed_time(e1) / 3
+                    return e0.elapsed_time(e1) / 3
+                if self.tune and not use_wino and not self.nopk and self._alt() is not None:
+                    # the LDS-DMA fp32 kernel on the very same call: codes 2000 + its tile
+                    d.tile = best
+                    mine = time_mine()
                     res = self.alt._time_tiles(self.alt._desc(srcs, out, out_coff, residual, res_coff, act, slope, None, out_nchw))
                     if res and min(res.values()) < mine:
-                        best = 2000 + min(res, key=res.get)
+                        best, mine = 2000 + min(res, key=res.get), min(res.values())
+                if x3 and self._alt3() is not None:
+                    # ... and the split-bf16 kernel: codes X3_BASE + its tile
+                    if mine is None:
+                        d.tile = best
+                        mine = time_mine()
+                    res = self.alt3._time_tiles(self.alt3._desc(srcs, out, out_coff, residual, res_coff, act, slope, None, out_nchw))
+                    if res and min(res.values()) < X3_MARGIN * mine:
+                        best, mine = X3_BASE + min(res, key=res.get), min(res.values())
+                if x3 and use_wino and self._wino_x3() is not None:
+                    # ... and the Winograd kernel with split operands: codes W3_BASE + its block shape
+                    for shape in W3_CANDIDATES:
+                        if launch_w3(shape)[0] != 0:
+                            continue
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            launch_w3(shape)
+                        e1.record()
+                        e1.synchronize()
+                        ms = e0.elapsed_time(e1) / 3
+                        if ms < X3_MARGIN * mine:
+                            best, mine = W3_BASE + shape, ms
                 best = _remember(key, best)
-            if best and best >= 2000:
+            if best and best >= W3_BASE:
+                w3_tile = best - W3_BASE
+            elif best and best >= X3_BASE:
+                return self._alt3()(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
+                                    tile=best - X3_BASE, out_nchw=out_nchw)
+            if best and self.tune and 2000 <= best < 2100:
                 return self._alt()(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
                                    tile=best - 2000, out_nchw=out_nchw)
-            d.tile = best or 0
+            if self.tune and w3_tile is None:
+                d.tile = best or 0
         if _L.TRACE is not None:
-            _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile))
-        if w4:
-            d.tile = w4[1]
-            _L.check(lib.e2fgvi_conv3x3_winograd4(C.byref(d), w4[0], _stream()), "conv3x3_winograd4")
-        elif use_wino:
-            _L.check(lib.e2fgvi_conv3x3_winograd(C.byref(d), _stream()), "conv3x3_winograd")
-        elif self.nopk:
-            _L.check(lib.e2fgvi_conv2d_nhwc_nopk(C.byref(d), _stream()), "conv2d_nhwc_nopk")
-        else:
-            _L.check(lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+            _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile if w3_tile is None else W3_BASE + w3_tile))
+        rc, what = launch()
+        _L.check(rc, what)
         return out
 
 
@@ -414,9 +509,11 @@ class PackedConvX:
     Either way: fp32 epilogue (bias, fp32 / bf16 residual, activation or the DCN offset post-processing), bf16 or fp32
     result (NHWC, or fp32 NCHW), optional second bf16 copy (`out2`)."""
 
-    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, dtype=torch.bfloat16, taps=None):
+    def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, dtype=torch.bfloat16, taps=None, x3=False):
         """taps: None = tap-packed K-steps whenever the layer qualifies (one bf16 source of <= 32 channels, no groups, more
-        than one tap), False = never (A/B measurements)"""
+        than one tap), False = never (A/B measurements).
+        x3 (fp32 sources only): fp32 on the bf16 matrix pipe -- weights stored as three bf16 planes whose sum is the fp32
+        weight, activations split the same way in registers, six exact bf16 MFMA terms per product (kernel MODE 2)"""
         lib = _L.load()
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
@@ -428,36 +525,56 @@ class PackedConvX:
         self.groups, self.stride, self.pad = groups, stride, pad
         self.dtype = dtype
         self.f32 = dtype == torch.float32
-        self._fn = lib.e2fgvi_conv2d_f32x if self.f32 else lib.e2fgvi_conv2d_bf16x
+        self.x3 = bool(x3)
+        if self.x3 and not self.f32:
+            raise ValueError("x3 splitting is for fp32 sources")
+        self._fn = (lib.e2fgvi_conv2d_f32x3 if self.x3 else lib.e2fgvi_conv2d_f32x) if self.f32 else lib.e2fgvi_conv2d_bf16x
+        wdtype = torch.bfloat16 if self.x3 else dtype
         self.name = "conv"
         self.tune = False          # time XTUNE_CANDIDATES on the first call of every new size class and keep the fastest
+        self.try_x3 = False        # (fp32 operands, with tune) also time the split-bf16 variant of this layer: codes X3_BASE + tile
+        self.alt3 = None
+        self._w_raw = w if (self.f32 and not self.x3) else None
+        self._taps_arg = taps
         arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         # narrow single-source layers (SPyNet's 7x7 stacks, the encoder's first layer): K-steps that carry several taps
         # (fp32 operands: only on request -- the one fp32 user is the FFN's second Linear as a conv, engine.py)
         self.taps = (len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 56 and self.KW > 1
                      and (taps is True if self.f32 else taps is not False) and os.environ.get("E2FGVI_TAPS", "1") != "0")
         if self.taps:
-            size_fn = lib.e2fgvi_packed_conv_weight_f32x_taps_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_taps_size
-            pack_fn = lib.e2fgvi_pack_conv_weight_f32x_taps if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x_taps
+            size_fn = ((lib.e2fgvi_packed_conv_weight_f32x3_taps_size if self.x3 else lib.e2fgvi_packed_conv_weight_f32x_taps_size)
+                       if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_taps_size)
+            pack_fn = ((lib.e2fgvi_pack_conv_weight_f32x3_taps if self.x3 else lib.e2fgvi_pack_conv_weight_f32x_taps)
+                       if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x_taps)
             n = size_fn(self.Cout, self.KH, self.KW, self.cpg[0])
             if n < 0:
                 _L.check(int(n), "packed_conv_weight_x_taps_size")
-            self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
+            self.wpacked = torch.empty(int(n), dtype=wdtype, device=w.device)
             _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, self.KH, self.KW, self.cpg[0], _stream()),
                      "pack_conv_weight_x_taps")
         else:
-            size_fn = lib.e2fgvi_packed_conv_weight_f32x_size if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size
-            pack_fn = lib.e2fgvi_pack_conv_weight_f32x if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x
+            size_fn = ((lib.e2fgvi_packed_conv_weight_f32x3_size if self.x3 else lib.e2fgvi_packed_conv_weight_f32x_size)
+                       if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size)
+            pack_fn = ((lib.e2fgvi_pack_conv_weight_f32x3 if self.x3 else lib.e2fgvi_pack_conv_weight_f32x)
+                       if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x)
             n = size_fn(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
             if n < 0:
                 _L.check(int(n), "packed_conv_weight_x_size")
-            self.wpacked = torch.empty(int(n), dtype=dtype, device=w.device)
+            self.wpacked = torch.empty(int(n), dtype=wdtype, device=w.device)
             _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, _stream()),
                      "pack_conv_weight_x")
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
 
     def out_hw(self, H, W):
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+    def _alt3(self):
+        """this fp32 layer on the bf16 matrix pipe (x3=True), built on first use"""
+        if self.alt3 is None and self._w_raw is not None:
+            self.alt3 = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
+                                    dtype=torch.float32, taps=self._taps_arg, x3=True)
+            self.alt3.name = self.name
+        return self.alt3
 
     def _desc(self, srcs, out, out_coff, residual, res_coff, act, slope, out2, out_nchw):
         """the C descriptor of one call (srcs: list of (tensor, channel offset))"""
@@ -522,14 +639,23 @@ class PackedConvX:
             return out
         d = self._desc(srcs, out, out_coff, residual, res_coff, act, slope, out2, out_nchw)
         d.tile = tile
+        x3 = self.try_x3 and X3_ENABLED and self.f32 and not self.x3
         if tile == 0 and self.tune and N * Ho * Wo >= 2048:
-            key = ("x32" if self.f32 else "x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
+            key = (("x3" if self.x3 else ("x32+3" if x3 else "x32")) if self.f32 else "x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
                    int(4.0 * math.log2(N * Ho * Wo)), _dt(out), out_nchw, self.taps)
             best = _TUNED.get(key)
             if best is None and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
                 res = self._time_tiles(d)
-                best = _remember(key, min(res, key=res.get) if res else 0)
+                best = min(res, key=res.get) if res else 0
+                if x3 and self._alt3() is not None:
+                    res3 = self.alt3._time_tiles(self.alt3._desc(srcs, out, out_coff, residual, res_coff, act, slope, out2, out_nchw))
+                    if res3 and (not res or min(res3.values()) < X3_MARGIN * min(res.values())):
+                        best = X3_BASE + min(res3, key=res3.get)
+                best = _remember(key, best)
+            if best and best >= X3_BASE:
+                return self._alt3()(srcs, out=out, out_dtype=out_dtype, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act,
+                                    slope=slope, out2=out2, tile=best - X3_BASE, out_nchw=out_nchw)
             d.tile = tile = best or 0
         if _L.TRACE is not None:
             cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
@@ -537,10 +663,13 @@ class PackedConvX:
             cin_p = sum(-(-c // kc) * kc for c in self.cpg)
             if self.taps:                                   # K-steps of several taps: issued K = steps * 64
                 cin_p = -(-K2 * (self.cpg[0] // (4 if self.f32 else 8)) // 8) * kc / K2
-            _L.annotate(layer=self.name, kernel="conv_%s tile=%d%s" % ("f32x" if self.f32 else "bf16x", tile, " taps" if self.taps else ""),
+            _L.annotate(layer=self.name, kernel="conv_%s tile=%d%s" % (("f32x3" if self.x3 else "f32x") if self.f32 else "bf16x", tile,
+                                                                      " taps" if self.taps else ""),
                         shape="N%d %dx%d %d->%d k%d s%d g%d" % (N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups),
                         macs=N * Ho * Wo * self.Cout * cin_g * K2,
-                        issued=int(N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2))
+                        # x3: six bf16 MACs per product, counted in fp32-pipe equivalents (a bf16 MAC occupies the matrix
+                        # pipe for 157.3 / 2500 of the time of an fp32 MAC): `issued / fp32 peak` stays matrix-pipe time
+                        issued=int(N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2 * (6 * 157.3 / 2500.0 if self.x3 else 1)))
         _L.check(self._fn(C.byref(d), _stream()), "conv2d_x")
         return out
 

@@ -367,6 +367,30 @@ int64_t e2fgvi_packed_conv_weight_f32x_size(int32_t Cout, int32_t groups, int32_
 int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
                                  int32_t nsrc, const int32_t* src_cpg, void* stream);
 
+/* ABI version 7.  fp32 layers on the bf16 matrix pipe by exact operand splitting ("x3"): fp32 NHWC sources as for
+ * e2fgvi_conv2d_f32x; every weight is stored as three bf16 numbers whose sum is the fp32 weight bit for bit (hi / mid / lo,
+ * 8 significand bits each), every activation is split the same way in registers, and of the nine bf16 products of a*b the six
+ * largest are accumulated by v_mfma_f32_32x32x16_bf16 in fp32 (the three dropped ones are < 2^-22 |a*b| together): fp32-level
+ * rounding at 2.7x the fp32 MFMA rate.  Same descriptor, tile codes 1..7; wpacked holds 3 x the fp32 element count, in bf16
+ * ([group][K-step][plane][4 k-octets][Npad][8]).  Replaces the same reference calls as e2fgvi_conv2d_nhwc (nn.Conv2d /
+ * nn.Linear of model/e2fgvi_hq.py, model/modules/tfocal_transformer_hq.py). */
+int e2fgvi_conv2d_f32x3(const e2fgvi_convx_desc* d, void* stream);
+int64_t e2fgvi_packed_conv_weight_f32x3_size(int32_t Cout, int32_t groups, int32_t KH, int32_t KW, int32_t nsrc,
+                                             const int32_t* src_cpg);
+int e2fgvi_pack_conv_weight_f32x3(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t KH, int32_t KW,
+                                  int32_t nsrc, const int32_t* src_cpg, void* stream);
+/* ... and the Winograd F(2x2,3x3) kernel the same way (csrc/conv_wino.hip, X3 build): the transformed input and the
+ * transformed weights are split exactly into three bf16 pieces each, six bf16 MFMA terms per product.  Same descriptor and
+ * epilogues as e2fgvi_conv3x3_winograd; tile 0 (auto), 32, 132, 164; wpacked holds
+ * e2fgvi_packed_winograd_weight_x3_size() bf16 elements ([group][16-channel stage][16 positions][plane][h][Npad][8]). */
+int e2fgvi_conv3x3_winograd_x3(const e2fgvi_conv_desc* d, void* stream);
+int64_t e2fgvi_packed_winograd_weight_x3_size(int32_t Cout, int32_t groups, int32_t nsrc, const int32_t* src_cpg);
+int e2fgvi_pack_winograd_weight_x3(const float* w, void* wpacked, int32_t Cout, int32_t groups, int32_t nsrc,
+                                   const int32_t* src_cpg, void* stream);
+int64_t e2fgvi_packed_conv_weight_f32x3_taps_size(int32_t Cout, int32_t KH, int32_t KW, int32_t cin);
+int e2fgvi_pack_conv_weight_f32x3_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
+                                       void* stream);
+
 /* Fused temporal focal window attention on bf16 MFMA: qkv / kv_pool / out are bf16 with the layouts of
  * e2fgvi_focal_attention; scores, softmax statistics and accumulation are fp32.  qkv and kv_pool must lie within one
  * 4 GiB window (the engine allocates them back to back). */

@@ -1,0 +1,259 @@
+"""fp32 layers on the bf16 matrix pipe ("x3", csrc/conv_bf16x.hip MODE 2): fp32 operands split exactly into three bf16
+pieces, six bf16 MFMA terms per product, fp32 accumulation.  The claim under test is that this is an fp32 kernel: against
+fp64 references it must meet the SAME bounds as the exact-fp32 MFMA kernels (tests/util.fp32_tol: 8 sqrt(K) 2^-24 of the
+output rms) on the same cases, its weight planes must sum to the fp32 weights bit for bit, and reruns must be bit-identical.
+Replaces the reference's nn.Conv2d / nn.Linear calls of model/e2fgvi_hq.py and model/modules/tfocal_transformer_hq.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_bf16x import CASES, F32_TAP_CASES, conv64
+from tests.util import assert_close, fp32_tol, gen as _gen, name_seed, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_x3(dev, case):
+    """every geometry of the LDS-DMA kernel's own case list (groups, virtual concat, strides, channel tails, narrow N, 1-pixel
+    images), every tile shape: fp32 tolerance against fp64"""
+    from e2fgvi_amd import ops
+    name, N, H, W, cpg, groups, Cout, k, stride, pad, tiles = case
+    g = _gen(name_seed(name, 23))
+    w = torch.randn(Cout, sum(cpg), k, k, generator=g) / math.sqrt(sum(cpg) * k * k)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    srcs, parts = [], []
+    for c in cpg:
+        t = torch.randn(N, H, W, c * groups + 8, generator=g)
+        srcs.append(t)
+        parts.append(t[..., 4:4 + c * groups])
+    x = torch.cat([torch.cat([p_[..., gi * c:(gi + 1) * c] for p_, c in zip(parts, cpg)], -1) for gi in range(groups)], -1)
+    ref0 = conv64(nchw(x), w, bias, stride=stride, padding=pad, groups=groups)
+    layer = ops.PackedConvX(w.to(dev), bias.to(dev), cpg, groups=groups, stride=stride, pad=pad, dtype=torch.float32, x3=True)
+    src_d = [(s.to(dev), 4) for s in srcs]
+    res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
+    ref = F.leaky_relu(ref0 + nchw(res), 0.1)
+    for tile in sorted(set(t for t in tiles if t < 10) | {1, 5, 7}):
+        out = layer(src_d, residual=res.to(dev), act=ops.ACT_LRELU, slope=0.1, tile=tile)
+        assert out.dtype == torch.float32
+        assert_close(nchw(out.cpu()), ref, fp32_tol(sum(cpg) * k * k), "%s x3 tile %d" % (name, tile))
+    with pytest.raises(Exception):
+        layer(src_d, tile=11)               # the row-shift tiles are bf16-only
+
+
+@pytest.mark.parametrize("case", F32_TAP_CASES, ids=[c[0] for c in F32_TAP_CASES])
+def test_conv_x3_tap_packed(dev, case):
+    from e2fgvi_amd import ops
+    name, N, H, W, cin, Cout, k, stride, pad, tiles = case
+    g = _gen(name_seed(name, 29))
+    w = torch.randn(Cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    wide = torch.randn(N, H, W, cin + 8, generator=g)
+    ref0 = conv64(nchw(wide[..., 4:4 + cin]), w, bias, stride=stride, padding=pad)
+    layer = ops.PackedConvX(w.to(dev), bias.to(dev), [cin], stride=stride, pad=pad, dtype=torch.float32, taps=True, x3=True)
+    plain = ops.PackedConvX(w.to(dev), bias.to(dev), [cin], stride=stride, pad=pad, dtype=torch.float32, x3=True)
+    assert layer.taps and not plain.taps and layer.wpacked.numel() < plain.wpacked.numel()
+    res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
+    src = [(wide.to(dev), 4)]
+    for tile in tiles:
+        out = layer(src, residual=res.to(dev), tile=tile)
+        assert_close(nchw(out.cpu()), ref0 + nchw(res), fp32_tol(cin * k * k), "%s x3 taps tile %d" % (name, tile))
+
+
+def test_x3_weight_planes_sum_to_the_weight(dev):
+    """the packing splits without loss: hi + mid + lo == w in fp32, for ordinary, tiny, huge and exactly-bf16 weights"""
+    from e2fgvi_amd import ops
+    g = _gen(41)
+    Cout, cin = 96, 64
+    w = torch.randn(Cout, cin, 1, 1, generator=g)
+    w[0] *= 1e-30
+    w[1] *= 1e30
+    w[2] = w[2].bfloat16().float()
+    w[3] = 0.0
+    w[4, :8, 0, 0] = torch.tensor([1.0, -1.0, 2.0 ** -126, -(2.0 ** -120), 3.0, 1.0 + 2.0 ** -23, -(1.0 + 2.0 ** -16), 65504.0])
+    layer = ops.PackedConvX(w.to(dev), None, [cin], dtype=torch.float32, x3=True)
+    torch.cuda.synchronize()
+    Npad = 96
+    p = layer.wpacked.view(cin // 32, 3, 4, Npad, 8).float().cpu()     # [K-step][plane][k-octet][n][8]
+    rebuilt = (p[:, 0].double() + p[:, 1].double() + p[:, 2].double())     # exact in fp64
+    rebuilt = rebuilt.permute(2, 0, 1, 3).reshape(Npad, cin)           # [n][step, octet, 8] -> [n][channel]
+    assert torch.equal(rebuilt.float(), w.view(Cout, cin)), "the three planes do not sum to the weight"
+    assert torch.equal(rebuilt, w.view(Cout, cin).double())
+
+
+def test_x3_matches_the_exact_fp32_kernel_on_exactly_representable_data(dev):
+    """operands with <= 8 significant bits have mid = lo = 0: the kernel must then reproduce an exact product sum (every term
+    fits fp32 for K = 256): bit-equal to the fp64 result rounded once"""
+    from e2fgvi_amd import ops
+    g = _gen(43)
+    x = torch.randint(-8, 9, (3000, 256), generator=g).float()
+    w = torch.randint(-8, 9, (128, 256), generator=g).float()
+    lin = ops.PackedLinearX(w.to(dev), None, dtype=torch.float32)
+    lin3 = ops.PackedConvX(w.to(dev), None, [256], dtype=torch.float32, x3=True)
+    ref = (x.double() @ w.double().t()).float()
+    out3 = torch.empty(3000, 1, 1, 128, device=dev)
+    lin3([x.to(dev).view(3000, 1, 1, 256)], out=out3)
+    assert torch.equal(out3.view(3000, 128).cpu(), ref)
+    assert torch.equal(lin(x.to(dev)).cpu(), ref)
+
+
+def test_x3_error_is_not_worse_than_the_fp32_mfma_kernel(dev):
+    """same call on the exact-fp32 MFMA kernel and on x3, both against fp64: the split kernel's error stays within 1.5x of the
+    fp32 kernel's (measured: equal or smaller -- the six terms are exact products, only the accumulation rounds)"""
+    from e2fgvi_amd import ops
+    from tests.util import err
+    g = _gen(47)
+    for rows, cin, cout in ((7200, 512, 1960), (7200, 1960, 512), (4000, 2880, 256)):
+        x = torch.randn(rows, cin, generator=g)
+        w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = F.linear(x.double(), w.double(), b.double())
+        a = ops.PackedLinearX(w.to(dev), b.to(dev), dtype=torch.float32)(x.to(dev)).cpu()
+        l3 = ops.PackedConvX(w.to(dev), b.to(dev), [cin], dtype=torch.float32, x3=True)
+        o3 = torch.empty(rows, 1, 1, cout, device=dev)
+        l3([x.to(dev).view(rows, 1, 1, cin)], out=o3)
+        e32, e3 = err(a, ref)[1], err(o3.view(rows, cout).cpu(), ref)[1]
+        print("linear %dx%d->%d: fp32 MFMA kernel %.2e, x3 %.2e of the output rms" % (rows, cin, cout, e32, e3))
+        assert e3 <= fp32_tol(cin) and e3 <= 1.5 * e32 + 1e-6
+
+
+def test_x3_dcn_postprocess_and_nchw(dev):
+    """the epilogue variants the fp32 engine uses: ACT_DCNPOST (conv_offset.6) and the fp32 NCHW store"""
+    from e2fgvi_amd import ops
+    g = _gen(53)
+    N, H, W = 2, 14, 22
+    x = torch.randn(N, 128, H, W, generator=g)
+    w = torch.randn(432, 128, 3, 3, generator=g) / 40
+    b = torch.randn(432, generator=g) * 0.1
+    f1 = torch.randn(N, 2, H, W, generator=g) * 2
+    f2 = torch.randn(N, 2, H, W, generator=g) * 2
+    raw = conv64(x, w, b, padding=1)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    off = 10 * torch.tanh(torch.cat((o1, o2), 1))
+    q1, q2 = torch.chunk(off, 2, 1)
+    ref = torch.cat([q1 + f1.flip(1).repeat(1, 72, 1, 1), q2 + f2.flip(1).repeat(1, 72, 1, 1), torch.sigmoid(m)], 1)
+    layer = ops.PackedConvX(w.to(dev), b.to(dev), [128], pad=1, dtype=torch.float32, x3=True)
+    out = layer([nhwc(x).to(dev)], residual=nhwc(torch.cat([f1, f2], 1)).to(dev), act=ops.ACT_DCNPOST, slope=10.0)
+    assert_close(nchw(out.cpu()), ref, 3e-5, "x3 dcn post-process epilogue")
+    w3 = torch.randn(24, 128, 3, 3, generator=g) / 34
+    l3 = ops.PackedConvX(w3.to(dev), None, [128], pad=1, dtype=torch.float32, x3=True)
+    out = l3([nhwc(x).to(dev)], out_nchw=True)
+    assert_close(out.cpu(), conv64(x, w3, padding=1), fp32_tol(1152), "x3 NCHW store")
+
+
+def test_x3_reruns_are_bit_identical(dev):
+    from e2fgvi_amd import ops
+    g = _gen(59)
+    x = torch.randn(7360, 512, generator=g).to(dev).view(7360, 1, 1, 512)
+    w = (torch.randn(1536, 512, generator=g) / 22).to(dev)
+    l3 = ops.PackedConvX(w, None, [512], dtype=torch.float32, x3=True)
+    first = l3([x], tile=7).clone()
+    bad = 0
+    for _ in range(100):
+        bad += int(not torch.equal(l3([x], tile=7), first))
+    assert bad == 0, "%d of 100 launches differ" % bad
+
+
+def test_fp32_layers_may_pick_the_split_kernel(dev):
+    """PackedConv / PackedLinear with try_x3: the decision (code ops.X3_BASE + tile when x3 wins) is recorded and whatever is chosen
+    meets the fp32 bound; E2FGVI_X3=0 (ops.X3_ENABLED False) never builds the alternative"""
+    from e2fgvi_amd import ops
+    g = _gen(61)
+    w = torch.randn(1960, 512, generator=g) / math.sqrt(512)
+    b = torch.randn(1960, generator=g) * 0.1
+    x = torch.randn(7200, 512, generator=g)
+    ref = F.linear(x.double(), w.double(), b.double())
+    lin = ops.PackedLinear(w.to(dev), b.to(dev))
+    lin.tune = lin.try_x3 = True
+    for _ in range(2):                        # first call tunes, second replays the decision
+        assert_close(lin(x.to(dev)).cpu(), ref, fp32_tol(512), "tuned linear with the x3 alternative")
+    key = [k for k in ops._TUNED if k[0] == 1960 and k[1] == (512,) and k[-1] == "x3"]
+    assert key, "no tuning decision recorded"
+    print("fc1-shaped fp32 linear: tile code", ops._TUNED[key[0]])
+    # a Winograd layer: the static rule against x3
+    wc = torch.randn(256, 128, 3, 3, generator=g) / 34
+    xc = torch.randn(10, 60, 108, 128, generator=g)
+    conv = ops.PackedConv(wc.to(dev), None, [128], pad=1, algo="auto")
+    conv.try_x3 = True
+    refc = conv64(nchw(xc), wc, padding=1)
+    for _ in range(2):
+        assert_close(nchw(conv([xc.to(dev)]).cpu()), refc, 3e-5, "winograd layer with the x3 alternative")
+    saved = ops.X3_ENABLED
+    try:
+        ops.X3_ENABLED = False
+        lin2 = ops.PackedLinear(w.to(dev), b.to(dev))
+        lin2.tune = lin2.try_x3 = True
+        lin2(x.to(dev))
+        assert lin2.alt3 is None
+    finally:
+        ops.X3_ENABLED = saved
+
+
+# ---------------------------------------------------------------------------------------------- Winograd with split operands
+from tests.test_gpu_ops import WINO_CASES, _act_ref     # noqa: E402
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c[:8]))
+def test_conv3x3_winograd_x3(dev, case):
+    """the fp32 Winograd kernel's own case list on the split-bf16 build (csrc/conv_wino.hip X3; tile codes ops.W3_BASE + block
+    shape): same bound against fp64 as the fp32 kernel (fp32 Winograd rounding), every block shape, and within the fp32
+    kernel's own error of the fp32 kernel"""
+    from e2fgvi_amd import ops
+    N, H, W, cpg, groups, Cout, act, tile, dst_ld, dst_coff = case
+    g = _gen(name_seed("wino x3 %s" % (case,), 3))
+    srcs = [torch.randn(N, groups * c, H, W, generator=g) for c in cpg]
+    cin_g = sum(cpg)
+    w = torch.randn(Cout, cin_g, 3, 3, generator=g) / math.sqrt(cin_g * 9)
+    b = torch.randn(Cout, generator=g)
+    xcat = torch.cat([s_.view(N, groups, c, H, W) for s_, c in zip(srcs, cpg)], 2).view(N, groups * cin_g, H, W)
+    ref = _act_ref(conv64(xcat, w, b, stride=1, padding=1, groups=groups), act, 0.2)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=1, pad=1, algo="winograd")
+    tol = fp32_tol(cin_g * 9, floor=3e-5)
+    src_d = [nhwc(s_).to(dev) for s_ in srcs]
+    fp32 = layer(src_d, act=act, slope=0.2, tile=132)
+    for shape in (132, 164, 32):
+        if dst_ld is None:
+            out = layer(src_d, act=act, slope=0.2, tile=ops.W3_BASE + shape)
+        else:
+            full = torch.full((N, H, W, dst_ld), 7.0, device=dev)
+            layer(src_d, out=full, out_coff=dst_coff, act=act, slope=0.2, tile=ops.W3_BASE + shape)
+            out = full[..., dst_coff:dst_coff + Cout]
+            rest = torch.cat([full[..., :dst_coff], full[..., dst_coff + Cout:]], 3)
+            assert (rest == 7.0).all(), "winograd x3 wrote outside its channel slice"
+        assert_close(nchw(out.cpu()), ref, tol, "winograd x3 shape %d %s" % (shape, case))
+        assert_close(out.cpu(), fp32.cpu(), 1.5 * tol, "winograd x3 vs fp32 winograd, shape %d %s" % (shape, case))
+
+
+@pytest.mark.parametrize("shape", [132, 164, 32])
+def test_conv3x3_winograd_x3_epilogues(dev, shape):
+    """residual (aligned and not) and ACT_DCNPOST on the split-bf16 Winograd kernel; reruns bit-identical"""
+    from e2fgvi_amd import ops
+    g = _gen(67 + shape)
+    x = torch.randn(2, 128, 30, 54, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
+    b = torch.randn(128, generator=g)
+    layer = ops.PackedConv(w.to(dev), b.to(dev), [128], pad=1, algo="winograd")
+    for res_ld, res_coff in ((128, 0), (131, 3)):
+        resfull = torch.randn(2, 30, 54, res_ld, generator=g)
+        res = resfull[..., res_coff:res_coff + 128]
+        ref = F.leaky_relu(conv64(x, w, b, padding=1) + nchw(res), 0.1)
+        out = layer([nhwc(x).to(dev)], residual=resfull.to(dev), res_coff=res_coff, act=2, slope=0.1, tile=ops.W3_BASE + shape)
+        assert_close(nchw(out.cpu()), ref, 3e-5, "winograd x3 + residual (ld %d coff %d) shape %d" % (res_ld, res_coff, shape))
+    w2 = torch.randn(432, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
+    b2 = torch.randn(432, generator=g) * 0.1
+    fl = torch.randn(2, 30, 54, 4, generator=g) * 3
+    raw = conv64(x, w2, b2, padding=1)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    off = 10 * torch.tanh(torch.cat([o1, o2], 1))
+    f1, f2 = fl[..., 0:2].permute(0, 3, 1, 2), fl[..., 2:4].permute(0, 3, 1, 2)
+    off1, off2 = torch.chunk(off, 2, 1)
+    ref = torch.cat([off1 + f1.flip(1).repeat(1, 72, 1, 1), off2 + f2.flip(1).repeat(1, 72, 1, 1), torch.sigmoid(m)], 1)
+    wl = ops.PackedConv(w2.to(dev), b2.to(dev), [128], pad=1, algo="winograd")
+    first = wl([nhwc(x).to(dev)], residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0, tile=ops.W3_BASE + shape)
+    assert_close(nchw(first.cpu()), ref, 5e-5, "winograd x3 DCNPOST shape %d" % shape)
+    first = first.clone()
+    bad = sum(int(not torch.equal(wl([nhwc(x).to(dev)], residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0,
+                                     tile=ops.W3_BASE + shape), first)) for _ in range(50))
+    assert bad == 0, "%d of 50 launches differ" % bad
