@@ -298,7 +298,10 @@ def main():
                              "the FLOPs ISSUED to the matrix pipe (the Winograd F(2x2,3x3) layers issue 16/36 of their direct-"
                              "convolution multiplies, plus block / channel padding: per-launch accounting of ops.PackedConv._work); "
                              "`*_algorithmic` count the reference's direct-convolution FLOPs (SURVEY.md 8d) and can exceed the "
-                             "peak on Winograd layers"},
+                             "peak on Winograd layers.  fp32 layers that run on the bf16 matrix pipe with exactly split operands "
+                             "(six bf16 MFMA terms per fp32 product, fp32-level rounding: tests/test_gpu_x3.py) are counted in "
+                             "fp32-MFMA equivalents (bf16 MACs x 157.3 / 2500), so `frac` stays the share of the time the "
+                             "matrix pipe is busy at its peak rate"},
     }
     # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the
     # summary of the last collection is committed under profiles/ and quoted here (bytes per forward of one clip)
@@ -329,7 +332,12 @@ def main():
                 dfile = os.path.join(ROOT, "profiles", "%s_dominant_kernel_traffic.json" % tag)
                 if os.path.exists(dfile):
                     try:
-                        dom["traffic"] = round(json.load(open(dfile))["hbm_bytes_per_launch"])
+                        dj = json.load(open(dfile))
+                        # only a measurement of the kernel that runs: round 3's files carry the kernel's trace name, older
+                        # ones are the fp32 F(2x4) kernel's
+                        if dj.get("kernel_tag", "conv_wino4<F(2x4),64>") != dom["kernel"].split(" (")[0]:
+                            continue
+                        dom["traffic"] = round(dj["hbm_bytes_per_launch"])
                         dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s_dominant_kernel_traffic.json)" % tag
                         break
                     except Exception:

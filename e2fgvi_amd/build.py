@@ -160,6 +160,16 @@ def check_kernel_waits(obj, name, ins):
             else:                                       # over the back edge: tail of the loop + its head
                 rng = list(range(inner[-1] + 2, hi + 1)) + list(range(lo, m))
             cnt = sum(1 for k in rng if vmem.match(ins[k][1]))
+            if cnt != n and len(inner) >= 1:
+                # a kernel that fetches TWO trips ahead (conv_wino.hip, X3 + LDS-DMA): its wait carries the loads of the two
+                # preceding inter-wait intervals (cyclically)
+                jj = (j - 1) % len(inner)
+                if jj:
+                    rng2 = range(inner[jj - 1] + 2, inner[jj])
+                else:
+                    rng2 = list(range(inner[-1] + 2, hi + 1)) + list(range(lo, inner[0]))
+                if cnt + sum(1 for k in rng2 if vmem.match(ins[k][1])) == n:
+                    continue
             if cnt != n:
                 raise RuntimeError("%s: %s: explicit s_waitcnt vmcnt(%d) at 0x%x follows %d vector-memory instructions "
                                    "since the previous explicit wait" % (obj, name[:60], n, ins[m][0], cnt))

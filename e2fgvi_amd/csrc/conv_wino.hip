@@ -180,7 +180,6 @@ typedef __attribute__((address_space(3))) void wino_lds_void;
 template <int MT, int BN, int SC, bool DMA, bool X3>
 __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
     static_assert(SC == 2, "chunks per LDS stage (the explicit vmcnt counts of k_loop assume two)");
-    static_assert(!(X3 && DMA), "the split-bf16 variant stages the patch through registers");
     constexpr int NT = 512;
     constexpr int TN = BN / 32;
     constexpr int RAW_H = 8 * MT + 2;
@@ -390,8 +389,8 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             for (int n = 0; n < TN; ++n) buf_load4_pinned(q[a][n], wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
     };
     // X3: the weights of a 16-channel stage, 3 planes per (position, column tile)
-    f32x4 bw[2][2][X3 ? TN : 1][3];
-    auto load_b3 = [&](int st, f32x4 (&q)[2][X3 ? TN : 1][3]) {
+    f32x4 bw[(X3 && DMA) ? 3 : 2][2][X3 ? TN : 1][3];
+    auto load_b3 = [&](int st, f32x4 (&q)[2][X3 ? TN : 1][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -446,21 +445,10 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
         if constexpr (X3) {
             // one iteration per LDS stage (16 channels): the stage's weights (2 positions x TN column tiles x 3 planes) were
             // issued a stage ago; since then: the patch prefetch of the stage after (SC * RAW_IT loads) and the next weights
-            // (stage 0's weights were issued by the prologue, between the two patch loads -- like the fp32 kernel's)
-            // (two stages per trip with compile-time buffer indices: `bw[st & 1]` would put the weight registers in scratch; an odd
-            //  stage count runs one stage past the end -- zero weights, like the fp32 kernel's chunk overrun)
-            auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
-                constexpr int CUR = decltype(CUR_)::value;
-                const unsigned char* stage = smem + CUR * STAGE_BYTES;
-                load_b3(st + 1, bw[CUR ^ 1]);
-                wait_vmcnt<6 * TN + SC * RAW_IT>();
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[CUR][a][n][pl]));
-                __builtin_amdgcn_sched_barrier(0);
+            // one stage's arithmetic: 12 patch reads, the transform of 8 channels for both positions, two splits, 12 TN MFMAs
+            // ... in two halves, so that the register-staged loop can run the MFMAs of stage st under the reads / transform / split
+            // of stage st + 1: x3_prep builds the six operand fragments of a stage, x3_mma issues the 12 TN MFMAs on them
+            auto x3_prep = [&](const unsigned char* stage, bf16x8 (&A)[MT][6]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const unsigned char* rm = stage + m * (8 * PLANE_ROW * 16);
@@ -477,15 +465,20 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
                         va[kq] = PB ? e[1] - e[0] : e[0] - e[2];
                         vb[kq] = PB ? e[0] - e[2] : e[1] + e[2];
                     }
-                    bf16x8 ah, am, al, bh, bm, bl;
-                    wino_split8(va[0], va[1], ah, am, al);
-                    wino_split8(vb[0], vb[1], bh, bm, bl);
+                    wino_split8(va[0], va[1], A[m][0], A[m][1], A[m][2]);
+                    wino_split8(vb[0], vb[1], A[m][3], A[m][4], A[m][5]);
+                }
+            };
+            auto x3_mma = [&](const bf16x8 (&A)[MT][6], f32x4 (&wq)[2][TN][3]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bf16x8 ah = A[m][0], am = A[m][1], al = A[m][2], bh = A[m][3], bm = A[m][4], bl = A[m][5];
 #pragma unroll
                     for (int n = 0; n < TN; ++n) {
-                        const bf16x8 u0h = __builtin_bit_cast(bf16x8, bw[CUR][0][n][0]), u0m = __builtin_bit_cast(bf16x8, bw[CUR][0][n][1]),
-                                     u0l = __builtin_bit_cast(bf16x8, bw[CUR][0][n][2]);
-                        const bf16x8 u1h = __builtin_bit_cast(bf16x8, bw[CUR][1][n][0]), u1m = __builtin_bit_cast(bf16x8, bw[CUR][1][n][1]),
-                                     u1l = __builtin_bit_cast(bf16x8, bw[CUR][1][n][2]);
+                        const bf16x8 u0h = __builtin_bit_cast(bf16x8, wq[0][n][0]), u0m = __builtin_bit_cast(bf16x8, wq[0][n][1]),
+                                     u0l = __builtin_bit_cast(bf16x8, wq[0][n][2]);
+                        const bf16x8 u1h = __builtin_bit_cast(bf16x8, wq[1][n][0]), u1m = __builtin_bit_cast(bf16x8, wq[1][n][1]),
+                                     u1l = __builtin_bit_cast(bf16x8, wq[1][n][2]);
                         // smallest terms first, the two positions interleaved (independent accumulators)
                         acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, u0h, acc[0][m][n], 0, 0, 0);
                         acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, u1h, acc[1][m][n], 0, 0, 0);
@@ -500,6 +493,76 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
                         acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, u0h, acc[0][m][n], 0, 0, 0);
                         acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, u1h, acc[1][m][n], 0, 0, 0);
                     }
+                }
+            };
+            auto claim3 = [&](f32x4 (&wq)[2][TN][3]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(wq[a][n][pl]));
+            };
+            if constexpr (DMA) {
+                // Patch by LDS-DMA into three LDS stages and everything fetched TWO stages ahead: with the matrix work of a
+                // stage cut to a third, one stage of lookahead no longer covers the L2 / fabric latency of the weight and patch
+                // loads (the one-workgroup-per-CU propagation layers ran at ~1.1 us per stage against ~0.5 us of arithmetic).
+                // Trip st issues the pieces and the weights of stage st + 2 (slot / buffer (st + 2) % 3: its previous readers
+                // passed the last barrier), claims stage st's weights -- issued two trips ago, 2 x (SC NPW + 6 TN) loads back --
+                // and, before the stage barrier, waits for its own pieces of stage st + 1 (all but this trip's loads).
+                constexpr int WV = 2 * XI + (PB ? 1 : 0);
+                constexpr int NPW = (PIECES - WV + 7) / 8;
+                constexpr int PER = SC * NPW + 6 * TN;                     // vector-memory instructions per trip
+#pragma unroll
+                for (int c4 = 0; c4 < 2 * SC; ++c4)
+                    dma_chunk(IC<WV>{}, IC<NPW>{}, c4, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
+                load_b3(0, bw[0]);
+                load_b3(1, bw[1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                auto trip = [&](auto CUR_, int st) __attribute__((always_inline)) {
+                    constexpr int CUR = decltype(CUR_)::value, NX2 = (CUR + 2) % 3;
+#pragma unroll
+                    for (int q = 0; q < SC; ++q)
+                        dma_chunk(IC<WV>{}, IC<NPW>{}, SC * (st + 2) + q, smem_lds + (unsigned)(NX2 * STAGE_BYTES + q * CHUNK_BYTES));
+                    load_b3(st + 2, bw[NX2]);
+                    wait_vmcnt<2 * PER>();
+                    claim3(bw[CUR]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        bf16x8 A[MT][6];
+                        x3_prep(smem + CUR * STAGE_BYTES, A);
+                        x3_mma(A, bw[CUR]);
+                    }
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");     // this wave's pieces of stage st + 1 have landed
+                    __syncthreads();
+                };
+                for (int st = 0; st < nstages; st += 3) {
+                    trip(IC<0>{}, st);
+                    trip(IC<1>{}, st + 1);
+                    trip(IC<2>{}, st + 2);
+                }
+                // pieces issued for stages past the end are still in flight and target LDS the epilogue is about to reuse
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                return;
+            }
+            // Register-staged patch (the product variant).  Entry state (prologue above): buffer 0 = stage 0 (visible), staging
+            // registers = stage 1, stage 0's weights issued between the two patch loads -- like the fp32 kernel's.
+            // (two stages per trip with compile-time buffer indices: `bw[st & 1]` would put the weight registers in scratch; an odd
+            //  stage count runs one stage past the end -- zero weights, like the fp32 kernel's chunk overrun)
+            // Measured and dropped (profiles/r03_x3_winograd_variants.txt): building the fragments of stage st + 1 under the MFMAs
+            // of stage st (one more fragment set, the same loads) ran 0-8 % slower; the LDS-DMA variant above 10-40 % slower.
+            auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
+                constexpr int CUR = decltype(CUR_)::value;
+                load_b3(st + 1, bw[CUR ^ 1]);
+                wait_vmcnt<6 * TN + SC * RAW_IT>();
+                claim3(bw[CUR]);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    bf16x8 A[MT][6];
+                    x3_prep(smem + CUR * STAGE_BYTES, A);
+                    x3_mma(A, bw[CUR]);
                 }
                 // the registers hold stage st + 1: park it in the other buffer (its readers passed the previous barrier)
                 store_raw(CUR ^ 1);
@@ -948,6 +1011,9 @@ static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
         case 32: return launch_wino<2, 32, 2, false, true>(p, d->groups, st);
         case 164: return launch_wino<1, 64, 2, false, true>(p, d->groups, st);
         case 132: return launch_wino<1, 32, 2, false, true>(p, d->groups, st);
+        // + 1000: patch by LDS-DMA, patch and weights fetched two stages ahead (32-cout shapes: three weight buffers fit)
+        case 1032: return launch_wino<2, 32, 2, true, true>(p, d->groups, st);
+        case 1132: return launch_wino<1, 32, 2, true, true>(p, d->groups, st);
         default: break;
     }
     e2fgvi_set_error("conv3x3_winograd_x3: tile must be 0 (auto), 32 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");

@@ -64,7 +64,7 @@ X3_MARGIN = 0.97
 X3_BASE = 30000
 # ... and the Winograd F(2x2,3x3) kernel with split operands (conv_wino.hip, X3 build): codes W3_BASE + its block shape
 W3_BASE = 40000
-W3_CANDIDATES = (132, 164, 32)
+W3_CANDIDATES = (132, 164, 32)       # (+ 1000: LDS-DMA patch staging with two stages of lookahead -- measured slower everywhere)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # The decisions are persisted: read from / appended to a per-library-build file next to the library (e2fgvi_amd/.tile_cache/,
 # or $E2FGVI_CACHE_DIR), so that
@@ -298,6 +298,7 @@ class PackedConv:
             kern = "conv_wino4<F(%dx4),%d>" % (fy, bn)
         elif use_wino and tile >= W3_BASE:
             shape = tile - W3_BASE
+            shape %= 1000
             mt, bn = (2, shape) if shape < 100 else (1, shape - 100)
             pix = N * (-(-H // (8 * mt)) * 8 * mt) * (-(-W // 16) * 16)
             cin_p = -(-sum(-(-c // 8) for c in self.cpg) // 2) * 16           # 16-channel stages
