@@ -25,9 +25,9 @@ NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
          ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino.hip", "conv_wino_x3.o", NOPK + ["-DE2_WINO_X3=1"]), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", NOPK),
          ("mdcn.hip", "mdcn.o", NOPK), ("attention.hip", "attention.o", []),
-         ("attention_bf16.hip", "attention_bf16.o", NOPK), ("misc.hip", "misc.o", NOPK),
+         ("attention_bf16.hip", "attention_bf16.o", NOPK), ("attention_x3.hip", "attention_x3.o", NOPK), ("misc.hip", "misc.o", NOPK),
          ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]
-NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "conv_wino_x3.o", "conv_tail.o", "mdcn.o", "attention_bf16.o", "misc.o", "video.o", "metrics.o")
+NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "conv_wino_x3.o", "conv_tail.o", "mdcn.o", "attention_bf16.o", "attention_x3.o", "misc.o", "video.o", "metrics.o")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 

@@ -392,7 +392,11 @@ class Engine(BF16Path):
         ops.window_pool(n1, blk["pool_w"], blk["pool_b"], b * t, fh, fw, out=nbuf[rows:])
         both = blk["qkv"](nbuf)
         qkv, kvp = both[:rows], both[rows:]
-        att = ops.focal_attention(qkv, kvp, tab, nk, b, t, fh, fw)
+        if ops.attention_x3_applies(b, t, fh, fw):
+            # both products on the bf16 matrix pipe (exactly split operands): one pass splits the k / v columns of all rows
+            att = ops.focal_attention_x3(qkv, ops.split3_kv(both), tab, nk, b, t, fh, fw)
+        else:
+            att = ops.focal_attention(qkv, kvp, tab, nk, b, t, fh, fw)
         x1 = blk["proj"](att, residual=x)
         n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"])
         hid = blk["fc1"](n2)

@@ -104,6 +104,8 @@ SYMBOLS = {
     "e2fgvi_pack_dcn_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_pack_dcn_weight_bf16": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_focal_attention": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_split3_kv": (C.c_int, [_fp, _fp, _i64, _fp]),
+    "e2fgvi_focal_attention_x3": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_nchw_to_nhwc": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _f, _f, _fp]),
     "e2fgvi_nhwc_to_nchw": (C.c_int, [_fp, _i32, _fp, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_resize_bilinear": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp]),

@@ -983,6 +983,60 @@ def focal_attention(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, waves=
     return out
 
 
+def split3_kv(rows_1536, out=None):
+    """the k / v columns of fp32 qkv rows ([rows, 1536], token rows followed by the pooled rows) as three bf16 planes
+    [3, rows, 1024] whose sum is the fp32 value bit for bit -- the K / V operand of focal_attention_x3"""
+    lib = _L.load()
+    _chk(rows_1536, "qkv rows")
+    if rows_1536.dim() != 2 or rows_1536.shape[1] != 1536:
+        raise ValueError("split3_kv takes [rows, 1536] fp32 rows")
+    rows = rows_1536.shape[0]
+    if out is None:
+        out = torch.empty((3, rows, 1024), dtype=torch.bfloat16, device=rows_1536.device)
+    _chk(out, "planes", torch.bfloat16)
+    _L.check(lib.e2fgvi_split3_kv(_ptr(rows_1536), _ptr(out), rows, _stream()), "split3_kv")
+    return out
+
+
+def focal_attention_x3(qkv, planes, key_tab, nkeys, B, T, fh, fw, out=None, waves=0):
+    """focal_attention (fp32 in / out, fp32 softmax) with both products on the bf16 matrix pipe: six exact bf16 MFMA terms
+    per fp32 product of three-way split operands (csrc/attention_x3.hip).  qkv: the fp32 token rows [B*T*fh*fw, 1536];
+    planes: split3_kv of those rows followed by the B*T*nWin pooled rows."""
+    lib = _L.load()
+    _chk(qkv, "qkv"); _chk(planes, "planes", torch.bfloat16)
+    _chk(key_tab, "key_tab", torch.int32); _chk(nkeys, "nkeys", torch.int32)
+    rows = B * T * fh * fw
+    nwin = (fh // 5) * (fw // 9)
+    if tuple(qkv.shape) != (rows, 1536):
+        raise ValueError("qkv must be [%d,1536], got %s" % (rows, tuple(qkv.shape)))
+    if tuple(planes.shape) != (3, rows + B * T * nwin, 1024):
+        raise ValueError("planes must be [3,%d,1024], got %s" % (rows + B * T * nwin, tuple(planes.shape)))
+    if key_tab.shape[0] != nwin or nkeys.shape[0] != nwin:
+        raise ValueError("key table must have %d rows" % nwin)
+    if out is None:
+        out = torch.empty((rows, 512), dtype=torch.float32, device=qkv.device)
+    _chk(out, "out")
+    if _L.TRACE is not None:
+        nkl = nkeys.tolist()
+        alg = B * nwin * 4 * (45 * T) * (210 * T) * 128 * 2
+        qpad = -(-(45 * T) // 32) * 32
+        iss = B * 4 * qpad * 128 * 2 * sum(-(-(T * k) // 32) * 32 for k in nkl)
+        # six bf16 MACs per product, in fp32-pipe equivalents (PackedConvX's trace record)
+        _L.annotate(layer="attention", kernel="focal_attn_x3", shape="B%d T%d grid %dx%d" % (B, T, fh, fw), macs=alg,
+                    issued=int(iss * 6 * 157.3 / 2500.0))
+    _L.check(lib.e2fgvi_focal_attention_x3(_ptr(qkv), _ptr(planes), _ptr(key_tab), key_tab.shape[1], _ptr(nkeys), _ptr(out),
+                                           B, T, fh, fw, waves, _stream()), "focal_attention_x3")
+    return out
+
+
+def attention_x3_applies(B, T, fh, fw):
+    """the split-operand attention takes the call: enabled, the three planes inside one 4 GiB buffer resource, and the
+    window's key table + two 48 KB stages inside the LDS"""
+    rows = B * T * (fh * fw + (fh // 5) * (fw // 9))
+    return (X3_ENABLED and os.environ.get("E2FGVI_ATT_X3", "1") != "0" and 3 * rows * 2048 < 0xFFFFF000
+            and -(-(T * 210) // 32) * 128 + 2 * 49152 + 1280 <= 160 * 1024)
+
+
 def focal_attention_bf16(qkv, kv_pool, key_tab, nkeys, B, T, fh, fw, out=None, variant=None):
     """bf16 data path: qkv [rows,1536] / kv_pool [B*T*nWin,1536] / out [rows,512] are bf16.
     variant (tests / A-B measurements): kernel variant for this call (see e2fgvi_focal_attention_bf16_variant)"""

@@ -391,6 +391,15 @@ int64_t e2fgvi_packed_conv_weight_f32x3_taps_size(int32_t Cout, int32_t KH, int3
 int e2fgvi_pack_conv_weight_f32x3_taps(const float* w, void* wpacked, int32_t Cout, int32_t KH, int32_t KW, int32_t cin,
                                        void* stream);
 
+/* ABI version 7: e2fgvi_focal_attention (fp32 in, fp32 softmax, fp32 out; tfocal_transformer.py:226-396) with both matrix
+ * products on the bf16 matrix pipe as six exact bf16 terms of three-way split operands (csrc/attention_x3.hip).
+ * e2fgvi_split3_kv: the k / v columns (512 .. 1535) of `rows` consecutive fp32 qkv rows -- the B*T*fh*fw token rows FOLLOWED by
+ * the B*T*nWin pooled rows -- as three bf16 planes planes[3][rows][1024] whose sum is the fp32 value bit for bit.
+ * e2fgvi_focal_attention_x3: qkv = the token rows (read for Q), planes = that buffer; waves: 0 (auto), 2, 4, 8. */
+int e2fgvi_split3_kv(const float* qkv_rows, void* planes, int64_t rows, void* stream);
+int e2fgvi_focal_attention_x3(const float* qkv, const void* planes, const int32_t* key_tab, int32_t tab_ld, const int32_t* nkeys,
+                              float* out, int32_t B, int32_t T, int32_t fh, int32_t fw, int32_t waves, void* stream);
+
 /* Fused temporal focal window attention on bf16 MFMA: qkv / kv_pool / out are bf16 with the layouts of
  * e2fgvi_focal_attention; scores, softmax statistics and accumulation are fp32.  qkv and kv_pool must lie within one
  * 4 GiB window (the engine allocates them back to back). */

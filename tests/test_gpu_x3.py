@@ -257,3 +257,48 @@ def test_conv3x3_winograd_x3_epilogues(dev, shape):
     bad = sum(int(not torch.equal(wl([nhwc(x).to(dev)], residual=fl.to(dev), act=ops.ACT_DCNPOST, slope=10.0,
                                      tile=ops.W3_BASE + shape), first)) for _ in range(50))
     assert bad == 0, "%d of 50 launches differ" % bad
+
+
+# ---------------------------------------------------------------------------------------------- attention with split operands
+def _attention_case(B, T, fh, fw, seed):
+    from e2fgvi_amd.engine import build_key_table
+    from e2fgvi_amd.synth import rolled_valid_index
+    from oracle import e2fgvi_oracle as O
+    g = _gen(seed)
+    Cc = 512
+    xn = torch.randn(B, T, fh, fw, Cc, generator=g)
+    sd = {"a.qkv.weight": torch.randn(1536, Cc, generator=g) / math.sqrt(Cc) * 2.0,
+          "a.qkv.bias": torch.randn(1536, generator=g) * 0.1,
+          "pool_layers.0.weight": torch.full((1, 45), 1 / 45.) + 0.02 * torch.randn(1, 45, generator=g),
+          "pool_layers.0.bias": torch.zeros(1)}
+    xp = O.pool_windows(sd, "", xn)
+    pre = O.window_attention(sd, "a.", xn, xp, preproj=True)
+    ref = O.window_reverse(pre, B, T, fh, fw).reshape(-1, Cc)
+    qkv = F.linear(xn.reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
+    kvp = F.linear(xp.permute(0, 3, 1, 2, 4).reshape(-1, Cc), sd["a.qkv.weight"], sd["a.qkv.bias"])
+    tab, nk = build_key_table(fh, fw, rolled_valid_index().tolist())
+    return ref, qkv, kvp, torch.from_numpy(tab), torch.from_numpy(nk)
+
+
+@pytest.mark.parametrize("B,T,fh,fw", [(1, 3, 10, 18), (2, 2, 20, 36), (1, 5, 20, 36), (1, 2, 15, 45), (1, 40, 5, 9), (1, 4, 60, 108)])
+def test_focal_attention_x3(dev, B, T, fh, fw):
+    """the fp32 attention's own cases (+ a 12x12-window HQ grid with 210-key windows) on the split-operand kernel, every
+    workgroup shape, against the oracle's roll / partition / cat / softmax chain (tfocal_transformer.py:226-396) at the fp32
+    kernel's tolerance; the planes of split3_kv sum to the k / v columns bit for bit; reruns are bit-identical"""
+    from e2fgvi_amd import ops
+    from tests.test_gpu_ops import ATT_TOL
+    ref, qkv, kvp, tab, nk = _attention_case(B, T, fh, fw, 6 + fh)
+    both = torch.cat([qkv, kvp], 0).to(dev)
+    q_d, p_d = both[:qkv.shape[0]], both[qkv.shape[0]:]
+    planes = ops.split3_kv(both)
+    torch.cuda.synchronize()
+    assert torch.equal(planes.double().sum(0).float(), both[:, 512:]) and torch.equal(planes.double().sum(0), both[:, 512:].double())
+    fp32 = ops.focal_attention(q_d, p_d, tab.to(dev), nk.to(dev), B, T, fh, fw)
+    for waves in (0, 2, 4, 8):
+        out = ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw, waves=waves)
+        assert_close(out.cpu(), ref, ATT_TOL, "attention x3 %dx%d T=%d waves=%d" % (fh, fw, T, waves))
+        # two fp32-level results, each within ~1.5e-5 of the truth: their difference within twice that, growing with sqrt(keys)
+        assert_close(out, fp32, 4e-5 * max(1.0, (T * 210 / 840.0) ** 0.5), "attention x3 vs the fp32 kernel, waves=%d" % waves)
+    first = ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw).clone()
+    bad = sum(int(not torch.equal(ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw), first)) for _ in range(30))
+    assert bad == 0, "%d of 30 launches differ" % bad
