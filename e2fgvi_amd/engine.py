@@ -25,9 +25,11 @@ from .engine_x import BF16Path
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedConvX, PackedDcn, PackedLinear
 
 TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
-# fp32 path: the FFN's second Linear as a conv of the folded tensor (as the bf16 path runs it).  Measured neutral in fp32
-# (15.785 vs 15.775 ms, profiles/r02_fc2_conv.txt: the 16-byte tap-packed fetches cost what the unfold kernel saved) -> off
-FC2_CONV = os.environ.get("E2FGVI_FC2_CONV_FP32", "0") != "0"
+# fp32 path: the FFN's second Linear as a conv of the folded tensor (as the bf16 path runs it).  Measured neutral on the fp32
+# MFMA kernels (15.785 vs 15.775 ms, profiles/r02_fc2_conv.txt: the 16-byte tap-packed fetches cost what the unfold kernel
+# saved); with the split-operand kernels (ops.X3_ENABLED) the conv form wins -- 743 -> 750 frames/s, same box, two runs each
+# (profiles/r03_fc2_conv_x3.txt) -- and is the default
+FC2_CONV = os.environ.get("E2FGVI_FC2_CONV_FP32", "1" if ops.X3_ENABLED else "0") != "0"
 WIN = (5, 9)
 
 
