@@ -78,9 +78,16 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // S16 (with BF): the sources are bf16 NHWC.  A 16-byte corner fetch then carries 8 channels instead of 4, so an item is
 // (row, unit, 8-channel half): half the items, half the fetches and half the per-item offset arithmetic (the bilinear
 // weights, tanh / sigmoid and address math are computed once per item) for the same slab.
-template <int BM, int BN, int WGM, int WGN, int KS, bool BF, bool S16>
+// X3 (with BF, fp32 sources; round 3): the fp32 layer on the bf16 matrix pipe -- every blended value is split EXACTLY into three
+// bf16 numbers (hi = the value with its low 16 bits cleared, mid = the same of the exact remainder, lo = the rest) by the
+// thread that blends it, once per workgroup, the weights are packed as three bf16 planes whose sum is the fp32 weight, and six
+// of the nine bf16 partial products are accumulated (conv_bf16x.hip MODE 2): fp32-level rounding at 6 x 32 instead of 8 x 64
+// MFMA cycles per 16 k.  LDS images: A [3 planes][BM rows][32 k (+8 pad)], B [3 planes][4 k-octets][BN][8].
+template <int BM, int BN, int WGM, int WGN, int KS, bool BF, bool S16, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnParams p) {
     static_assert(BF || !S16, "bf16 sources only with the bf16 MFMA slab");
+    static_assert(!X3 || (BF && !S16), "the split-operand variant: bf16 LDS images of fp32 sources");
+    constexpr int NP = X3 ? 3 : 1;                    // bf16 planes per operand
     constexpr int SB = S16 ? 2 : 4;                   // source element size
     constexpr int CQ = S16 ? 2 : 4;                   // 16-byte corner fetches per (row, unit): 16 channels
     constexpr int BK = 32;
@@ -90,9 +97,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     constexpr int LDA16 = BK + 8;                     // bf16 elements per A row
     constexpr int A_ITEMS = BM * 2 * CQ;              // (row, unit-in-chunk, 16-byte channel part)
     constexpr int A_IT = (A_ITEMS + NG - 1) / NG;
-    constexpr int B_F4 = BF ? BK * BN / 8 : BK * BN / 4;      // 16-byte items of a chunk's weight slab
+    constexpr int B_F4 = BF ? NP * BK * BN / 8 : BK * BN / 4;      // 16-byte items of a chunk's weight slab
     constexpr int B_IT = (B_F4 + NG - 1) / NG;
-    constexpr int STAGE = BF ? (BM * LDA16 + BK * BN) / 2 : BM * LDA + BK * BN;      // floats
+    constexpr int STAGE = BF ? NP * (BM * LDA16 + BK * BN) / 2 : BM * LDA + BK * BN;      // floats
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(KS * 2 * STAGE >= (KS - 1) * NG * TM * TN * 16, "reduction scratch must fit in LDS");
 
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         const bool ok = (B_F4 % NG == 0 || f < B_F4) && (n0 + n) < p.Npad;
         b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
     }
-    const unsigned b_step = (unsigned)(BF ? BK / 8 : BK / 4) * (unsigned)p.Npad * 16u;
+    const unsigned b_step = (unsigned)(BF ? NP * BK / 8 : BK / 4) * (unsigned)p.Npad * 16u;
 
     // two register sets: the corner fetches / weights of chunk k+2 are issued while those of chunk k+1 (issued one
     // iteration earlier) are blended into LDS -- a whole MFMA block plus another group's turn covers the gather latency
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     };
     auto store_tile = [&](int buf, int S) {
         float* sA = sbase + buf * STAGE;
-        float* sB = BF ? sA + BM * LDA16 / 2 : sA + BM * LDA;
+        float* sB = BF ? sA + NP * BM * LDA16 / 2 : sA + BM * LDA;
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             if (A_ITEMS % NG == 0 || (tid + ia * NG) < A_ITEMS) {
@@ -321,7 +328,27 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                     continue;
                 }
                 const f32x4 v = c00[S][ia] * w00[S][ia] + c01[S][ia] * w01[S][ia] + c10[S][ia] * w10[S][ia] + c11[S][ia] * w11[S][ia];
-                if (BF) {
+                if constexpr (X3) {
+                    // hi / mid / lo of the four blended values: 8-byte writes into the three A planes
+                    const u32x4 xb = __builtin_bit_cast(u32x4, v);
+                    unsigned rb[4], r2b[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned xe = xb[e];       // (a scalar copy: bit_cast of a vector ELEMENT reads element 0, see conv_bf16x.hip)
+                        const float r = __builtin_bit_cast(float, xe) - __builtin_bit_cast(float, xe & 0xFFFF0000u);
+                        rb[e] = __builtin_bit_cast(unsigned, r);
+                        const float r2 = r - __builtin_bit_cast(float, rb[e] & 0xFFFF0000u);
+                        r2b[e] = __builtin_bit_cast(unsigned, r2);
+                    }
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 ph = {(xb[1] & 0xFFFF0000u) | (xb[0] >> 16), (xb[3] & 0xFFFF0000u) | (xb[2] >> 16)};
+                    const u32x2 pm = {(rb[1] & 0xFFFF0000u) | (rb[0] >> 16), (rb[3] & 0xFFFF0000u) | (rb[2] >> 16)};
+                    const u32x2 pl = {(r2b[1] & 0xFFFF0000u) | (r2b[0] >> 16), (r2b[3] & 0xFFFF0000u) | (r2b[2] >> 16)};
+                    __bf16* a16 = reinterpret_cast<__bf16*>(sA) + it_row[ia] * LDA16 + it_uu[ia] * 16 + it_c4[ia] * 4;
+                    *reinterpret_cast<u32x2*>(a16) = ph;
+                    *reinterpret_cast<u32x2*>(a16 + BM * LDA16) = pm;
+                    *reinterpret_cast<u32x2*>(a16 + 2 * BM * LDA16) = pl;
+                } else if (BF) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     bf16x4 hv = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(sA) + it_row[ia] * LDA16 + it_uu[ia] * 16 + it_c4[ia] * 4) = hv;
@@ -375,7 +402,34 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             const int kt = kg + (it + par) * KS;
             issue_corners(kt + 2 * KS, par, par);            // raw words of chunk i+2 from sraw buffer i&1
             load_w(kt + 2 * KS, par);
-            if (BF) {
+            if constexpr (X3) {
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                const __bf16* sA16 = reinterpret_cast<const __bf16*>(sbase + cur * STAGE);
+                const __bf16* sB16 = sA16 + 3 * BM * LDA16;
+                const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            a[pl][tm] = *reinterpret_cast<const bf16x8*>(sA16 + pl * (BM * LDA16) + ((wm * TM + tm) * 32 + li) * LDA16 + (2 * kk + lh) * 8);
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            b[pl][tn] = *reinterpret_cast<const bf16x8*>(sB16 + pl * (BK * BN) + ((2 * kk + lh) * BN + (wn * TN + tn) * 32 + li) * 8);
+                    }
+                    // smallest terms first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t6]][tm], b[PB[t6]][tn], acc[tm][tn], 0, 0, 0);
+                }
+            } else if (BF) {
                 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                 const __bf16* sA16 = reinterpret_cast<const __bf16*>(sbase + cur * STAGE);
                 const __bf16* sB16 = sA16 + BM * LDA16;
@@ -504,6 +558,36 @@ __global__ void pack_dcn_weight_bf16_kernel(const float* __restrict__ w, __bf16*
     wp[idx] = (__bf16)v;
 }
 
+// split-operand weights (X3): [chunk][plane hi, mid, lo][4 k-octets][Npad][8] bf16; `total` counts the fp32 values
+__global__ void pack_dcn_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout, int C, int KK,
+                                          int cg, int Npad, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = (int)(idx & 7);
+    long long rem = idx >> 3;
+    const int n = (int)(rem % Npad);
+    const int ko = (int)(rem / Npad);
+    const int k = ko * 8 + e;
+    const int u = k >> 4, c = k & 15;
+    const int cgq = cg / 16;
+    const int g = u / (KK * cgq);
+    const int r2u = u - g * (KK * cgq);
+    const int tap = r2u / cgq, cq = r2u - tap * cgq;
+    const int ch = g * cg + cq * 16 + c;
+    float v = 0.f;
+    if (ch < C && n < Cout && g * cg < C) v = w[((long long)n * C + ch) * KK + tap];
+    const unsigned xb = __builtin_bit_cast(unsigned, v);
+    const float r = v - __builtin_bit_cast(float, xb & 0xFFFF0000u);
+    const unsigned rb = __builtin_bit_cast(unsigned, r);
+    const float r2 = r - __builtin_bit_cast(float, rb & 0xFFFF0000u);
+    const int chunk = ko >> 2, oct = ko & 3;
+    const long long plane = 4LL * Npad * 8;
+    unsigned short* o = wp + (long long)chunk * 3 * plane + ((long long)oct * Npad + n) * 8 + e;
+    o[0] = (unsigned short)(xb >> 16);
+    o[plane] = (unsigned short)(rb >> 16);
+    o[2 * plane] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+}
+
 long long dcn_packed_size(int Cout, int C, int KH, int KW) {
     const int units = (C / 16) * KH * KW;
     const int KT = (units + 1) / 2;
@@ -511,7 +595,7 @@ long long dcn_packed_size(int Cout, int C, int KH, int KW) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS>
-int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16) {
+int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16, bool x3 = false) {
     p.tilesM = cdiv(p.M, BM);
     if (p.sw) {
         p.swX = cdiv(p.Wo, 8);
@@ -519,7 +603,15 @@ int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16) {
         p.tilesM = p.N * p.swX * p.swY;
     }
     p.tilesN = cdiv(p.Cout, BN);
-    if (s16)
+    if (x3) {
+        // three bf16 planes per operand: two ring stages per K group must fit the LDS beside the offset slots
+        if constexpr (KS * 2 * 3 * (BM * (32 + 8) + 32 * BN) * 2 + KS * 2 * 2 * BM * 32 + MAX_UNITS * 32 + 1024 <= 160 * 1024)
+            hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+        else {
+            e2fgvi_set_error("mdcn: this tile does not fit the LDS with split operands");
+            return E2FGVI_EUNSUP;
+        }
+    } else if (s16)
         hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
     else if (bf)
         hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
@@ -564,6 +656,19 @@ extern "C" int e2fgvi_pack_dcn_weight_bf16(const float* w, void* wpacked, int32_
     return 0;
 }
 
+/* split-operand weights for mfma_dtype = E2FGVI_BF16X3: 3 x e2fgvi_packed_dcn_weight_size elements of 2 bytes (ABI 7) */
+extern "C" int e2fgvi_pack_dcn_weight_x3(const float* w, void* wpacked, int32_t Cout, int32_t C, int32_t KH, int32_t KW,
+                                         int32_t deform_groups, void* stream) {
+    E2_REQUIRE(w && wpacked, E2FGVI_EINVAL, "pack_dcn_weight_x3: null pointer");
+    E2_REQUIRE(Cout > 0 && C > 0 && deform_groups > 0 && C % deform_groups == 0 && (C / deform_groups) % 16 == 0,
+               E2FGVI_EUNSUP, "pack_dcn_weight_x3: channels per deform group must be a multiple of 16");
+    const long long total = dcn_packed_size(Cout, C, KH, KW);
+    hipLaunchKernelGGL(pack_dcn_weight_x3_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short*)wpacked, Cout, C, KH * KW, C / deform_groups, round_up(Cout, 32), total);
+    E2_LAUNCH_CHECK("pack_dcn_weight_x3");
+    return 0;
+}
+
 extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "mdcn: null descriptor");
     E2_REQUIRE(d->nsrc == 1 || d->nsrc == 2, E2FGVI_EINVAL, "mdcn: nsrc must be 1 or 2");
@@ -571,6 +676,9 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     int C = 0;
     E2_REQUIRE(d->src_dtype == E2FGVI_F32 || (d->src_dtype == E2FGVI_BF16 && d->mfma_dtype == E2FGVI_BF16), E2FGVI_EINVAL,
                "mdcn: src_dtype must be E2FGVI_F32, or E2FGVI_BF16 together with mfma_dtype = E2FGVI_BF16");
+    E2_REQUIRE(d->mfma_dtype == E2FGVI_F32 || d->mfma_dtype == E2FGVI_BF16 || d->mfma_dtype == E2FGVI_BF16X3, E2FGVI_EINVAL,
+               "mdcn: mfma_dtype must be E2FGVI_F32, E2FGVI_BF16 or E2FGVI_BF16X3");
+    const bool x3 = d->mfma_dtype == E2FGVI_BF16X3;
     const bool s16 = d->src_dtype == E2FGVI_BF16;
     const int sb = s16 ? 2 : 4;
     for (int s = 0; s < 2; ++s) { p.src[s] = nullptr; p.ld[s] = 0; p.c[s] = 0; }
@@ -617,7 +725,7 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         const long long P = (long long)d->N * d->Ho * d->Wo;
         const long long sb0 = (long long)d->N * d->H * d->W * p.ld[0] * sb, sb1 = (long long)d->N * d->H * d->W * p.ld[1] * sb;
         const long long ob = P * d->off_ld * 4, mb = P * d->mask_ld * 4,
-                        wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * (d->mfma_dtype == E2FGVI_BF16 ? 2 : 4);
+                        wb = dcn_packed_size(d->Cout, C, d->KH, d->KW) * (d->mfma_dtype == E2FGVI_BF16 ? 2 : x3 ? 6 : 4);
         E2_REQUIRE(sb0 < 2147483392LL && sb1 < 2147483392LL && ob < 4294967295LL && mb < 4294967295LL && wb < 4294967295LL,
                    E2FGVI_EUNSUP, "mdcn: a source spans >= 2 GiB (or offsets / masks >= 4 GiB); buffer addressing needs less (split the batch)");
         p.src_bytes[0] = (unsigned)sb0; p.src_bytes[1] = (unsigned)sb1;
@@ -649,12 +757,13 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         }
     }
     const bool bf = d->mfma_dtype == E2FGVI_BF16;
-    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf, s16);
-    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream, bf, s16);
-    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream, bf, s16);
-    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream, bf, s16);
-    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream, bf, s16);
-    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream, bf, s16);
+    if (x3 && !d->tile) tile = tile == 5 ? 4 : tile;     // three planes per operand: the three-K-group tile does not fit the LDS
+    if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf, s16, x3);
+    if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream, bf, s16, x3);
+    if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream, bf, s16, x3);
+    if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream, bf, s16, x3);
+    if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream, bf, s16, x3);
+    if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream, bf, s16, x3);
     e2fgvi_set_error("mdcn: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }

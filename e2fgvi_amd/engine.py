@@ -143,7 +143,9 @@ class Engine(BF16Path):
                    PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1, **ww),
                    PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1,
                               algo=ww["algo"])]
-            dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1)
+            # (split-operand MFMA with the other x3 kernels: ops.X3_ENABLED, E2FGVI_DCN_X3=0 keeps the fp32 MFMA)
+            dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1,
+                            mfma="x3" if (precision == "fp32" and ops.X3_ENABLED and os.environ.get("E2FGVI_DCN_X3", "1") != "0") else "fp32")
             b = "feat_prop_module.backbone.%s." % d
             bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **ww),
                   PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **ww)]

@@ -103,6 +103,7 @@ SYMBOLS = {
     "e2fgvi_packed_dcn_weight_size": (_i64, [_i32, _i32, _i32, _i32]),
     "e2fgvi_pack_dcn_weight": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_pack_dcn_weight_bf16": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
+    "e2fgvi_pack_dcn_weight_x3": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_focal_attention": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),
     "e2fgvi_split3_kv": (C.c_int, [_fp, _fp, _i64, _fp]),
     "e2fgvi_focal_attention_x3": (C.c_int, [_fp, _fp, _fp, _i32, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp]),

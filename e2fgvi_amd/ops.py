@@ -861,16 +861,25 @@ class PackedTailConv:
 class PackedDcn:
     def __init__(self, weight, bias, deform_groups, stride=1, pad=0, dil=1, mfma="fp32"):
         """mfma="bf16": the sampled columns and the weights are rounded to bf16 for the MFMA (bf16 data path); the gather,
-        the bilinear blend and the accumulation stay fp32."""
+        the bilinear blend and the accumulation stay fp32.
+        mfma="x3": the fp32 layer on the bf16 matrix pipe -- blended values and weights split exactly into three bf16 pieces,
+        six bf16 MFMA terms per product (fp32-level rounding; fp32 sources)."""
         lib = _L.load()
+        if mfma not in ("fp32", "bf16", "x3"):
+            raise ValueError("mfma must be 'fp32', 'bf16' or 'x3'")
         self.mfma_bf16 = mfma == "bf16"
+        self.mfma_x3 = mfma == "x3"
         w = _chk(weight.detach().float().contiguous(), "weight")
         self.Cout, self.C, self.KH, self.KW = w.shape
         self.dg, self.stride, self.pad, self.dil = deform_groups, stride, pad, dil
         n = lib.e2fgvi_packed_dcn_weight_size(self.Cout, self.C, self.KH, self.KW)
         if n < 0:
             _L.check(int(n), "packed_dcn_weight_size")
-        if self.mfma_bf16:
+        if self.mfma_x3:
+            self.wpacked = torch.empty(3 * int(n), dtype=torch.bfloat16, device=w.device)
+            _L.check(lib.e2fgvi_pack_dcn_weight_x3(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
+                                                   deform_groups, _stream()), "pack_dcn_weight_x3")
+        elif self.mfma_bf16:
             self.wpacked = torch.empty(int(n), dtype=torch.bfloat16, device=w.device)
             _L.check(lib.e2fgvi_pack_dcn_weight_bf16(_ptr(w), _ptr(self.wpacked), self.Cout, self.C, self.KH, self.KW,
                                                      deform_groups, _stream()), "pack_dcn_weight_bf16")
@@ -936,11 +945,12 @@ class PackedDcn:
             out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=sources[0].device)
         _chk_any(out, "out")
         d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile, _dt(out)
-        d.mfma_dtype = _L.DT_BF16 if self.mfma_bf16 else _L.DT_F32
+        d.mfma_dtype = 2 if self.mfma_x3 else (_L.DT_BF16 if self.mfma_bf16 else _L.DT_F32)
         if _L.TRACE is not None:
             m = N * Ho * Wo * self.Cout * self.C * K
-            _L.annotate(layer=self.name, kernel="mdcn_bf16" if self.mfma_bf16 else "mdcn", shape="N%d %dx%d %d->%d dg%d" % (N, H, W, self.C, self.Cout, self.dg),
-                        macs=m, issued=m)
+            _L.annotate(layer=self.name, kernel="mdcn_x3" if self.mfma_x3 else ("mdcn_bf16" if self.mfma_bf16 else "mdcn"),
+                        shape="N%d %dx%d %d->%d dg%d" % (N, H, W, self.C, self.Cout, self.dg),
+                        macs=m, issued=int(m * 6 * 157.3 / 2500.0) if self.mfma_x3 else m)
         _L.check(lib.e2fgvi_mdcn_nhwc(C.byref(d), _stream()), "mdcn_nhwc")
         return out
 

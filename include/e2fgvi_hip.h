@@ -74,6 +74,7 @@ int e2fgvi_psnr_ssim(const float* img1, const float* img2, int32_t N, int32_t H,
 /* element types of the tensors of the bf16 data path (see the end of this header) */
 #define E2FGVI_F32 0
 #define E2FGVI_BF16 1
+#define E2FGVI_BF16X3 2      /* mdcn mfma_dtype (ABI 7): fp32 sources and results, the MFMA operands as three bf16 pieces each, six exact terms per product */
 
 const char* e2fgvi_last_error(void);
 int e2fgvi_abi_version(void);
@@ -207,6 +208,10 @@ int64_t e2fgvi_packed_dcn_weight_size(int32_t Cout, int32_t C, int32_t KH, int32
 /* w: [Cout, C, KH, KW] */
 int e2fgvi_pack_dcn_weight(const float* w, float* wpacked, int32_t Cout, int32_t C, int32_t KH,
                            int32_t KW, int32_t deform_groups, void* stream);
+/* split-operand packing (3 x e2fgvi_packed_dcn_weight_size elements of 2 bytes: three bf16 planes whose sum is the fp32 weight)
+ * for mfma_dtype = E2FGVI_BF16X3 -- the fp32 deformable conv (feat_prop.py:55-58) on the bf16 matrix pipe, fp32-level rounding */
+int e2fgvi_pack_dcn_weight_x3(const float* w, void* wpacked, int32_t Cout, int32_t C, int32_t KH, int32_t KW,
+                              int32_t deform_groups, void* stream);
 /* bf16 packing (e2fgvi_packed_dcn_weight_size elements of 2 bytes) for mfma_dtype = E2FGVI_BF16 */
 int e2fgvi_pack_dcn_weight_bf16(const float* w, void* wpacked, int32_t Cout, int32_t C, int32_t KH,
                                 int32_t KW, int32_t deform_groups, void* stream);

@@ -302,3 +302,50 @@ def test_focal_attention_x3(dev, B, T, fh, fw):
     first = ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw).clone()
     bad = sum(int(not torch.equal(ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw), first)) for _ in range(30))
     assert bad == 0, "%d of 30 launches differ" % bad
+
+
+# ---------------------------------------------------------------------------------------------- deformable conv with split operands
+def test_mdcn_x3(dev):
+    """the propagation's fused deformable conv (two sources, raw conv_offset output + flows, feat_prop.py:38-58) and the
+    finished-offsets form on the split-operand MFMA (mfma="x3"): the fp32 kernel's bound against the oracle's
+    modulated_deform_conv2d, every tile that fits the LDS with three planes per operand, the weight planes sum to the weights,
+    reruns bit-identical"""
+    from e2fgvi_amd import ops
+    from oracle.dcn import modulated_deform_conv2d
+    g = _gen(71)
+    N, H, W, dg = 1, 30, 54, 16
+    a = torch.randn(N, 128, H, W, generator=g)
+    c = torch.randn(N, 128, H, W, generator=g)
+    raw = torch.randn(N, 432, H, W, generator=g) * 0.5
+    f1 = torch.randn(N, 2, H, W, generator=g) * 2
+    f2 = torch.randn(N, 2, H, W, generator=g) * 2
+    w = torch.randn(128, 256, 3, 3, generator=g) / 48
+    b = torch.randn(128, generator=g)
+    o1, o2, m = torch.chunk(raw, 3, 1)
+    offset = 10 * torch.tanh(torch.cat((o1, o2), 1))
+    q1, q2 = torch.chunk(offset, 2, 1)
+    q1 = q1 + f1.flip(1).repeat(1, 72, 1, 1)
+    q2 = q2 + f2.flip(1).repeat(1, 72, 1, 1)
+    ref = modulated_deform_conv2d(torch.cat([a, c], 1), torch.cat([q1, q2], 1), torch.sigmoid(m), w, b, 1, 1, 1, 1, dg)
+    layer = ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1, mfma="x3")
+    fp32 = ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)
+    torch.cuda.synchronize()
+    assert torch.equal(layer.wpacked.view(-1, 3, 4 * 128 * 8).double().sum(1).float().view(-1), fp32.wpacked.view(-1, 4, 128, 2, 4).permute(
+        0, 1, 3, 2, 4).reshape(-1)) or True       # (layouts differ: [chunk][4 octets][N][8] vs [chunk][8 quads][N][4]; checked below)
+    w3 = layer.wpacked.view(-1, 3, 4, 128, 8).double().sum(1)                      # [chunk][octet][n][8]  -> k = octet * 8 + e
+    w1 = fp32.wpacked.view(-1, 8, 128, 4).double()                                  # [chunk][quad][n][4]   -> k = quad * 4 + e
+    assert torch.equal(w3.permute(0, 2, 1, 3).reshape(-1, 128, 32), w1.permute(0, 2, 1, 3).reshape(-1, 128, 32)), \
+        "the three weight planes do not sum to the fp32 weights"
+    flows = nhwc(torch.cat([f1, f2], 1)).to(dev)
+    srcs = [nhwc(a).to(dev), nhwc(c).to(dev)]
+    for tile in (0, 1, 2, 3, 4):
+        out = layer(srcs, nhwc(raw).to(dev), flows=flows, max_residue=10.0, tile=tile)
+        assert_close(nchw(out.cpu()), ref, 5e-5, "mdcn x3 fused tile %d" % tile)
+    with pytest.raises(Exception):
+        layer(srcs, nhwc(raw).to(dev), flows=flows, tile=5)          # three K groups x three planes: no LDS for it
+    final = torch.cat([q1, q2, torch.sigmoid(m)], 1)
+    out = layer(srcs, nhwc(final).to(dev))
+    assert_close(nchw(out.cpu()), ref, 5e-5, "mdcn x3 finished offsets")
+    first = out.clone()
+    bad = sum(int(not torch.equal(layer(srcs, nhwc(final).to(dev)), first)) for _ in range(100))
+    assert bad == 0, "%d of 100 launches differ" % bad

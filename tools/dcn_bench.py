@@ -29,3 +29,17 @@ for tile in (0, 1, 2, 3, 4, 5, 6, 105, 104, 102, 5):
     us = 1e3 * e0.elapsed_time(e1) / iters
     gf = 2 * N * H * W * 128 * 2304 * 1e-9
     print("dcn N=%d tile %d: %7.1f us  %5.1f TF (diff %.1e)" % (N, tile, us, gf / us * 1e3 / 1e3, diff), flush=True)
+# the same layer on the split-operand MFMA (mfma="x3")
+layer3 = ops.PackedDcn(w, b, 16, pad=1, mfma="x3")
+for tile in (0, 1, 2, 3, 4):
+    out = layer3([a, c], raw, flows=fl, tile=tile)
+    diff = (out - ref).abs().max().item()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        layer3([a, c], raw, flows=fl, out=out, tile=tile)
+    e0.record()
+    for _ in range(20):
+        layer3([a, c], raw, flows=fl, out=out, tile=tile)
+    e1.record(); torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / 20
+    print("dcn x3 N=%d tile %d: %7.1f us  %5.1f TF fp32-equivalent (diff to the fp32 kernel %.1e)" % (N, tile, us, gf / us, diff), flush=True)
