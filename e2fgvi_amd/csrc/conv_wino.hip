@@ -552,7 +552,8 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             // (two stages per trip with compile-time buffer indices: `bw[st & 1]` would put the weight registers in scratch; an odd
             //  stage count runs one stage past the end -- zero weights, like the fp32 kernel's chunk overrun)
             // Measured and dropped (profiles/r03_x3_winograd_variants.txt): building the fragments of stage st + 1 under the MFMAs
-            // of stage st (one more fragment set, the same loads) ran 0-8 % slower; the LDS-DMA variant above 10-40 % slower.
+            // of stage st (one more fragment set, the same loads) ran 0-8 % slower, with the compiler's own instruction order and
+            // with an explicit one-MFMA-per-16-VALU interleave (sched_group_barrier) alike; the LDS-DMA variant above 10-40 % slower.
             auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
                 constexpr int CUR = decltype(CUR_)::value;
                 load_b3(st + 1, bw[CUR ^ 1]);
