@@ -553,7 +553,11 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             //  stage count runs one stage past the end -- zero weights, like the fp32 kernel's chunk overrun)
             // Measured and dropped (profiles/r03_x3_winograd_variants.txt): building the fragments of stage st + 1 under the MFMAs
             // of stage st (one more fragment set, the same loads) ran 0-8 % slower, with the compiler's own instruction order and
-            // with an explicit one-MFMA-per-16-VALU interleave (sched_group_barrier) alike; the LDS-DMA variant above 10-40 % slower.
+            // with an explicit one-MFMA-per-16-VALU interleave (sched_group_barrier) alike; the LDS-DMA variant above 10-40 % slower;
+            // weights fetched two stages ahead into a third buffer with the patch loads pinned (so that the compiler's vmcnt(0) in
+            // front of store_raw no longer drains the next stage's weights): 3-8 % slower; all eight waves on ONE role's code (an
+            // instruction-cache test, wrong results): identical time.  What bounds the ~1.1 us per 16-channel stage is none of:
+            // matrix pipe, phase serialisation inside a SIMD, weight / patch latency, instruction fetch.
             auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
                 constexpr int CUR = decltype(CUR_)::value;
                 load_b3(st + 1, bw[CUR ^ 1]);
