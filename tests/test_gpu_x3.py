@@ -297,8 +297,9 @@ def test_focal_attention_x3(dev, B, T, fh, fw):
     for waves in (0, 2, 4, 8):
         out = ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw, waves=waves)
         assert_close(out.cpu(), ref, ATT_TOL, "attention x3 %dx%d T=%d waves=%d" % (fh, fw, T, waves))
-        # two fp32-level results, each within ~1.5e-5 of the truth: their difference within twice that, growing with sqrt(keys)
-        assert_close(out, fp32, 4e-5 * max(1.0, (T * 210 / 840.0) ** 0.5), "attention x3 vs the fp32 kernel, waves=%d" % waves)
+        # two fp32-level results, each held to ATT_TOL against the oracle above: their difference to the same figure, growing
+        # with sqrt(keys) (measured over three data sets: <= 3.3e-5, profiles/r03_gpu_suite_soak_x3_summary.txt)
+        assert_close(out, fp32, ATT_TOL * max(1.0, (T * 210 / 840.0) ** 0.5), "attention x3 vs the fp32 kernel, waves=%d" % waves)
     first = ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw).clone()
     bad = sum(int(not torch.equal(ops.focal_attention_x3(q_d, planes, tab.to(dev), nk.to(dev), B, T, fh, fw), first)) for _ in range(30))
     assert bad == 0, "%d of 30 launches differ" % bad
