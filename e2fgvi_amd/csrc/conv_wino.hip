@@ -560,20 +560,29 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             // matrix pipe, phase serialisation inside a SIMD, weight / patch latency, instruction fetch.
             auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
                 constexpr int CUR = decltype(CUR_)::value;
+                E2T(const unsigned long long t_a = E2T_NOW();)
                 load_b3(st + 1, bw[CUR ^ 1]);
                 wait_vmcnt<6 * TN + SC * RAW_IT>();
                 claim3(bw[CUR]);
                 __builtin_amdgcn_sched_barrier(0);
+                E2T(const unsigned long long t_b = E2T_NOW(); tsum[0] += t_b - t_a;)
                 {
                     bf16x8 A[MT][6];
                     x3_prep(smem + CUR * STAGE_BYTES, A);
+                    // (timing build only: fragments complete before the first MFMA issues, so that the two segments separate)
+                    E2T(_Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) _Pragma("unroll") for (int f_ = 0; f_ < 6; ++f_) asm volatile("" : "+v"(A[m_][f_]));
+                        __builtin_amdgcn_sched_barrier(0); const unsigned long long t_c = E2T_NOW(); tsum[1] += t_c - t_b;)
                     x3_mma(A, bw[CUR]);
+                    E2T(__builtin_amdgcn_sched_barrier(0); tsum[2] += E2T_NOW() - t_c;)
                 }
+                E2T(const unsigned long long t_d = E2T_NOW();)
                 // the registers hold stage st + 1: park it in the other buffer (its readers passed the previous barrier)
                 store_raw(CUR ^ 1);
 #pragma unroll
                 for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
+                E2T(__builtin_amdgcn_sched_barrier(0); const unsigned long long t_e = E2T_NOW(); tsum[3] += t_e - t_d;)
                 __syncthreads();
+                E2T(tsum[4] += E2T_NOW() - t_e;)
             };
             for (int st = 0; st < nstages; st += 2) {
                 stage_body(IC<0>{}, st);

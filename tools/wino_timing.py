@@ -20,6 +20,18 @@ if "--variant" in sys.argv:
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     print("built", out)
     sys.exit(0)
+X3 = "--x3" in sys.argv      # the split-operand build (conv_wino_x3.o): segments = weights wait / fragments (LDS reads + transform +
+#                              split) / MFMA issue / park + next patch loads / stage barrier
+if X3:
+    SO = os.path.join(ROOT, "tools", "probe", "libe2fgvi_timing_x3.so")
+if "--build" in sys.argv and X3:
+    B.build()
+    obj = os.path.join(ROOT, "tools", "probe", "conv_wino_x3_timing.o")
+    subprocess.check_call([B._hipcc()] + B.FLAGS + B.NOPK + ["-DE2_WINO_X3=1", "-DE2_WINO_TIMING", "-c", os.path.join(B.CSRC, "conv_wino.hip"), "-o", obj])
+    objs = [obj if o == "conv_wino_x3.o" else os.path.join(B.CSRC, "build", o) for _, o, _ in B.UNITS]
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+    print("built", SO)
+    sys.exit(0)
 if "--build" in sys.argv:
     B.build()
     obj = os.path.join(ROOT, "tools", "probe", "conv_wino_timing.o")
@@ -40,6 +52,12 @@ CASES = [("encoder.10 <2,64>", 10, [128, 192], 2, 512, 64), ("encoder.10 <1,32>"
          ("encoder.8 <2,64>", 10, [256], 1, 384, 64), ("prop 128->128 x1 <1,32>", 1, [128], 1, 128, 132),
          ("prop 128->128 x10 <1,32>", 10, [128], 1, 128, 132)]
 NAMES = ["weights wait", "transform+MFMA issue", "park next stage (store_raw)", "issue stage after (load_raw)", "stage barrier"]
+if X3:
+    CASES = [("encoder.10 x3 <1,64>", 10, [128, 192], 2, 512, ops.W3_BASE + 164), ("encoder.10 x3 <1,32>", 10, [128, 192], 2, 512, ops.W3_BASE + 132),
+             ("prop 128->128 x1 x3 <1,32>", 1, [128], 1, 128, ops.W3_BASE + 132), ("prop 384->128 x1 x3 <1,32>", 1, [128, 128, 128], 1, 128, ops.W3_BASE + 132),
+             ("prop 128->128 x10 x3 <1,32>", 10, [128], 1, 128, ops.W3_BASE + 132)]
+    NAMES = ["issue next weights + wait for this stage's", "fragments: LDS reads + transform + split", "MFMA issue",
+             "park next patch + issue the loads after", "stage barrier"]
 for name, N, cpg, g, Cout, tile in CASES:
     srcs = [torch.randn(N, 60, 108, c * g, device=dev) for c in cpg]
     w = torch.randn(Cout, sum(cpg), 3, 3, device=dev) * 0.05
@@ -56,9 +74,10 @@ for name, N, cpg, g, Cout, tile in CASES:
     nst = t[0, 0, 7]
     chunks = 2 * nst
     kl, ep = t[..., 5].mean(), t[..., 6].mean()
-    mt = 2 if tile < 100 else 1
-    tn = (tile % 100) // 32
-    mfma_wave = chunks * 8 * mt * tn * 64            # cycles of this wave's own MFMAs
+    shape = tile % 1000 if X3 else tile
+    mt = 2 if shape < 100 else 1
+    tn = (shape % 100) // 32
+    mfma_wave = (nst * 12 * mt * tn * 32) if X3 else chunks * 8 * mt * tn * 64            # cycles of this wave's own MFMAs
     print("%-26s %7.1f us (instrumented)  K loop %8.0f cyc / wave, epilogue %6.0f; %d chunks; own MFMA cycles %8.0f (x2 waves per SIMD = %.0f %% of the K loop)"
           % (name, 1e3 * e0.elapsed_time(e1), kl, ep, chunks, mfma_wave, 200 * mfma_wave / kl))
     for k in range(5):
