@@ -301,7 +301,11 @@ def main():
                              "peak on Winograd layers.  fp32 layers that run on the bf16 matrix pipe with exactly split operands "
                              "(six bf16 MFMA terms per fp32 product, fp32-level rounding: tests/test_gpu_x3.py) are counted in "
                              "fp32-MFMA equivalents (bf16 MACs x 157.3 / 2500), so `frac` stays the share of the time the "
-                             "matrix pipe is busy at its peak rate"},
+                             "matrix pipe is busy at its peak rate (what rocprofv3's SQ_VALU_MFMA_BUSY_CYCLES measures).  Round 2's "
+                             "0.57 was that share on fp32 MFMA instructions only; with most layers issued as 6 bf16 MFMAs of 32 "
+                             "cycles per 16 k instead of 8 fp32 MFMAs of 64, the same work occupies the pipe for 0.375 of the time "
+                             "and the forward is bound by VALU / LDS-fill / launch latency instead (DESIGN.md section 6): `frac` "
+                             "falls while frames/s rise; `frac_algorithmic` is the reference's FLOPs against the fp32 MFMA peak"},
     }
     # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the
     # summary of the last collection is committed under profiles/ and quoted here (bytes per forward of one clip)
