@@ -89,3 +89,65 @@ def test_softcomp_fold_is_nine_phase_convolutions_of_the_token_grid():
             xp = F.pad(x, (pad_x, kw - 1 - pad_x, pad_y, kh - 1 - pad_y))
             out[:, :, py::3, px::3] += F.conv2d(xp, wp)
     assert torch.allclose(out, ref, rtol=0, atol=1e-11)
+
+
+def _split3(x):
+    """the kernels' split (conv_bf16x.hip::split8, mdcn.hip, attention_x3.hip, conv_wino.hip): hi = x with its low 16 bits
+    cleared, mid = the same of the exact remainder, lo = the rest; returned as fp64 values of the three bf16 numbers"""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float32)
+    hi = (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    r = (x - hi).astype(np.float32)
+    mid = (r.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    r2 = (r - mid).astype(np.float32)
+    lo = (r2.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    return hi.astype(np.float64), mid.astype(np.float64), lo.astype(np.float64), r, r2
+
+
+def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level():
+    """the arithmetic behind the split-operand ("x3") kernels, on the CPU: (1) hi + mid + lo == x bit for bit and every piece is
+    a bf16 number (16 low bits zero), for random, tiny, huge, negative and few-bit values -- both remainders are exact fp32
+    differences and the last one has at most 8 significant bits; (2) the six partial products the kernels issue differ from
+    the exact product by less than 2^-21 |ab| (the three dropped ones: mid*lo, lo*mid, lo*lo), i.e. below one fp32 rounding
+    of the product; (3) a K = 512 dot product accumulated in fp32 from those six terms is as close to the fp64 result as the
+    plain fp32 dot product is"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    # (values below 2^-110: the last piece becomes an fp32 denormal and loses bits -- an absolute error < 2^-133, checked apart)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32), (rng.standard_normal(2000) * 1e-25).astype(np.float32),
+                        (rng.standard_normal(2000) * 1e30).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.0, 1 + 2.0 ** -23, -(1 + 2.0 ** -16), 65504.0, 2.0 ** -126, 2.0 ** -120,
+                                  1 - 2.0 ** -24, 255.0, 256.5], dtype=np.float32)])
+    hi, mid, lo, r, r2 = _split3(x)
+    assert np.array_equal(hi + mid + lo, x.astype(np.float64)), "the three pieces do not sum to the value"
+    assert np.array_equal(r.astype(np.float64), x.astype(np.float64) - hi) and np.array_equal(r2.astype(np.float64), r.astype(np.float64) - mid), \
+        "a remainder was rounded"
+    assert np.array_equal(lo, r2.astype(np.float64)), "the last remainder does not fit a bf16 number"
+    for piece in (hi, mid, lo):
+        assert not (piece.astype(np.float32).view(np.uint32) & np.uint32(0xFFFF)).any()
+    tiny = (rng.standard_normal(5000) * 1e-36).astype(np.float32)
+    th, tm, tl, _, _ = _split3(tiny)
+    assert np.max(np.abs(th + tm + tl - tiny.astype(np.float64))) < 2.0 ** -133
+    a = rng.standard_normal(100000).astype(np.float32)
+    b = rng.standard_normal(100000).astype(np.float32)
+    ah, am, al, _, _ = _split3(a)
+    bh, bm, bl, _, _ = _split3(b)
+    six = al * bh + ah * bl + am * bm + am * bh + ah * bm + ah * bh            # exact in fp64: each term has <= 16 significant bits
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    assert np.max(np.abs(six - exact) / np.abs(exact)) < 2.0 ** -21
+    # a dot product: fp32 accumulation of the six-term products against a plain fp32 dot product, both against fp64
+    K, n = 512, 2000
+    A = rng.standard_normal((n, K)).astype(np.float32)
+    B = rng.standard_normal((K,)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    plain = np.zeros(n, np.float32)
+    split = np.zeros(n, np.float32)
+    Ah, Am, Al, _, _ = _split3(A)
+    Bh, Bm, Bl, _, _ = _split3(B)
+    for k in range(K):
+        plain = (plain + A[:, k] * B[k]).astype(np.float32)
+        for t in (Al[:, k] * Bh[k], Ah[:, k] * Bl[k], Am[:, k] * Bm[k], Am[:, k] * Bh[k], Ah[:, k] * Bm[k], Ah[:, k] * Bh[k]):
+            split = (split + t.astype(np.float32)).astype(np.float32)         # each term is exact in fp32
+    rms = np.sqrt(np.mean(ref ** 2))
+    e_plain, e_split = np.max(np.abs(plain - ref)) / rms, np.max(np.abs(split - ref)) / rms
+    assert e_split < 8 * np.sqrt(K) * 2.0 ** -24 and e_split < 3 * e_plain + 1e-7, (e_plain, e_split)
