@@ -150,4 +150,6 @@ def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level():
             split = (split + t.astype(np.float32)).astype(np.float32)         # each term is exact in fp32
     rms = np.sqrt(np.mean(ref ** 2))
     e_plain, e_split = np.max(np.abs(plain - ref)) / rms, np.max(np.abs(split - ref)) / rms
-    assert e_split < 8 * np.sqrt(K) * 2.0 ** -24 and e_split < 3 * e_plain + 1e-7, (e_plain, e_split)
+    # (one fp32 rounding per TERM here -- six per product, the worst case; the MFMA rounds once per 16-product instruction and
+    #  measures at or below the plain fp32 kernel on the GPU, tests/test_gpu_x3.py)
+    assert e_split < 8 * np.sqrt(K) * 2.0 ** -24 and e_split < 4 * e_plain + 1e-7, (e_plain, e_split)
