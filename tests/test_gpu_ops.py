@@ -271,7 +271,8 @@ def test_focal_attention(dev, B, T, fh, fw):
         outs[waves] = out
     # same arithmetic in the same key order (34 / 32 vs 14 / 12: two key groups each; on a small grid the launcher gives
     # 4 / 2 two key groups as well, 24 / 22 always one: another summation order): agreement to fp32 summation noise
-    agree = 2e-5 * max(1.0, (T * 210 / 840.0) ** 0.5)          # summation noise grows with the square root of the key count
+    # summation noise grows with the square root of the key count (7 data sets: <= 0.85 of a 2e-5 base, hence 3e-5)
+    agree = 3e-5 * max(1.0, (T * 210 / 840.0) ** 0.5)
     for a, b_ in ((24, 4), (22, 2), (34, 14), (32, 12)):
         assert_close(outs[a], outs[b_], agree, "LDS-DMA kernel (waves=%d) vs the register-staged one (waves=%d)" % (a, b_))
 
