@@ -89,8 +89,14 @@ __global__ void split3_kv_kernel(const float* __restrict__ src, unsigned short* 
     *reinterpret_cast<bf16x8*>(o + 2 * plane) = lo;
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* __restrict__ qkv, const int* __restrict__ key_tab,
+// KS = 2: two key groups of NW waves per workgroup.  Group kg walks the tiles kg, kg + 2, ... with its own LDS ring and the
+// SAME queries; the partial results are merged at the end (flash-decoding inside a workgroup).  At the 432x240 shape there are
+// only ~900 blocks of 32 queries for 1024 SIMDs: with one key group every SIMD holds ONE wave whose MFMA, softmax and LDS
+// phases cannot overlap; two groups put two waves of half the length on a SIMD.  A ring is then K double-buffered + V
+// single-buffered (72 KB; two rings fit the LDS): K(t + 1) is issued at the top of tile t, V(t + 1) after tile t's PV products
+// (two barriers per tile).
+template <int NW, int KS>
+__global__ __launch_bounds__(64 * NW * KS, 1) void focal_attn_x3_kernel(const float* __restrict__ qkv, const int* __restrict__ key_tab,
                                                                   int tab_ld, const int* __restrict__ nkeys,
                                                                   float* __restrict__ out, int B, int T, int fh, int fw,
                                                                   const char* planes, unsigned planes_bytes, unsigned plane_stride,
@@ -100,11 +106,13 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
     constexpr int PIECES = 8 / NW;                 // 1-KiB DMA pieces of one plane of a K (and of a V) tile per wave
     constexpr unsigned OOB = 0xFFFFF000u;          // a key row past the end: out of range in every plane (launcher: 3 planes < 0xFFFFF000)
     static_assert(NW == 2 || NW == 4 || NW == 8, "waves per workgroup");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * X_STAGE];
+    constexpr int RING = KS == 1 ? 2 * X_STAGE : 9 * X_KB;          // KS = 2: K stage 0, K stage 1, V (three planes each)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[KS * RING];
     __shared__ int stab[256];
     extern __shared__ __attribute__((aligned(16))) unsigned ktab[];       // byte offset of every key row in plane 0, OOB past the end
 
-    const int tid = threadIdx.x;
+    const int kg = (KS == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x / NT));
+    const int tid = threadIdx.x - kg * NT;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int nWw = fw / WS1, nWh = fh / WS0, nWin = nWh * nWw;
@@ -122,14 +130,15 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
     const int nv = nkeys[win];
     const int NK = T * nv;
     const int ntiles = (NK + TK - 1) / TK;
+    const int nIter = (ntiles + KS - 1) / KS;       // tiles per key group (the last group may get an all-masked one)
     const int* tab = key_tab + (long long)win * tab_ld;
-    for (int e = tid; e < nv && e < 256; e += NT) stab[e] = tab[e];
+    for (int e = threadIdx.x; e < nv && e < 256; e += KS * NT) stab[e] = tab[e];
     __syncthreads();
-    {   // the key-row table: entry k = (frame t = k / nv, slot s = k % nv), walked without divisions
-        int t = 0, sl = tid;
+    {   // the key-row table: entry k = (frame t = k / nv, slot s = k % nv), walked without divisions; KS * nIter tiles
+        int t = 0, sl = threadIdx.x;
         while (sl >= nv) { sl -= nv; ++t; }
         const unsigned head_off = (unsigned)(head * HD * 2);
-        for (int k = tid; k < ntiles * TK; k += NT) {
+        for (int k = threadIdx.x; k < KS * nIter * TK; k += KS * NT) {
             unsigned e = OOB;
             if (k < NK) {
                 const int ref = stab[sl];
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
                 e = rowi * (unsigned)(CP * 2) + head_off;
             }
             ktab[k] = e;
-            sl += NT;
+            sl += KS * NT;
             while (sl >= nv) { sl -= nv; ++t; }
         }
     }
@@ -190,7 +199,22 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
         d_kb[jp] = (unsigned)((slot ^ (row & 15)) * 16);
         d_vb[jp] = 1024u + (unsigned)(((((slot >> 2) ^ (row & 3)) << 2) | (slot & 3)) * 16);     // V sits 512 bf16 behind K
     }
-    const unsigned smem_lds = (unsigned)(unsigned long long)(x_lds_void*)smem;
+    const unsigned smem_lds = (unsigned)(unsigned long long)(x_lds_void*)smem + (unsigned)(kg * RING);
+    // KS = 2: the K planes of tile kt into K stage `kb`, or its V planes into the ring's V area
+    auto issue_half = [&](int kt, unsigned lds_off, bool v_half) {
+        const unsigned sk = smem_lds + lds_off + (unsigned)(wave * 1024);
+        unsigned e[PIECES];
+#pragma unroll
+        for (int jp = 0; jp < PIECES; ++jp) e[jp] = ktab[kt * TK + d_row[jp]];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int jp = 0; jp < PIECES; ++jp) {
+                const unsigned base = e[jp] == OOB ? OOB : e[jp] + (unsigned)pl * plane_stride;
+                x_dma16(rsrc, __builtin_amdgcn_readfirstlane(sk + (unsigned)(pl * X_KB + jp * NW * 1024)),
+                        base == OOB ? OOB : base + (v_half ? d_vb[jp] : d_kb[jp]));
+            }
+    };
     auto issue_tile = [&](int kt, int stage) {
         const unsigned sk = smem_lds + (unsigned)(stage * X_STAGE + wave * 1024);
         unsigned e[PIECES];
@@ -217,18 +241,8 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) { asm volatile("" : "+v"(qh[kk])); asm volatile("" : "+v"(qm[kk])); asm volatile("" : "+v"(ql[kk])); }
 
-    issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const unsigned char* cK = smem + cur * X_STAGE;
-        const unsigned char* cV = cK + 3 * X_KB;
-        if (kt + 1 < ntiles) issue_tile(kt + 1, cur ^ 1);       // lands under this tile's products
-
-        if (wave_active) {
-            f32x16 s;
+    f32x16 s;                                      // S^T of the current tile, then its softmax numerators
+    auto s_phase = [&](const unsigned char* cK, int kt) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qm[kk], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[kk], s, 0, 0, 0);
             }
-            if (kt == ntiles - 1) {                             // rows past the last key: out of the softmax
+            if ((kt + 1) * TK > NK) {                           // rows past the last key: out of the softmax
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int krow = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -275,6 +289,8 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
             }
+    };
+    auto pv_phase = [&](const unsigned char* cV) __attribute__((always_inline)) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 ph, pm, pl;
@@ -300,10 +316,69 @@ __global__ __launch_bounds__(64 * NW, 1) void focal_attn_x3_kernel(const float* 
                     acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], ph, acc[dt], 0, 0, 0);
                 }
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt + 1 have landed
+    };
+    if constexpr (KS == 1) {
+        issue_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const unsigned char* cK = smem + cur * X_STAGE;
+            if (kt + 1 < ntiles) issue_tile(kt + 1, cur ^ 1);       // lands under this tile's products
+            if (wave_active) {
+                s_phase(cK, kt);
+                pv_phase(cK + 3 * X_KB);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt + 1 have landed
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // ring of this group: K stage 0 | K stage 1 | V   (3 planes of 8 KB each)
+        const unsigned char* const ring = smem + kg * RING;
+        issue_half(kg, 0u, false);
+        issue_half(kg, 6u * X_KB, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int itr = 0; itr < nIter; ++itr) {
+            const int kt = kg + itr * KS;                             // may be == ntiles for the last group: an all-masked tile
+            const bool more = itr + 1 < nIter;
+            if (more) issue_half(kt + KS, (unsigned)((cur ^ 1) * 3 * X_KB), false);       // K of the next tile: lands under this tile
+            if (wave_active) s_phase(ring + cur * 3 * X_KB, kt);
+            // this tile's V planes were issued BEFORE the K planes above (loads return in order): all but those may be pending
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                          // ... everybody's pieces of V
+            if (wave_active) pv_phase(ring + 6 * X_KB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the next K
+            __syncthreads();                                          // V and K[cur] are free, K[cur ^ 1] is complete
+            if (more) issue_half(kt + KS, 6u * X_KB, true);           // V of the next tile: lands under its S products and softmax
+            cur ^= 1;
+        }
+        // merge the key groups: O = sum_g 2^(m_g - m) O_g, l likewise (attention.hip); group 1 parks its state in its own ring
+        float* scr = reinterpret_cast<float*>(smem + RING);
+        if (kg > 0) {
+            scr[tid] = m_run;
+            scr[NT + tid] = l_run;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[(2 + dt * 16 + r) * NT + tid] = acc[dt][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+        {
+            const float m_o = scr[tid], l_o = scr[NT + tid];
+            const float m_new = fmaxf(m_run, m_o);
+            const float a0 = __builtin_amdgcn_exp2f(m_run - m_new), a1 = __builtin_amdgcn_exp2f(m_o - m_new);
+            l_run = l_run * a0 + l_o * a1;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[dt][r] = acc[dt][r] * a0 + scr[(2 + dt * 16 + r) * NT + tid] * a1;
+        }
     }
 
     if (wave_active) {
@@ -357,30 +432,42 @@ extern "C" int e2fgvi_focal_attention_x3(const float* qkv, const void* planes, c
     const long long rows = (long long)B * T * fh * fw + (long long)B * T * nWin;
     const long long plane_bytes = rows * CP * 2;
     E2_REQUIRE(3 * plane_bytes < 0xFFFFF000LL, E2FGVI_EUNSUP, "focal_attention_x3: the three k / v planes span >= 4 GiB (split the batch)");
-    const size_t dyn = (size_t)cdiv(T * SLOTS, TK) * TK * 4;
+    // waves: 0 (auto), 2 / 4 / 8 = waves of 32 queries per workgroup, one key group; 14 = four waves x TWO key groups
+    int ks = 1;
+    if (waves == 14) { ks = 2; waves = 4; }
+    const int ntiles = cdiv(T * SLOTS, TK);
+    size_t dyn = (size_t)ntiles * TK * 4;
+    const size_t dyn2 = (size_t)cdiv(ntiles, 2) * 2 * TK * 4;
+    const bool fits2 = dyn2 + 2 * 9 * X_KB + 1024 + 256 <= 160 * 1024;
     E2_REQUIRE(dyn + 2 * X_STAGE + 1024 + 256 <= 160 * 1024, E2FGVI_EUNSUP, "focal_attention_x3: window of %d frames does not fit the LDS key table", T);
     if (waves <= 0) {
-        // enough workgroups for the chip first, then as many queries per staged K / V tile as possible
+        // enough workgroups for the chip first, then as many queries per staged K / V tile as possible; when there are not even
+        // two 32-query blocks per SIMD (the 432x240 clip: 900 for 1024), two key groups per workgroup
         const long long wg4 = (long long)cdiv(T * WTOK, 128) * nWin * NH * B;
+        const long long qblocks = (long long)cdiv(T * WTOK, 32) * nWin * NH * B;
         waves = wg4 >= 512 ? 8 : 4;
-        if ((long long)cdiv(T * WTOK, 128) * nWin * NH * B < 192) waves = 2;
+        if (wg4 < 192) waves = 2;
+        if (waves == 4 && qblocks < 2048 && fits2) ks = 2;
     }
-    E2_REQUIRE(waves == 2 || waves == 4 || waves == 8, E2FGVI_EINVAL, "focal_attention_x3: waves must be 0, 2, 4 or 8");
+    E2_REQUIRE(waves == 2 || waves == 4 || waves == 8, E2FGVI_EINVAL, "focal_attention_x3: waves must be 0, 2, 4, 8 or 14");
+    E2_REQUIRE(ks == 1 || fits2, E2FGVI_EUNSUP, "focal_attention_x3: two key groups do not fit the LDS for a window of %d frames", T);
+    if (ks == 2) dyn = dyn2;
     const long long nblk = (long long)cdiv(T * WTOK, 32 * waves) * nWin * NH * B;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "focal_attention_x3: more than 2^31 workgroups");
-    dim3 grid((unsigned)nblk), block(64 * waves);
-#define E2_ATT_X3(NW_)                                                                                                            \
+    dim3 grid((unsigned)nblk), block(64 * waves * ks);
+#define E2_ATT_X3(NW_, KS_)                                                                                                       \
     do {                                                                                                                          \
-        hipError_t ea = hipFuncSetAttribute((const void*)focal_attn_x3_kernel<NW_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+        hipError_t ea = hipFuncSetAttribute((const void*)focal_attn_x3_kernel<NW_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                             (int)dyn);                                                                            \
         E2_REQUIRE(ea == hipSuccess, (int)ea, "focal_attention_x3: cannot reserve %zu bytes of dynamic LDS", dyn);                \
-        hipLaunchKernelGGL((focal_attn_x3_kernel<NW_>), grid, block, dyn, (hipStream_t)stream, qkv, key_tab, tab_ld, nkeys, out, \
+        hipLaunchKernelGGL((focal_attn_x3_kernel<NW_, KS_>), grid, block, dyn, (hipStream_t)stream, qkv, key_tab, tab_ld, nkeys, out, \
                            B, T, fh, fw, (const char*)planes, (unsigned)(3 * plane_bytes), (unsigned)plane_bytes,                 \
                            (unsigned)((long long)B * T * fh * fw));                                                               \
     } while (0)
-    if (waves == 2) E2_ATT_X3(2);
-    else if (waves == 4) E2_ATT_X3(4);
-    else E2_ATT_X3(8);
+    if (ks == 2) E2_ATT_X3(4, 2);
+    else if (waves == 2) E2_ATT_X3(2, 1);
+    else if (waves == 4) E2_ATT_X3(4, 1);
+    else E2_ATT_X3(8, 1);
 #undef E2_ATT_X3
     E2_LAUNCH_CHECK("focal_attention_x3");
     return 0;

@@ -42,7 +42,7 @@ print("attention fp32 %dx%d T=%d: fp32 MFMA kernel %8.1f us  %6.1f TF/s (valid-k
 planes = torch.empty(3, both.shape[0], 1024, dtype=torch.bfloat16, device=dev)
 us_s = timed(lambda: ops.split3_kv(both, out=planes))
 print("  split3_kv of %d rows: %6.1f us (%.0f MB read + written)" % (both.shape[0], us_s, both.shape[0] * 1024 * 10e-6))
-for w in (2, 4, 8):
+for w in (0, 2, 4, 8, 14):
     o = ops.focal_attention_x3(qkv, planes, tab, nk, B, T, fh, fw, waves=w)
     d = (o - ref).abs().max().item() / ref.pow(2).mean().sqrt().item()
     us = timed(lambda: ops.focal_attention_x3(qkv, planes, tab, nk, B, T, fh, fw, out=out, waves=w))
