@@ -418,7 +418,7 @@ extern "C" int e2fgvi_split3_kv(const float* qkv_rows, void* planes, int64_t row
 
 /* e2fgvi_focal_attention with both products on the bf16 matrix pipe (six exact bf16 terms per fp32 product).  qkv: the fp32
  * token rows [B*T*fh*fw][1536] (read for Q only); planes: e2fgvi_split3_kv of those rows FOLLOWED by the B*T*nWin pooled rows;
- * out fp32 [rows][512].  waves: 0 (auto), 2, 4 or 8 waves of 32 queries per workgroup. */
+ * out fp32 [rows][512].  waves: 0 (auto), 2, 4 or 8 waves of 32 queries per workgroup; 14 = four waves x two key groups. */
 extern "C" int e2fgvi_focal_attention_x3(const float* qkv, const void* planes, const int32_t* key_tab, int32_t tab_ld,
                                          const int32_t* nkeys, float* out, int32_t B, int32_t T, int32_t fh, int32_t fw,
                                          int32_t waves, void* stream) {

@@ -400,7 +400,8 @@ int e2fgvi_pack_conv_weight_f32x3_taps(const float* w, void* wpacked, int32_t Co
  * products on the bf16 matrix pipe as six exact bf16 terms of three-way split operands (csrc/attention_x3.hip).
  * e2fgvi_split3_kv: the k / v columns (512 .. 1535) of `rows` consecutive fp32 qkv rows -- the B*T*fh*fw token rows FOLLOWED by
  * the B*T*nWin pooled rows -- as three bf16 planes planes[3][rows][1024] whose sum is the fp32 value bit for bit.
- * e2fgvi_focal_attention_x3: qkv = the token rows (read for Q), planes = that buffer; waves: 0 (auto), 2, 4, 8. */
+ * e2fgvi_focal_attention_x3: qkv = the token rows (read for Q), planes = that buffer; waves: 0 (auto), 2, 4, 8 = waves of 32
+ * queries per workgroup, 14 = four waves x two key groups (small grids: fewer than two query blocks per SIMD). */
 int e2fgvi_split3_kv(const float* qkv_rows, void* planes, int64_t rows, void* stream);
 int e2fgvi_focal_attention_x3(const float* qkv, const void* planes, const int32_t* key_tab, int32_t tab_ld, const int32_t* nkeys,
                               float* out, int32_t B, int32_t T, int32_t fh, int32_t fw, int32_t waves, void* stream);
