@@ -796,6 +796,288 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
 #endif
 }
 
+#if E2_WINO_X3
+
+// ---- split-operand Winograd, FOUR transform positions per wave (round 3, late).  The eight-wave kernel above is bound by the
+// LDS reads of its fragment phase (12 ds_read_b128 per lane and stage: every patch element is read by six of the eight waves)
+// and runs one workgroup per CU (156+ registers), so nothing overlaps its weight waits, parks and barriers.  Here a wave owns
+// one patch-row pair (xi = wave) and all four column combinations: 16 reads (2 rows x 4 columns x 2 channel quads) feed four
+// positions instead of 12 feeding two -- a third less LDS traffic per MFMA -- and a workgroup is four waves (256 threads) of
+// one 8x16-pixel block x BN couts, two of which fit a CU with independent barriers.  The weights of a stage are
+// single-buffered: issued right after the MFMAs that read them (the loads return long after an issued MFMA has read its
+// operands), waited for at the top of the next stage -- the other resident workgroup covers that latency.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams p) {
+    constexpr int NT = 256, MT = 1, SC = 2;
+    constexpr int TN = BN / 32;
+    constexpr int RAW_H = 8 * MT + 2;
+    constexpr int PLANE_RAW = RAW_H * PLANE_ROW * 16;
+    constexpr int PLANE_BYTES = PLANE_RAW + ((16 - PLANE_RAW % 128) + 128) % 128;
+    constexpr int CHUNK_BYTES = 4 * PLANE_BYTES;
+    constexpr int STAGE_BYTES = SC * CHUNK_BYTES;
+    constexpr int TILES = 32 * MT;
+    constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
+    constexpr int SMEM = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int RAW_ITEMS = RAW_H * RAW_W * 2;
+    constexpr int RAW_IT = (RAW_ITEMS + NT - 1) / NT;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y;
+    const int logical = xcd_remap(blockIdx.x, p.nblk);
+    const int mblocks = p.N * p.blocksY * p.blocksX;
+    const int tile_n = logical / mblocks;
+    int rem = logical - tile_n * mblocks;
+    const int img = rem / (p.blocksY * p.blocksX);
+    rem -= img * (p.blocksY * p.blocksX);
+    const int by = rem / p.blocksX, bx = rem - by * p.blocksX;
+    const int n0 = tile_n * BN;
+    const int y0 = by * (8 * MT) - 1, x0 = bx * 16 - 1;
+
+    unsigned raw_off[RAW_IT];
+    int raw_dst[RAW_IT];
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int item = tid + it * NT;
+        const int kq = item & 1, px = item >> 1;
+        const int py = px / RAW_W, pxx = px - py * RAW_W;
+        const int gy = y0 + py, gx = x0 + pxx;
+        const bool have = item < RAW_ITEMS;
+        const bool in = have && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        raw_off[it] = in ? (unsigned)((img * p.H + gy) * p.W + gx) : OOB;
+        raw_dst[it] = have ? (kq * 2 + (pxx & 1)) * PLANE_BYTES + (py * PLANE_ROW + (pxx >> 1)) * 16 : -1;
+    }
+    const unsigned raw_kq16 = (unsigned)(tid & 1) * 16u;
+
+    int s = 0, c0 = 0;
+    const float* cur_src = p.src[0];
+    unsigned cur_bytes = p.src_bytes[0];
+    unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
+    unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int cur_cpg = p.cpg[0];
+    f32x4 rraw[SC][RAW_IT];
+    auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
+        const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
+        const unsigned chan = cur_chan + (unsigned)c0 * 4u + raw_kq16;
+        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;
+#pragma unroll
+        for (int it = 0; it < RAW_IT; ++it) {
+            unsigned off = (cvalid && raw_off[it] != OOB) ? raw_off[it] * cur_ld4 + chan : OOB;
+            asm volatile("" : "+v"(off));
+            q[it] = buf_load4(arsrc, off);
+        }
+        c0 += 8;
+        if (c0 >= cur_cpg) {
+            c0 = 0;
+            ++s;
+            if (s == p.nsrc) s = 0;
+            if (p.nsrc > 1) {
+                cur_src = p.src[s]; cur_bytes = p.src_bytes[s]; cur_ld4 = (unsigned)p.ld[s] * 4u;
+                cur_chan = (unsigned)(p.coff[s] + g * p.cpg[s]) * 4u; cur_cpg = p.cpg[s];
+            }
+        }
+    };
+    auto store_raw = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < SC; ++q)
+#pragma unroll
+            for (int it = 0; it < RAW_IT; ++it)
+                if (raw_dst[it] >= 0) *reinterpret_cast<f32x4*>(base + q * CHUNK_BYTES + raw_dst[it]) = rraw[q][it];
+    };
+
+    // this wave's patch rows: B^T rows  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3
+    const int xi = wave;
+    const int ra0 = (xi == 0) ? 0 : 1, ra1 = (xi == 3) ? 3 : 2;
+    const int i = lane & 31, h = lane >> 5;
+    const int ty = i >> 3, tx = i & 7;
+    int a_off[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int prow = 2 * ty + (r ? ra1 : ra0);
+            a_off[r][j] = h * CHUNK_BYTES + (j & 1) * PLANE_BYTES + (prow * PLANE_ROW + tx + (j >> 1)) * 16;
+        }
+    const i32x4 wrsrc = rsrc_words(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes, p.wgroup_bytes);
+    const unsigned u_step = 96u * (unsigned)p.Npad * 16u;
+    const unsigned u_plane = 2u * (unsigned)p.Npad * 16u;
+    unsigned u_off[4][TN];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + n * 32 + i;
+            u_off[a][n] = col < p.Npad ? (unsigned)((((4 * wave + a) * 6 + h) * p.Npad + col) * 16) : 0x80000000u;
+        }
+    f32x4 bw[4][TN][3];
+    auto load_b3 = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    buf_load4_pinned(bw[a][n][pl], wrsrc, u_off[a][n] + (unsigned)pl * u_plane + (unsigned)st * u_step);
+    };
+    f32x16 acc[4][TN];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
+
+    const int nstages = (p.nchunks + SC - 1) / SC;
+    // prologue: stage 0 into LDS buffer 0, stage 1 into the staging registers, stage 0's weights issued LAST (the first trip
+    // waits for them with vmcnt(0))
+#pragma unroll
+    for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
+    store_raw(0);
+#pragma unroll
+    for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
+    load_b3(0);
+    __syncthreads();
+
+    auto k_loop = [&](auto XI_) __attribute__((always_inline)) {
+        constexpr int XI = decltype(XI_)::value;
+        for (int st = 0; st < nstages; ++st) {
+            const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
+            // this stage's weights were the last vector loads issued before the barrier: wait for everything in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[a][n][pl]));
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 e[2][4];
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(stage + kq * (2 * PLANE_BYTES) + a_off[0][j]);
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(stage + kq * (2 * PLANE_BYTES) + a_off[1][j]);
+                    e[kq][j] = XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
+                }
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                bf16x8 ah, am, al;
+                {
+                    const f32x4 v0 = nu == 0 ? e[0][0] - e[0][2] : nu == 1 ? e[0][1] + e[0][2] : nu == 2 ? e[0][2] - e[0][1] : e[0][1] - e[0][3];
+                    const f32x4 v1 = nu == 0 ? e[1][0] - e[1][2] : nu == 1 ? e[1][1] + e[1][2] : nu == 2 ? e[1][2] - e[1][1] : e[1][1] - e[1][3];
+                    wino_split8(v0, v1, ah, am, al);
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const bf16x8 uh = __builtin_bit_cast(bf16x8, bw[nu][n][0]), um = __builtin_bit_cast(bf16x8, bw[nu][n][1]),
+                                 ul = __builtin_bit_cast(bf16x8, bw[nu][n][2]);
+                    acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, uh, acc[nu][n], 0, 0, 0);
+                    acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ul, acc[nu][n], 0, 0, 0);
+                    acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, um, acc[nu][n], 0, 0, 0);
+                    acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, uh, acc[nu][n], 0, 0, 0);
+                    acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, um, acc[nu][n], 0, 0, 0);
+                    acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, uh, acc[nu][n], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // park stage st + 1 (the compiler waits for its loads: the newest ones, issued a stage ago), fetch stage st + 2, then
+            // the next stage's weights into the registers the MFMAs above have read
+            store_raw((st & 1) ^ 1);
+#pragma unroll
+            for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
+            load_b3(st + 1);
+            __syncthreads();
+        }
+    };
+    switch (wave) {          // wave-uniform
+        case 0: k_loop(IC<0>{}); break;
+        case 1: k_loop(IC<1>{}); break;
+        case 2: k_loop(IC<2>{}); break;
+        default: k_loop(IC<3>{}); break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weights of the stage past the end
+
+    // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
+    float* E = reinterpret_cast<float*>(smem);
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int nh = 0; nh < TN; ++nh) {
+        if (nh) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
+                E[((4 * wave + a) * TILES + tile) * 32 + i] = acc[a][nh][r];
+            }
+        __syncthreads();
+        // one (tile, 4 consecutive couts) item per thread: 16 ds_read_b128, A^T M A, 4 stores of 16 bytes
+        const int cq = tid & 7, tile = tid >> 3;
+        const int n = n0 + nh * 32 + cq * 4;
+        const int oy = by * (8 * MT) + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7);
+        // H and W are even: a tile is inside or outside the image as a whole
+        if (tile < TILES && n < p.Cout_g && oy < p.H && ox < p.W) {
+            f32x4 mm[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) mm[a] = *reinterpret_cast<const f32x4*>(E + (a * TILES + tile) * 32 + cq * 4);
+            // A^T = [1 1 1 0; 0 1 -1 -1]
+            f32x4 t0[4], t1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                t0[nu] = mm[0 * 4 + nu] + mm[1 * 4 + nu] + mm[2 * 4 + nu];
+                t1[nu] = mm[1 * 4 + nu] - mm[2 * 4 + nu] - mm[3 * 4 + nu];
+            }
+            f32x4 y[4];
+            y[0] = t0[0] + t0[1] + t0[2];
+            y[1] = t0[1] - t0[2] - t0[3];
+            y[2] = t1[0] + t1[1] + t1[2];
+            y[3] = t1[1] - t1[2] - t1[3];
+            const int co = g * p.Cout_g + n;
+            const long long pix0 = (long long)img * HW + (long long)oy * p.W + ox;
+            const int pstep[4] = {0, 1, p.W, p.W + 1};
+            const bool full = n + 3 < p.Cout_g;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bv[c] = (full || n + c < p.Cout_g) ? p.bias[co + c] : 0.f;
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const long long pix = pix0 + pstep[px];
+                f32x4 v = y[px] + bv;
+                if (p.act == E2FGVI_ACT_DCNPOST) {
+                    const f32x4 fl = *reinterpret_cast<const f32x4*>(p.res + pix * 4);
+                    const float flv[4] = {fl[0], fl[1], fl[2], fl[3]};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = wino_dcn_post(v[c], co + c, p.Cout, flv, p.slope);
+                } else {
+                    if (p.res) {
+                        const float* r = p.res + pix * p.res_ld + p.res_coff + co;
+                        if (p.vec_store && full) v = v + *reinterpret_cast<const f32x4*>(r);
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (full || n + c < p.Cout_g) v[c] += r[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+                }
+                float* o = p.dst + pix * p.dst_ld + p.dst_coff + co;
+                if (p.vec_store && full) *reinterpret_cast<f32x4*>(o) = v;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (full || n + c < p.Cout_g) o[c] = v[c];
+                }
+            }
+        }
+    }
+}
+#endif
+
 struct WinoPack {
     int Cout, groups, nsrc;
     int cpg[E2FGVI_MAX_SRC];
@@ -962,6 +1244,21 @@ static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     return 0;
 }
 
+#if E2_WINO_X3
+template <int BN>
+static int launch_wino_p4(WinoParams& p, int groups, hipStream_t st) {
+    p.blocksY = cdiv(p.H, 8);
+    p.blocksX = cdiv(p.W, 16);
+    p.tilesN = cdiv(p.Cout_g, BN);
+    const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
+    E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd_x3: grid too large");
+    p.nblk = (int)nblk;
+    hipLaunchKernelGGL((conv_wino_x3p4_kernel<BN>), dim3(p.nblk, groups, 1), dim3(256), 0, st, p);
+    E2_LAUNCH_CHECK("conv3x3_winograd_x3 (four positions per wave)");
+    return 0;
+}
+#endif
+
 static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv3x3_winograd: null descriptor");
     WinoPack q;
@@ -1025,6 +1322,8 @@ static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
         case 32: return launch_wino<2, 32, 2, false, true>(p, d->groups, st);
         case 164: return launch_wino<1, 64, 2, false, true>(p, d->groups, st);
         case 132: return launch_wino<1, 32, 2, false, true>(p, d->groups, st);
+        // + 5000: four positions per wave, four-wave workgroups (two per CU)
+        case 5132: return launch_wino_p4<32>(p, d->groups, st);
         // + 1000: patch by LDS-DMA, patch and weights fetched two stages ahead (32-cout shapes: three weight buffers fit)
         case 1032: return launch_wino<2, 32, 2, true, true>(p, d->groups, st);
         case 1132: return launch_wino<1, 32, 2, true, true>(p, d->groups, st);
