@@ -803,9 +803,8 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
 // and runs one workgroup per CU (156+ registers), so nothing overlaps its weight waits, parks and barriers.  Here a wave owns
 // one patch-row pair (xi = wave) and all four column combinations: 16 reads (2 rows x 4 columns x 2 channel quads) feed four
 // positions instead of 12 feeding two -- a third less LDS traffic per MFMA -- and a workgroup is four waves (256 threads) of
-// one 8x16-pixel block x BN couts, two of which fit a CU with independent barriers.  The weights of a stage are
-// single-buffered: issued right after the MFMAs that read them (the loads return long after an issued MFMA has read its
-// operands), waited for at the top of the next stage -- the other resident workgroup covers that latency.
+// one 8x16-pixel block x BN couts, two of which fit a CU with independent barriers.  Weights double-buffered in registers,
+// issued a stage ahead, as in the eight-wave kernel (explicit vmcnt, re-counted by build.verify_wino_waits).
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams p) {
     constexpr int NT = 256, MT = 1, SC = 2;
@@ -912,15 +911,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
             const int col = n0 + n * 32 + i;
             u_off[a][n] = col < p.Npad ? (unsigned)((((4 * wave + a) * 6 + h) * p.Npad + col) * 16) : 0x80000000u;
         }
-    f32x4 bw[4][TN][3];
-    auto load_b3 = [&](int st) __attribute__((always_inline)) {
+    f32x4 bw[2][4][TN][3];
+    auto load_b3 = [&](int st, f32x4 (&q)[4][TN][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int n = 0; n < TN; ++n)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    buf_load4_pinned(bw[a][n][pl], wrsrc, u_off[a][n] + (unsigned)pl * u_plane + (unsigned)st * u_step);
+                    buf_load4_pinned(q[a][n][pl], wrsrc, u_off[a][n] + (unsigned)pl * u_plane + (unsigned)st * u_step);
     };
     f32x16 acc[4][TN];
 #pragma unroll
@@ -931,28 +930,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
             for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
 
     const int nstages = (p.nchunks + SC - 1) / SC;
-    // prologue: stage 0 into LDS buffer 0, stage 1 into the staging registers, stage 0's weights issued LAST (the first trip
-    // waits for them with vmcnt(0))
+    // prologue: stage 0 into LDS buffer 0, stage 0's weights, stage 1 into the staging registers (the order the first trip's
+    // explicit wait counts on)
 #pragma unroll
     for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
+    load_b3(0, bw[0]);
     store_raw(0);
 #pragma unroll
     for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
-    load_b3(0);
     __syncthreads();
 
     auto k_loop = [&](auto XI_) __attribute__((always_inline)) {
         constexpr int XI = decltype(XI_)::value;
-        for (int st = 0; st < nstages; ++st) {
-            const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
-            // this stage's weights were the last vector loads issued before the barrier: wait for everything in flight
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto trip = [&](auto CUR_, int st) __attribute__((always_inline)) {
+            constexpr int CUR = decltype(CUR_)::value;
+            const unsigned char* stage = smem + CUR * STAGE_BYTES;
+            load_b3(st + 1, bw[CUR ^ 1]);
+            // this stage's weights were issued a stage ago; since then: the patch prefetch and the next stage's weights
+            wait_vmcnt<12 * TN + SC * RAW_IT>();
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[a][n][pl]));
+                    for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[CUR][a][n][pl]));
             __builtin_amdgcn_sched_barrier(0);
             f32x4 e[2][4];
 #pragma unroll
@@ -973,8 +974,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
                 }
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
-                    const bf16x8 uh = __builtin_bit_cast(bf16x8, bw[nu][n][0]), um = __builtin_bit_cast(bf16x8, bw[nu][n][1]),
-                                 ul = __builtin_bit_cast(bf16x8, bw[nu][n][2]);
+                    const bf16x8 uh = __builtin_bit_cast(bf16x8, bw[CUR][nu][n][0]), um = __builtin_bit_cast(bf16x8, bw[CUR][nu][n][1]),
+                                 ul = __builtin_bit_cast(bf16x8, bw[CUR][nu][n][2]);
                     acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, uh, acc[nu][n], 0, 0, 0);
                     acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ul, acc[nu][n], 0, 0, 0);
                     acc[nu][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, um, acc[nu][n], 0, 0, 0);
@@ -984,13 +985,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // park stage st + 1 (the compiler waits for its loads: the newest ones, issued a stage ago), fetch stage st + 2, then
-            // the next stage's weights into the registers the MFMAs above have read
-            store_raw((st & 1) ^ 1);
+            // park stage st + 1 (the compiler waits for its loads -- and, not knowing the asm loads, for the weights issued above
+            // as well), fetch stage st + 2
+            store_raw(CUR ^ 1);
 #pragma unroll
             for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
-            load_b3(st + 1);
             __syncthreads();
+        };
+        for (int st = 0; st < nstages; st += 2) {
+            trip(IC<0>{}, st);
+            trip(IC<1>{}, st + 1);
         }
     };
     switch (wave) {          // wave-uniform

@@ -65,7 +65,7 @@ X3_BASE = 30000
 # ... and the Winograd F(2x2,3x3) kernel with split operands (conv_wino.hip, X3 build): codes W3_BASE + its block shape
 W3_BASE = 40000
 # (+ 1000: LDS-DMA patch staging with two stages of lookahead -- measured slower everywhere; 5132: four positions per wave in
-#  four-wave workgroups, two per CU: 3-8 % ahead of 132 on the batched layers, behind 164 where 64 couts per workgroup fit)
+#  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit)
 W3_CANDIDATES = (132, 164, 32, 5132)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # The decisions are persisted: read from / appended to a per-library-build file next to the library (e2fgvi_amd/.tile_cache/,
