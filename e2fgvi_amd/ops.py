@@ -455,6 +455,7 @@ class PackedConv:
                         best, mine = X3_BASE + min(res, key=res.get), min(res.values())
                 if x3 and use_wino and self._wino_x3() is not None:
                     # ... and the Winograd kernel with split operands: codes W3_BASE + its block shape
+                    w3 = {}
                     for shape in W3_CANDIDATES:
                         if launch_w3(shape)[0] != 0:
                             continue
@@ -464,9 +465,10 @@ class PackedConv:
                             launch_w3(shape)
                         e1.record()
                         e1.synchronize()
-                        ms = e0.elapsed_time(e1) / 3
-                        if ms < X3_MARGIN * mine:
-                            best, mine = W3_BASE + shape, ms
+                        w3[shape] = e0.elapsed_time(e1) / 3
+                    # the margin is for leaving the fp32 kernel; among the block shapes of the split kernel the fastest wins
+                    if w3 and min(w3.values()) < X3_MARGIN * mine:
+                        best, mine = W3_BASE + min(w3, key=w3.get), min(w3.values())
                 best = _remember(key, best)
             if best and best >= W3_BASE:
                 w3_tile = best - W3_BASE
