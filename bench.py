@@ -332,20 +332,19 @@ def main():
         if not hq and args.precision == "fp32":
             dom = runner.dominant_kernel_probe(net, dev)
             dom["traffic"] = None
-            for tag in ("r03", "r02", "r01"):
-                dfile = os.path.join(ROOT, "profiles", "%s_dominant_kernel_traffic.json" % tag)
-                if os.path.exists(dfile):
-                    try:
-                        dj = json.load(open(dfile))
-                        # only a measurement of the kernel that runs: round 3's files carry the kernel's trace name, older
-                        # ones are the fp32 F(2x4) kernel's
-                        if dj.get("kernel_tag", "conv_wino4<F(2x4),64>") != dom["kernel"].split(" (")[0]:
-                            continue
-                        dom["traffic"] = round(dj["hbm_bytes_per_launch"])
-                        dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s_dominant_kernel_traffic.json)" % tag
-                        break
-                    except Exception:
-                        pass
+            # PMC traffic of the kernel that runs: the newest profiles/*dominant_kernel_traffic*.json whose kernel_tag is this
+            # kernel's trace name (round 3's files carry it; older ones are the fp32 F(2x4) kernel's)
+            import glob
+            for dfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_dominant_kernel_traffic*.json")), reverse=True):
+                try:
+                    dj = json.load(open(dfile))
+                    if dj.get("kernel_tag", "conv_wino4<F(2x4),64>") != dom["kernel"].split(" (")[0]:
+                        continue
+                    dom["traffic"] = round(dj["hbm_bytes_per_launch"])
+                    dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s)" % os.path.basename(dfile)
+                    break
+                except Exception:
+                    pass
             out["roofline"]["dominant_kernel"] = dom
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.model, H, W, t, lt)

@@ -306,7 +306,7 @@ class PackedConv:
             cin_p = -(-sum(-(-c // 8) for c in self.cpg) // 2) * 16           # 16-channel stages
             # 16 positions per 4 pixels, six bf16 MACs per product, in fp32-pipe equivalents (see PackedConvX's trace record)
             issued = int(pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * 4 * 6 * 157.3 / 2500.0)
-            kern = "conv_wino_x3<%d,%d>" % (mt, bn)
+            kern = ("conv_wino_x3p4<%d>" % bn) if tile - W3_BASE >= 5000 else "conv_wino_x3<%d,%d>" % (mt, bn)
         elif use_wino:
             if not tile:
                 big = N * -(-H // 16) * -(-W // 16) * -(-cout_g // 64) * self.groups
