@@ -147,12 +147,34 @@ def check_kernel_waits(obj, name, ins):
             if off < 0 and tgt in addr_to_idx:
                 spans.append((addr_to_idx[tgt], i))
     loops = 0
+    # kernels that opt in to other wait disciplines, by (mangled) name:
+    #   conv_wino_kernel<..., DMA = true, X3 = true> fetches TWO trips ahead (its wait carries two inter-wait intervals);
+    #   conv_wino_x3w_kernel reloads its single-buffered weight planes in place and claims them group by group (below)
+    two_ahead = re.search(r"conv_wino_kernelILi\d+ELi\d+ELi\d+ELb1ELb1E", name) is not None
+    rolling = "conv_wino_x3w_kernel" in name
     for lo, hi in spans:
         inner = [m for m in marks if lo <= m <= hi]
         if not inner or any(lo <= l2 and h2 <= hi and (l2, h2) != (lo, hi) and any(l2 <= m <= h2 for m in inner)
                             for l2, h2 in spans):
             continue                                   # no marked wait, or an inner loop owns them
         loops += 1
+        if rolling:
+            # The plane loads of the next stage are the LAST vector-memory instructions of a trip, G per position; the next
+            # trip claims them position by position with vmcnt(n_0 = (P - 1) G), ..., vmcnt(0), nothing issued in between.
+            counts = [int(re.search(r"vmcnt\((\d+)\)", ins[m][2]).group(1)) for m in inner]
+            for a, b in zip(inner, inner[1:]):
+                if any(vmem.match(ins[k][1]) for k in range(a + 2, b)):
+                    raise RuntimeError("%s: %s: vector-memory instruction between the group waits at 0x%x and 0x%x"
+                                       % (obj, name[:60], ins[a][0], ins[b][0]))
+            g = counts[0] - counts[1] if len(counts) > 1 else counts[0]
+            if counts[-1] != 0 or g <= 0 or any(c != counts[0] - j * g for j, c in enumerate(counts)):
+                raise RuntimeError("%s: %s: group waits %s are not (P-1) G, ..., G, 0" % (obj, name[:60], counts))
+            tail = [k for k in list(range(inner[-1] + 2, hi + 1)) + list(range(lo, inner[0])) if vmem.match(ins[k][1])]
+            planes = tail[-(counts[0] + g):]
+            if len(planes) != counts[0] + g or any(ins[k][1] != "buffer_load_dwordx4" or " lds" in ins[k][2] for k in planes):
+                raise RuntimeError("%s: %s: the %d vector-memory instructions in front of the group waits are not the plane "
+                                   "loads" % (obj, name[:60], counts[0] + g))
+            continue
         for j, m in enumerate(inner):
             n = int(re.search(r"vmcnt\((\d+)\)", ins[m][2]).group(1))
             if j:
@@ -160,7 +182,7 @@ def check_kernel_waits(obj, name, ins):
             else:                                       # over the back edge: tail of the loop + its head
                 rng = list(range(inner[-1] + 2, hi + 1)) + list(range(lo, m))
             cnt = sum(1 for k in rng if vmem.match(ins[k][1]))
-            if cnt != n and len(inner) >= 1:
+            if cnt != n and two_ahead:
                 # a kernel that fetches TWO trips ahead (conv_wino.hip, X3 + LDS-DMA): its wait carries the loads of the two
                 # preceding inter-wait intervals (cyclically)
                 jj = (j - 1) % len(inner)

@@ -164,7 +164,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // statement that reads it and restored (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void dma_piece(i32x4 rsrc, unsigned lds_dst, unsigned voff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+    // (s_nop 2: five wait states between a v_readfirstlane / v_readlane that produced the resource words and the load that reads them)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 typedef __attribute__((address_space(3))) void wino_lds_void;
@@ -1082,6 +1083,395 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
 }
 #endif
 
+#if E2_WINO_X3
+
+// x = hi + mid + lo for four fp32 values (the half of wino_split8 that belongs to one channel quad): two packed bf16 pairs per plane
+__device__ __forceinline__ void wino_split4(const f32x4& v, unsigned (&H)[2], unsigned (&M)[2], unsigned (&L)[2]) {
+    const u32x4 bv = __builtin_bit_cast(u32x4, v);
+    // (plain scalars first: __builtin_bit_cast of a vector-element lvalue reads element 0 for every index with this hipcc)
+    unsigned b[4], rb[4], r2b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = bv[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float r = __builtin_bit_cast(float, b[j]) - __builtin_bit_cast(float, b[j] & 0xFFFF0000u);
+        rb[j] = __builtin_bit_cast(unsigned, r);
+        const float r2 = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
+        r2b[j] = __builtin_bit_cast(unsigned, r2);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        H[j] = __builtin_amdgcn_perm(b[2 * j + 1], b[2 * j], 0x07060302u);
+        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
+        L[j] = __builtin_amdgcn_perm(r2b[2 * j + 1], r2b[2 * j], 0x07060302u);
+    }
+}
+
+// ---- split-operand Winograd, WIDE tile (round 4): one eight-wave workgroup = a 16x16-pixel block (64 Winograd tiles, two MFMA
+// row-tiles) x 64 output channels -- the largest block whose 16 x 64 x 64 fp32 accumulators (128 registers per lane) fit two
+// waves per SIMD.  Against the 8x16-pixel x 32-cout shapes above, every transform + split of a patch feeds four times the MFMAs
+// (5 VALU per MFMA instead of 10-17), every 16-byte weight fragment feeds 12 MFMAs instead of 6, and a stage moves 119 KB
+// (21 KB of patch + 98 KB of weights) per 384 MFMAs instead of 60 KB per 96: 39 B/clk per CU at the matrix rate, under what
+// the L2 delivers (~56 B/clk per CU).  What made the shape impossible in round 3 was the DOUBLE-buffered weight registers
+// (2 x 48 + 128 accumulators + the transform's working set): here the weights are SINGLE-buffered and reloaded in place --
+// the six MFMAs of a (position, column tile) group of the stage's second row-tile are the last readers of the group's three
+// plane registers, and the pinned loads of the next stage's planes into the same registers are issued right behind them (an
+// in-flight MFMA has read its B operand long before a load can return).  Loads return in order, so the first row-tile of the
+// next stage claims them group by group with vmcnt(9 / 6 / 3 / 0): every load has the rest of its stage's MFMAs, the stage
+// barrier and the next stage's first fragment phase to land.  Wave w owns the transform positions 2w, 2w + 1 as in the
+// eight-wave kernel; fragments are built one row-tile at a time, one channel quad at a time (12 fragment registers per
+// position), the patch of stage st + 1 is parked between the two row-tiles' MFMA blocks.
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams p) {
+    constexpr int MT = 2, SC = 2;
+    constexpr int TN = BN / 32;
+    constexpr int RAW_H = 8 * MT + 2;
+    constexpr int PLANE_RAW = RAW_H * PLANE_ROW * 16;
+    constexpr int PLANE_BYTES = PLANE_RAW + ((16 - PLANE_RAW % 128) + 128) % 128;
+    constexpr int CHUNK_USED = 4 * PLANE_BYTES;
+    constexpr int CHUNK_BYTES = (CHUNK_USED + 1023) / 1024 * 1024;       // whole 1-KiB LDS-DMA pieces
+    constexpr int STAGE_BYTES = SC * CHUNK_BYTES;
+    constexpr int NSTAGE = 3;
+    constexpr int TILES = 32 * MT;
+    constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
+    constexpr int SMEM = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
+    constexpr int PIECES = CHUNK_BYTES / 1024;                            // wave w issues the pieces w, w + 8 of a chunk
+    constexpr int NPMAX = (PIECES + 7) / 8;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y;
+    const int logical = xcd_remap(blockIdx.x, p.nblk);
+    const int mblocks = p.N * p.blocksY * p.blocksX;
+    const int tile_n = logical / mblocks;
+    int rem = logical - tile_n * mblocks;
+    const int img = rem / (p.blocksY * p.blocksX);
+    rem -= img * (p.blocksY * p.blocksX);
+    const int by = rem / p.blocksX, bx = rem - by * p.blocksX;
+    const int n0 = tile_n * BN;
+    const int y0 = by * (8 * MT) - 1, x0 = bx * 16 - 1;
+
+    // The raw patch goes global -> LDS by LDS-DMA (no staging registers: the 128 accumulator + 48 weight registers leave no room
+    // for them): each lane fetches the 16-byte unit that belongs at its LDS position of piece j of its wave (unit U of the chunk
+    // area = plane [kq][column parity], patch row, column pair; padding units and pixels outside the image fetch out of range =
+    // zeros).  dma_pix: the source pixel, bit 31 set = nothing to fetch; bit 30 = the channel quad kq of the unit's plane.
+    unsigned dma_pix[NPMAX];
+    {
+        constexpr int UP = PLANE_BYTES / 16;
+#pragma unroll
+        for (int j = 0; j < NPMAX; ++j) {
+            const int U = (wave + 8 * j) * 64 + lane;
+            const int plane = U / UP, r2 = U - plane * UP;
+            const int py = r2 / PLANE_ROW, c = r2 - py * PLANE_ROW;
+            const int pxx = 2 * c + (plane & 1);
+            const int gy = y0 + py, gx = x0 + pxx;
+            const bool in = plane < 4 && py < RAW_H && c < RAW_W / 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            dma_pix[j] = in ? ((unsigned)((img * p.H + gy) * p.W + gx) | ((unsigned)(plane >> 1) << 30)) : OOB;
+        }
+    }
+    const unsigned smem_lds = (unsigned)(unsigned long long)(wino_lds_void*)smem;
+    const float* const dsp0 = p.src[0]; const float* const dsp1 = p.src[1]; const float* const dsp2 = p.src[2]; const float* const dsp3 = p.src[3];
+    const unsigned dsb0 = p.src_bytes[0], dsb1 = p.src_bytes[1], dsb2 = p.src_bytes[2], dsb3 = p.src_bytes[3];
+    const unsigned dsl0 = (unsigned)p.ld[0] * 4u, dsl1 = (unsigned)p.ld[1] * 4u, dsl2 = (unsigned)p.ld[2] * 4u, dsl3 = (unsigned)p.ld[3] * 4u;
+    const unsigned dsc0 = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u, dsc1 = (unsigned)(p.coff[1] + g * p.cpg[1]) * 4u,
+                   dsc2 = (unsigned)(p.coff[2] + g * p.cpg[2]) * 4u, dsc3 = (unsigned)(p.coff[3] + g * p.cpg[3]) * 4u;
+    const int dsg0 = p.cpg[0], dsg1 = p.cpg[1], dsg2 = p.cpg[2], dsg3 = p.cpg[3];
+    const int dpre1 = (dsg0 + 7) / 8, dpre2 = dpre1 + (p.nsrc > 1 ? (dsg1 + 7) / 8 : 0), dpre3 = dpre2 + (p.nsrc > 2 ? (dsg2 + 7) / 8 : 0);
+    const int dnsrc = p.nsrc, dlast = p.nchunks - 1;
+    // the pieces of wave WV of chunk `chunk` of the source walk -> LDS chunk area lds_chunk; exactly NPW vector-memory instructions
+    // on every path; the chunk -> (source, channel) map is stateless arithmetic (see conv_wino_kernel's DMA variant)
+    auto dma_chunk = [=, &dma_pix](auto W_, auto NPW_, int chunk, unsigned lds_chunk) __attribute__((always_inline)) {
+        constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
+        const int k = chunk < dlast ? chunk : dlast;
+        const int sidx = (dnsrc > 1 && k >= dpre1 ? 1 : 0) + (dnsrc > 2 && k >= dpre2 ? 1 : 0) + (dnsrc > 3 && k >= dpre3 ? 1 : 0);
+        const unsigned long long m1 = dnsrc > 1 && sidx == 1, m2 = dnsrc > 2 && sidx == 2, m3 = dnsrc > 3 && sidx == 3;
+        auto sel = [=](unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long d) {
+            return a + m1 * (b - a) + m2 * (c - a) + m3 * (d - a);
+        };
+        const float* csrc = dsp0;
+        unsigned cbytes = dsb0, cld4 = dsl0, cchan = dsc0;
+        int ccpg = dsg0, cc0 = k * 8;
+        if (dnsrc > 1) {                           // wave-uniform
+            csrc = reinterpret_cast<const float*>(sel((unsigned long long)dsp0, (unsigned long long)dsp1, (unsigned long long)dsp2,
+                                                      (unsigned long long)dsp3));
+            cbytes = (unsigned)sel(dsb0, dsb1, dsb2, dsb3);
+            cld4 = (unsigned)sel(dsl0, dsl1, dsl2, dsl3);
+            cchan = (unsigned)sel(dsc0, dsc1, dsc2, dsc3);
+            ccpg = (int)sel((unsigned)dsg0, (unsigned)dsg1, (unsigned)dsg2, (unsigned)dsg3);
+            cc0 = (k - (int)sel(0u, (unsigned)dpre1, (unsigned)dpre2, (unsigned)dpre3)) * 8;
+        }
+        const i32x4 rs = rsrc_words(csrc, cbytes);
+        const unsigned chan = cchan + (unsigned)cc0 * 4u;
+        const bool half = cc0 + 4 >= ccpg;           // a source may end in the middle of a chunk: its kq = 1 units are zeros
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const unsigned pix = dma_pix[j] & 0x3FFFFFFFu, kq = (dma_pix[j] >> 30) & 1u;
+            unsigned off = ((int)dma_pix[j] >= 0 && !(half && kq)) ? pix * cld4 + chan + kq * 16u : OOB;
+            asm volatile("" : "+v"(off));
+            dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
+        }
+    };
+
+    const int i = lane & 31, h = lane >> 5;
+    const int ty = i >> 3, tx = i & 7;
+    // LDS byte offset of the lane's tile inside a stage: chunk h of the stage (8 channels), patch row 2 ty, column pair tx; the
+    // patch row / column / channel quad / row-tile of a read are compile-time offsets on top
+    const int a_lane = h * CHUNK_BYTES + (2 * ty * PLANE_ROW + tx) * 16;
+
+    // weights: [stage][a = 16][plane = 3][h = 2][Npad] x 16 bytes.  ONE lane-dependent byte offset (half h, column i of the
+    // workgroup's first column tile, advanced by a stage per trip: past the last stage it is out of the group's range and the loads
+    // return zeros); position, plane and column tile are wave-uniform and go into the instruction's scalar offset (which the
+    // buffer range check does not see: column tiles past Npad are redirected to tile 0 below)
+    const i32x4 wrsrc = rsrc_words(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes, p.wgroup_bytes);
+    const unsigned u_step = 96u * (unsigned)p.Npad * 16u;
+    const unsigned u_plane = 2u * (unsigned)p.Npad * 16u;
+    unsigned u_lane = (unsigned)((h * p.Npad + n0 + i) * 16);
+    auto load_plane = [&](f32x4& v, unsigned soff) __attribute__((always_inline)) {
+        // s_nop 4: the scalar offset may be a spilled SGPR that the compiler has just restored with v_readlane (a VALU write of an
+        // SGPR needs 5 wait states before a vector-memory instruction reads it, and the hazard recognizer does not look inside an
+        // asm statement: without the nops, single plane loads used a stale offset in a few workgroups per launch)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(u_lane), "s"(wrsrc), "s"(soff) : "memory");
+    };
+    f32x4 bw[2][TN][3];
+    f32x16 acc[2][MT][TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
+
+    const int nstages = (p.nchunks + SC - 1) / SC;
+
+    auto k_loop = [&](auto XI_, auto PB_) __attribute__((always_inline)) {
+        constexpr int XI = decltype(XI_)::value;
+        constexpr bool PB = decltype(PB_)::value != 0;
+        constexpr int R0 = (XI == 0) ? 0 : 1, R1 = (XI == 3) ? 3 : 2;       // the two patch rows of B^T row xi
+        constexpr int CB = PB ? 1 : 0;                                      // first of the three patch columns
+        constexpr int WV = 2 * XI + (PB ? 1 : 0);                           // this wave
+        constexpr int NPW = (PIECES - WV + 7) / 8;                          // its LDS-DMA pieces per chunk
+        const unsigned u_pos = (unsigned)(WV * 2 * 6) * (unsigned)p.Npad * 16u;     // scalar offset of position a = 0
+        // ... of column tile n: a tile that lies entirely past Npad (Cout_g not a multiple of BN) re-reads tile 0's columns -- its
+        // results are never stored, and the scalar offset must not lead outside the packed weights
+        unsigned u_n[TN];
+#pragma unroll
+        for (int n = 0; n < TN; ++n) u_n[n] = (n0 + n * 32 < p.Npad) ? (unsigned)(n * 32 * 16) : 0u;
+        // prologue: stages 0 and 1 of the patch, stage 0's planes; everything waited for
+#pragma unroll
+        for (int c4 = 0; c4 < 2 * SC; ++c4)
+            dma_chunk(IC<WV>{}, IC<NPW>{}, c4, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    load_plane(bw[a][n][pl], u_pos + (unsigned)(a * 3 + pl) * u_plane + u_n[n]);
+        u_lane += u_step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // fragments of one row-tile: positions a = 0, 1 x planes hi, mid, lo; built one channel quad at a time
+        auto prep = [&](const unsigned char* rm, bf16x8 (&A)[6]) __attribute__((always_inline)) {
+            unsigned P[6][4];
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                f32x4 e[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int col = CB + j;
+                    const int off = kq * (2 * PLANE_BYTES) + (col & 1) * PLANE_BYTES + (col >> 1) * 16;
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(rm + off + R0 * PLANE_ROW * 16);
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(rm + off + R1 * PLANE_ROW * 16);
+                    e[j] = XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
+                }
+                const f32x4 va = PB ? e[1] - e[0] : e[0] - e[2];
+                const f32x4 vb = PB ? e[0] - e[2] : e[1] + e[2];
+                unsigned H[2], M[2], L[2];
+                wino_split4(va, H, M, L);
+                P[0][2 * kq] = H[0]; P[0][2 * kq + 1] = H[1]; P[1][2 * kq] = M[0]; P[1][2 * kq + 1] = M[1];
+                P[2][2 * kq] = L[0]; P[2][2 * kq + 1] = L[1];
+                wino_split4(vb, H, M, L);
+                P[3][2 * kq] = H[0]; P[3][2 * kq + 1] = H[1]; P[4][2 * kq] = M[0]; P[4][2 * kq + 1] = M[1];
+                P[5][2 * kq] = L[0]; P[5][2 * kq + 1] = L[1];
+            }
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                u32x4 t = {P[f][0], P[f][1], P[f][2], P[f][3]};
+                A[f] = __builtin_bit_cast(bf16x8, t);
+            }
+        };
+        // the 12 TN MFMAs of one row-tile; LAST: behind each position's block, the next stage's planes into the same registers
+        auto mma = [&](auto M_, auto LAST_, const bf16x8 (&A)[6]) __attribute__((always_inline)) {
+            constexpr int M = decltype(M_)::value;
+            constexpr bool LAST = decltype(LAST_)::value != 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if constexpr (!LAST) {
+                    // this position's 3 TN plane loads were issued a stage ago, and after them the other position's (a = 0: 3 TN)
+                    // (issued twice: the mark build.verify_wino_waits() looks for)
+                    if (a == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(3 * TN) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[a][n][pl]));
+                }
+                __builtin_amdgcn_sched_barrier(0);     // the positions' MFMA blocks stay behind their own waits
+                const bf16x8 xh = A[3 * a], xm = A[3 * a + 1], xl = A[3 * a + 2];
+                bf16x8 uh[TN], um[TN], ul[TN];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    uh[n] = __builtin_bit_cast(bf16x8, bw[a][n][0]);
+                    um[n] = __builtin_bit_cast(bf16x8, bw[a][n][1]);
+                    ul[n] = __builtin_bit_cast(bf16x8, bw[a][n][2]);
+                }
+                // smallest terms first, the column tiles interleaved (independent accumulators)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, uh[n], acc[a][M][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ul[n], acc[a][M][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, um[n], acc[a][M][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, uh[n], acc[a][M][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, um[n], acc[a][M][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, uh[n], acc[a][M][n], 0, 0, 0);
+                if constexpr (LAST) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            load_plane(bw[a][n][pl], u_pos + (unsigned)(a * 3 + pl) * u_plane + u_n[n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // one stage per trip; `slot` = its LDS slot, stage st + 2 goes to slot (slot + 2) % 3, whose readers passed the last barrier
+        int slot = 0;
+        for (int st = 0; st < nstages; ++st) {
+            const unsigned char* rm = smem + slot * STAGE_BYTES + a_lane;
+            const unsigned ahead = smem_lds + (unsigned)((slot == 0 ? 2 : slot - 1) * STAGE_BYTES);
+            {
+                bf16x8 A[6];
+                prep(rm, A);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(IC<0>{}, IC<0>{}, A);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                bf16x8 A[6];
+                prep(rm + 8 * PLANE_ROW * 16, A);
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's pieces of stage st + 2: in front of the plane loads, so that the next stage's first plane wait also
+                // retires them (loads return in order); the barrier at the end of the next stage publishes them
+#pragma unroll
+                for (int q = 0; q < SC; ++q) dma_chunk(IC<WV>{}, IC<NPW>{}, SC * (st + 2) + q, ahead + (unsigned)(q * CHUNK_BYTES));
+                __builtin_amdgcn_sched_barrier(0);
+                mma(IC<1>{}, IC<1>{}, A);
+            }
+            u_lane += u_step;
+            slot = slot == 2 ? 0 : slot + 1;
+            __syncthreads();
+        }
+    };
+    switch (wave) {          // wave-uniform
+        case 0: k_loop(IC<0>{}, IC<0>{}); break;
+        case 1: k_loop(IC<0>{}, IC<1>{}); break;
+        case 2: k_loop(IC<1>{}, IC<0>{}); break;
+        case 3: k_loop(IC<1>{}, IC<1>{}); break;
+        case 4: k_loop(IC<2>{}, IC<0>{}); break;
+        case 5: k_loop(IC<2>{}, IC<1>{}); break;
+        case 6: k_loop(IC<3>{}, IC<0>{}); break;
+        default: k_loop(IC<3>{}, IC<1>{}); break;
+    }
+    // the planes and the patch pieces of the stages past the end are still in flight: they target registers and LDS the epilogue reuses
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
+    float* E = reinterpret_cast<float*>(smem);
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int nh = 0; nh < TN; ++nh) {
+        if (nh) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    E[((2 * wave + a) * TILES + tile) * 32 + i] = acc[a][m][nh][r];
+                }
+        __syncthreads();
+        const int cq = tid & 7, tile = tid >> 3;
+        const int n = n0 + nh * 32 + cq * 4;
+        const int oy = by * (8 * MT) + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7);
+        if (tile < TILES && n < p.Cout_g && oy < p.H && ox < p.W) {
+            f32x4 mm[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) mm[a] = *reinterpret_cast<const f32x4*>(E + (a * TILES + tile) * 32 + cq * 4);
+            f32x4 t0[4], t1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                t0[nu] = mm[0 * 4 + nu] + mm[1 * 4 + nu] + mm[2 * 4 + nu];
+                t1[nu] = mm[1 * 4 + nu] - mm[2 * 4 + nu] - mm[3 * 4 + nu];
+            }
+            f32x4 y[4];
+            y[0] = t0[0] + t0[1] + t0[2];
+            y[1] = t0[1] - t0[2] - t0[3];
+            y[2] = t1[0] + t1[1] + t1[2];
+            y[3] = t1[1] - t1[2] - t1[3];
+            const int co = g * p.Cout_g + n;
+            const long long pix0 = (long long)img * HW + (long long)oy * p.W + ox;
+            const int pstep[4] = {0, 1, p.W, p.W + 1};
+            const bool full = n + 3 < p.Cout_g;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bv[c] = (full || n + c < p.Cout_g) ? p.bias[co + c] : 0.f;
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const long long pix = pix0 + pstep[px];
+                f32x4 v = y[px] + bv;
+                if (p.act == E2FGVI_ACT_DCNPOST) {
+                    const f32x4 fl = *reinterpret_cast<const f32x4*>(p.res + pix * 4);
+                    const float flv[4] = {fl[0], fl[1], fl[2], fl[3]};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = wino_dcn_post(v[c], co + c, p.Cout, flv, p.slope);
+                } else {
+                    if (p.res) {
+                        const float* r = p.res + pix * p.res_ld + p.res_coff + co;
+                        if (p.vec_store && full) v = v + *reinterpret_cast<const f32x4*>(r);
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (full || n + c < p.Cout_g) v[c] += r[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(v[c], p.act, p.slope);
+                }
+                float* o = p.dst + pix * p.dst_ld + p.dst_coff + co;
+                if (p.vec_store && full) *reinterpret_cast<f32x4*>(o) = v;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (full || n + c < p.Cout_g) o[c] = v[c];
+                }
+            }
+        }
+    }
+}
+#endif
+
 struct WinoPack {
     int Cout, groups, nsrc;
     int cpg[E2FGVI_MAX_SRC];
@@ -1263,6 +1653,21 @@ static int launch_wino_p4(WinoParams& p, int groups, hipStream_t st) {
 }
 #endif
 
+#if E2_WINO_X3
+template <int BN>
+static int launch_wino_w(WinoParams& p, int groups, hipStream_t st) {
+    p.blocksY = cdiv(p.H, 16);
+    p.blocksX = cdiv(p.W, 16);
+    p.tilesN = cdiv(p.Cout_g, BN);
+    const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
+    E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd_x3: grid too large");
+    p.nblk = (int)nblk;
+    hipLaunchKernelGGL((conv_wino_x3w_kernel<BN>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    E2_LAUNCH_CHECK("conv3x3_winograd_x3 (wide tile)");
+    return 0;
+}
+#endif
+
 static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv3x3_winograd: null descriptor");
     WinoPack q;
@@ -1328,6 +1733,8 @@ static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
         case 132: return launch_wino<1, 32, 2, false, true>(p, d->groups, st);
         // + 5000: four positions per wave, four-wave workgroups (two per CU)
         case 5132: return launch_wino_p4<32>(p, d->groups, st);
+        // + 6000: 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place (round 4)
+        case 6064: return launch_wino_w<64>(p, d->groups, st);
         // + 1000: patch by LDS-DMA, patch and weights fetched two stages ahead (32-cout shapes: three weight buffers fit)
         case 1032: return launch_wino<2, 32, 2, true, true>(p, d->groups, st);
         case 1132: return launch_wino<1, 32, 2, true, true>(p, d->groups, st);

@@ -65,8 +65,9 @@ X3_BASE = 30000
 # ... and the Winograd F(2x2,3x3) kernel with split operands (conv_wino.hip, X3 build): codes W3_BASE + its block shape
 W3_BASE = 40000
 # (+ 1000: LDS-DMA patch staging with two stages of lookahead -- measured slower everywhere; 5132: four positions per wave in
-#  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit)
-W3_CANDIDATES = (132, 164, 32, 5132)
+#  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
+#  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
+W3_CANDIDATES = (132, 164, 32, 5132, 6064)
 _TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # The decisions are persisted: read from / appended to a per-library-build file next to the library (e2fgvi_amd/.tile_cache/,
 # or $E2FGVI_CACHE_DIR), so that
@@ -306,7 +307,8 @@ class PackedConv:
             cin_p = -(-sum(-(-c // 8) for c in self.cpg) // 2) * 16           # 16-channel stages
             # 16 positions per 4 pixels, six bf16 MACs per product, in fp32-pipe equivalents (see PackedConvX's trace record)
             issued = int(pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * 4 * 6 * 157.3 / 2500.0)
-            kern = ("conv_wino_x3p4<%d>" % bn) if tile - W3_BASE >= 5000 else "conv_wino_x3<%d,%d>" % (mt, bn)
+            code = tile - W3_BASE
+            kern = ("conv_wino_x3w<%d>" % bn) if code >= 6000 else ("conv_wino_x3p4<%d>" % bn) if code >= 5000 else "conv_wino_x3<%d,%d>" % (mt, bn)
         elif use_wino:
             if not tile:
                 big = N * -(-H // 16) * -(-W // 16) * -(-cout_g // 64) * self.groups
