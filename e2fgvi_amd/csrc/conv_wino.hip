@@ -49,6 +49,7 @@
 // parking the next stage / issuing the stage after / the stage barrier) and writes the sums here at the end.  Diagnostics
 // only -- the product library is built without it.
 __device__ unsigned long long e2_wino_dbg[64 * 8 * 8];
+__device__ unsigned long long e2_wino_dbg2[64 * 8 * 4];      // conv_wino_x3w_kernel: cycles before the K loop / K loop / epilogue / whole kernel
 #define E2T_NOW() __builtin_readcyclecounter()
 #define E2T(...) __VA_ARGS__
 #else
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
+    E2T(const unsigned long long t_entry = E2T_NOW();)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y;
@@ -1172,45 +1174,39 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
         }
     }
     const unsigned smem_lds = (unsigned)(unsigned long long)(wino_lds_void*)smem;
-    const float* const dsp0 = p.src[0]; const float* const dsp1 = p.src[1]; const float* const dsp2 = p.src[2]; const float* const dsp3 = p.src[3];
-    const unsigned dsb0 = p.src_bytes[0], dsb1 = p.src_bytes[1], dsb2 = p.src_bytes[2], dsb3 = p.src_bytes[3];
-    const unsigned dsl0 = (unsigned)p.ld[0] * 4u, dsl1 = (unsigned)p.ld[1] * 4u, dsl2 = (unsigned)p.ld[2] * 4u, dsl3 = (unsigned)p.ld[3] * 4u;
-    const unsigned dsc0 = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u, dsc1 = (unsigned)(p.coff[1] + g * p.cpg[1]) * 4u,
-                   dsc2 = (unsigned)(p.coff[2] + g * p.cpg[2]) * 4u, dsc3 = (unsigned)(p.coff[3] + g * p.cpg[3]) * 4u;
-    const int dsg0 = p.cpg[0], dsg1 = p.cpg[1], dsg2 = p.cpg[2], dsg3 = p.cpg[3];
-    const int dpre1 = (dsg0 + 7) / 8, dpre2 = dpre1 + (p.nsrc > 1 ? (dsg1 + 7) / 8 : 0), dpre3 = dpre2 + (p.nsrc > 2 ? (dsg2 + 7) / 8 : 0);
-    const int dnsrc = p.nsrc, dlast = p.nchunks - 1;
-    // the pieces of wave WV of chunk `chunk` of the source walk -> LDS chunk area lds_chunk; exactly NPW vector-memory instructions
-    // on every path; the chunk -> (source, channel) map is stateless arithmetic (see conv_wino_kernel's DMA variant)
-    auto dma_chunk = [=, &dma_pix](auto W_, auto NPW_, int chunk, unsigned lds_chunk) __attribute__((always_inline)) {
+    // The source walk of the pieces (chunks are fetched strictly in order: 0, 1, 2, ...): the parameters of the source being
+    // walked live in scalar registers and are re-read from the kernel arguments only when the walk crosses into the next source
+    // (past the last chunk it wraps to the first source: those stages' weights are out of range = zeros).
+    int w_s = 0, w_c0 = 0;
+    const float* w_src = p.src[0];
+    unsigned w_bytes = p.src_bytes[0], w_ld4 = (unsigned)p.ld[0] * 4u, w_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int w_cpg = p.cpg[0];
+    // the pieces of wave WV of the NEXT chunk of the walk -> LDS chunk area lds_chunk; exactly NPW vector-memory instructions
+    auto dma_chunk = [&](auto W_, auto NPW_, unsigned lds_chunk) __attribute__((always_inline)) {
         constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
-        const int k = chunk < dlast ? chunk : dlast;
-        const int sidx = (dnsrc > 1 && k >= dpre1 ? 1 : 0) + (dnsrc > 2 && k >= dpre2 ? 1 : 0) + (dnsrc > 3 && k >= dpre3 ? 1 : 0);
-        const unsigned long long m1 = dnsrc > 1 && sidx == 1, m2 = dnsrc > 2 && sidx == 2, m3 = dnsrc > 3 && sidx == 3;
-        auto sel = [=](unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long d) {
-            return a + m1 * (b - a) + m2 * (c - a) + m3 * (d - a);
-        };
-        const float* csrc = dsp0;
-        unsigned cbytes = dsb0, cld4 = dsl0, cchan = dsc0;
-        int ccpg = dsg0, cc0 = k * 8;
-        if (dnsrc > 1) {                           // wave-uniform
-            csrc = reinterpret_cast<const float*>(sel((unsigned long long)dsp0, (unsigned long long)dsp1, (unsigned long long)dsp2,
-                                                      (unsigned long long)dsp3));
-            cbytes = (unsigned)sel(dsb0, dsb1, dsb2, dsb3);
-            cld4 = (unsigned)sel(dsl0, dsl1, dsl2, dsl3);
-            cchan = (unsigned)sel(dsc0, dsc1, dsc2, dsc3);
-            ccpg = (int)sel((unsigned)dsg0, (unsigned)dsg1, (unsigned)dsg2, (unsigned)dsg3);
-            cc0 = (k - (int)sel(0u, (unsigned)dpre1, (unsigned)dpre2, (unsigned)dpre3)) * 8;
-        }
-        const i32x4 rs = rsrc_words(csrc, cbytes);
-        const unsigned chan = cchan + (unsigned)cc0 * 4u;
-        const bool half = cc0 + 4 >= ccpg;           // a source may end in the middle of a chunk: its kq = 1 units are zeros
+        const i32x4 rs = rsrc_words(w_src, w_bytes);
+        const unsigned chan = w_chan + (unsigned)w_c0 * 4u;
+        const bool half = w_c0 + 4 >= w_cpg;         // a source may end in the middle of a chunk: its kq = 1 units are zeros
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
             const unsigned pix = dma_pix[j] & 0x3FFFFFFFu, kq = (dma_pix[j] >> 30) & 1u;
-            unsigned off = ((int)dma_pix[j] >= 0 && !(half && kq)) ? pix * cld4 + chan + kq * 16u : OOB;
+            unsigned off = ((int)dma_pix[j] >= 0 && !(half && kq)) ? pix * w_ld4 + chan + kq * 16u : OOB;
             asm volatile("" : "+v"(off));
             dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
+        }
+        w_c0 += 8;
+        if (w_c0 >= w_cpg) {
+            w_c0 = 0;
+            ++w_s;
+            if (w_s == p.nsrc) w_s = 0;
+            if (p.nsrc > 1) {
+                // static indices, one arm per source: a dynamic index into the parameter block makes hipcc copy the block to scratch
+                // memory (and walk it with vector loads); each arm is a handful of scalar loads from the kernel arguments
+#define E2_WALK_ARM(S) { w_src = p.src[S]; w_bytes = p.src_bytes[S]; w_ld4 = (unsigned)p.ld[S] * 4u; \
+                         w_chan = (unsigned)(p.coff[S] + g * p.cpg[S]) * 4u; w_cpg = p.cpg[S]; }
+                if (w_s == 0) E2_WALK_ARM(0) else if (w_s == 1) E2_WALK_ARM(1) else if (w_s == 2) E2_WALK_ARM(2) else E2_WALK_ARM(3)
+#undef E2_WALK_ARM
+            }
         }
     };
 
@@ -1246,6 +1242,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
 
     const int nstages = (p.nchunks + SC - 1) / SC;
+    E2T(unsigned long long t_loop0 = 0, t_loop1 = 0;)
 
     auto k_loop = [&](auto XI_, auto PB_) __attribute__((always_inline)) {
         constexpr int XI = decltype(XI_)::value;
@@ -1263,7 +1260,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
         // prologue: stages 0 and 1 of the patch, stage 0's planes; everything waited for
 #pragma unroll
         for (int c4 = 0; c4 < 2 * SC; ++c4)
-            dma_chunk(IC<WV>{}, IC<NPW>{}, c4, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
+            dma_chunk(IC<WV>{}, IC<NPW>{}, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1309,6 +1306,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
         auto mma = [&](auto M_, auto LAST_, const bf16x8 (&A)[6]) __attribute__((always_inline)) {
             constexpr int M = decltype(M_)::value;
             constexpr bool LAST = decltype(LAST_)::value != 0;
+            if (E2_WINO_VARIANT & 16) __builtin_amdgcn_s_setprio(3);      // experiment: the wave in an MFMA phase wins the issue port
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 if constexpr (!LAST) {
@@ -1353,34 +1351,82 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (E2_WINO_VARIANT & 16) __builtin_amdgcn_s_setprio(0);
         };
-        // one stage per trip; `slot` = its LDS slot, stage st + 2 goes to slot (slot + 2) % 3, whose readers passed the last barrier
+        // One stage = P0 (fragments of row-tile 0) M0 (its MFMAs) P1 (fragments of row-tile 1 + this wave's LDS-DMA pieces of stage
+        // st + 2) M1 (its MFMAs + the plane reloads), one barrier per stage.  Stage st lives in LDS slot st % 3; stage st + 2 goes to
+        // slot (st + 2) % 3, whose readers passed the last barrier.
+        // SKEW (waves 4-7, the SIMD partners of waves 0-3): the same phases shifted by one -- M1 of stage st runs BEHIND the
+        // stage's barrier, in front of P0 of stage st + 1 (its fragments wait in registers, where they are anyway) -- so that one
+        // wave of a SIMD is in a fragment phase (VALU, LDS) while the other is in an MFMA phase; without it the two go through the
+        // phases together (both were released by the same barrier) and the matrix pipe idles through both fragment phases.
+        constexpr bool SKEW = XI >= 2 && (E2_WINO_VARIANT & 8) != 0;
+        E2T(unsigned long long tsum[6]; for (int k_ = 0; k_ < 6; ++k_) tsum[k_] = 0; const unsigned long long t_k0 = E2T_NOW(); t_loop0 = t_k0;)
         int slot = 0;
-        for (int st = 0; st < nstages; ++st) {
+        auto first_half = [&](bf16x8 (&A1)[6]) __attribute__((always_inline)) {
             const unsigned char* rm = smem + slot * STAGE_BYTES + a_lane;
             const unsigned ahead = smem_lds + (unsigned)((slot == 0 ? 2 : slot - 1) * STAGE_BYTES);
+            E2T(const unsigned long long t_a = E2T_NOW();)
             {
                 bf16x8 A[6];
                 prep(rm, A);
                 __builtin_amdgcn_sched_barrier(0);
+                E2T(const unsigned long long t_b = E2T_NOW(); tsum[0] += t_b - t_a;)
                 mma(IC<0>{}, IC<0>{}, A);
+                E2T(__builtin_amdgcn_sched_barrier(0); tsum[1] += E2T_NOW() - t_b;)
             }
             __builtin_amdgcn_sched_barrier(0);
-            {
-                bf16x8 A[6];
-                prep(rm + 8 * PLANE_ROW * 16, A);
-                __builtin_amdgcn_sched_barrier(0);
-                // this wave's pieces of stage st + 2: in front of the plane loads, so that the next stage's first plane wait also
-                // retires them (loads return in order); the barrier at the end of the next stage publishes them
+            E2T(const unsigned long long t_c = E2T_NOW();)
+            prep(rm + 8 * PLANE_ROW * 16, A1);
+            __builtin_amdgcn_sched_barrier(0);
+            E2T(const unsigned long long t_d = E2T_NOW(); tsum[2] += t_d - t_c;)
+            // this wave's pieces of stage st + 2: in front of the plane loads, so that the next stage's first plane wait also
+            // retires them (loads return in order); the barrier at the end of the next stage publishes them
 #pragma unroll
-                for (int q = 0; q < SC; ++q) dma_chunk(IC<WV>{}, IC<NPW>{}, SC * (st + 2) + q, ahead + (unsigned)(q * CHUNK_BYTES));
-                __builtin_amdgcn_sched_barrier(0);
-                mma(IC<1>{}, IC<1>{}, A);
-            }
+            for (int q = 0; q < SC; ++q) dma_chunk(IC<WV>{}, IC<NPW>{}, ahead + (unsigned)(q * CHUNK_BYTES));
+            __builtin_amdgcn_sched_barrier(0);
+            E2T(tsum[3] += E2T_NOW() - t_d;)
+        };
+        auto second_half = [&](const bf16x8 (&A1)[6]) __attribute__((always_inline)) {
+            E2T(const unsigned long long t_e = E2T_NOW();)
+            mma(IC<1>{}, IC<1>{}, A1);
             u_lane += u_step;
             slot = slot == 2 ? 0 : slot + 1;
+            E2T(__builtin_amdgcn_sched_barrier(0); tsum[4] += E2T_NOW() - t_e;)
+        };
+        auto stage_barrier = [&]() __attribute__((always_inline)) {
+            E2T(const unsigned long long t_f = E2T_NOW();)
             __syncthreads();
+            E2T(tsum[5] += E2T_NOW() - t_f;)
+        };
+        if constexpr (SKEW) {
+            bf16x8 A1[6];
+            first_half(A1);
+            stage_barrier();
+            for (int st = 0; st < nstages; ++st) {
+                second_half(A1);
+                if (st + 1 < nstages) {           // (the last M1 runs into the barrier behind the loop: as many barriers as the other waves)
+                    first_half(A1);
+                    stage_barrier();
+                }
+            }
+        } else {
+            for (int st = 0; st < nstages; ++st) {
+                bf16x8 A1[6];
+                first_half(A1);
+                second_half(A1);
+                stage_barrier();
+            }
         }
+#ifdef E2_WINO_TIMING
+        if (blockIdx.x < 64 && blockIdx.y == 0 && lane == 0) {
+            unsigned long long* o = e2_wino_dbg + (blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 6; ++k) o[k] = tsum[k];
+            o[6] = E2T_NOW() - t_k0;                   // the whole K loop
+            o[7] = (unsigned long long)nstages;
+        }
+        t_loop1 = E2T_NOW();
+#endif
     };
     switch (wave) {          // wave-uniform
         case 0: k_loop(IC<0>{}, IC<0>{}); break;
@@ -1469,6 +1515,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             }
         }
     }
+#ifdef E2_WINO_TIMING
+    if (blockIdx.x < 64 && blockIdx.y == 0 && lane == 0) {
+        unsigned long long* o2 = e2_wino_dbg2 + (blockIdx.x * 8 + wave) * 4;
+        const unsigned long long t_end = E2T_NOW();
+        o2[0] = t_loop0 - t_entry; o2[1] = t_loop1 - t_loop0; o2[2] = t_end - t_loop1; o2[3] = t_end - t_entry;
+    }
+#endif
 }
 #endif
 
@@ -1772,6 +1825,9 @@ extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) 
 #endif
 
 #ifdef E2_WINO_TIMING
+extern "C" int e2fgvi_wino_timing_read2(unsigned long long* host_dst, int32_t n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(e2_wino_dbg2), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int e2fgvi_wino_timing_read(unsigned long long* host_dst, int32_t n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(e2_wino_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
 }
