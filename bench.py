@@ -54,10 +54,15 @@ def flops_per_clip(H, W, t, lt, hq):
     return 2e-9 * (enc + spy + off + dcn + bb + fus + ss + blk + dec)
 
 
+KERNELS = {}      # layer -> kernel of the last traced forward (bench line: config.kernels)
+
+
 def traced_work(net, x, lt):
     """One eager forward with launch tracing on: sums of the algorithmic MACs (what the reference's layers compute) and of
     the MACs actually ISSUED to the matrix pipe (Winograd layers issue 16/36 of theirs, x block / channel padding) over
-    every conv / linear / deformable-conv / attention launch."""
+    every conv / linear / deformable-conv / attention launch.  Side effect: KERNELS = {layer: kernel that ran} of that forward
+    (the eight transformer blocks and the two propagation directions collapsed when they agree)."""
+    import re
     from e2fgvi_amd import lib
     lib.TRACE = []
     try:
@@ -66,14 +71,24 @@ def traced_work(net, x, lt):
         rows = [r["meta"] for r in lib.TRACE if r["meta"] and "macs" in r["meta"]]
     finally:
         lib.TRACE = None
+    names = {}
+    for r in rows:
+        layer = re.sub(r"^transformer\.\d+\.", "transformer.*.", str(r.get("layer", "?")))
+        layer = re.sub(r"(backward_|forward_)", "*_", layer)
+        names.setdefault(layer, set()).add(str(r.get("kernel", "?")))
+    KERNELS.clear()
+    KERNELS.update({k: " | ".join(sorted(v)) for k, v in sorted(names.items()) if not k.startswith("spynet.")})
+    KERNELS["spynet.*"] = " | ".join(sorted({kk for k, v in names.items() if k.startswith("spynet.") for kk in v}))
     return 2e-9 * sum(r["macs"] for r in rows), 2e-9 * sum(r["issued"] for r in rows), len(rows)
 
 
-def cpu_baseline(sd, model, H, W, t, lt):
+def cpu_baseline(sd, model, H, W, t, lt, hip_out=None):
     """The CPU restatement of the reference forward (oracle/e2fgvi_oracle.py, kind "port": the reference's own Python
     cannot travel to the GPU box) timed on this host's cores on a bounded sample of the same workload: ONE clip,
     1 warm-up + median of 3 forwards for the 432x240 workload; the HQ resolutions take minutes per
-    clip on a CPU, there the sample is one un-warmed forward of a 2-frame clip of the same resolution."""
+    clip on a CPU, there the sample is one un-warmed forward of a 2-frame clip of the same resolution.
+    hip_out: the frames the TIMED configuration (same clip, same weights, the timed kernels) produced -- the oracle's output of
+    the first forward is compared with them and returned as the second value: the bench line carries its own parity."""
     from e2fgvi_amd.synth import synth_clip
     from oracle import e2fgvi_oracle as O
     host = os.cpu_count() or 1
@@ -85,17 +100,27 @@ def cpu_baseline(sd, model, H, W, t, lt):
     ts, ls = (t, lt) if small else (2, 2)
     x, _ = synth_clip(1, ts, H, W, seed=0, smooth=False)
     times = []
+    parity = None
     for k in range(4 if small else 1):
         t0 = time.perf_counter()
-        O.forward(sd, x, ls, model)
+        ref, _ = O.forward(sd, x, ls, model)
         times.append(time.perf_counter() - t0)
+        if k == 0 and hip_out is not None and tuple(hip_out.shape) == tuple(ref.shape):
+            d = (hip_out.double() - ref.double()).abs()
+            rms = float(ref.double().pow(2).mean().sqrt())
+            parity = {"max_abs": float("%.3e" % d.max()), "max_abs_over_rms": float("%.3e" % (float(d.max()) / rms)),
+                      "rms_of_reference": float("%.3e" % rms), "bound_max_abs": 1e-3, "vs": "oracle port (oracle/e2fgvi_oracle.py, torch CPU "
+                      "fp32) on the timed clip and weights; the HIP frames are those of the timed configuration (same engine, same "
+                      "kernel decisions as config.kernels)"}
     timed = times[1:] if small else times
     dt = statistics.median(timed)
     return {"value": round(ts / dt, 4), "unit": "frames/s", "cores": cores, "host_cores": host, "kind": "port",
             "sample": "one %s %dx%d T=%d l_t=%d clip, torch CPU fp32 on %d threads (host has %d): %s; frames/s = %d frames / "
-                      "that time" % (model, W, H, ts, ls, cores, host,
-                                     "1 warm-up + median of 3 forwards (%.1f s each)" % dt if small else
-                                     "one un-warmed forward (%.1f s)" % dt, ts)}
+                      "that time.  A lower bound on the reference's own CPU speed: the port's deformable conv is a pure-torch gather, "
+                      "the reference calls mmcv's C++ CPU op (mmcv is not in this image)"
+                      % (model, W, H, ts, ls, cores, host,
+                         "1 warm-up + median of 3 forwards (%.1f s each)" % dt if small else
+                         "one un-warmed forward (%.1f s)" % dt, ts)}, parity
 
 
 def time_local(net, x, lt, steps, warmup, use_graph=True):
@@ -117,33 +142,55 @@ def time_local(net, x, lt, steps, warmup, use_graph=True):
     return time.perf_counter() - t0, ev0.elapsed_time(ev1), bool(step.graphed)
 
 
-SECONDARY = [   # (model, H, W, t, precision, steps, warmup): BASELINE.json configs[3] and [4] on ONE GPU
-    ("e2fgvi_hq", 720, 1296, 10, "bf16", 20, 3),
-    ("e2fgvi_hq", 1080, 1944, 20, "bf16", 5, 2),
+ARITHMETIC = {
+    "fp32+x3": "fp32 tensors; contractions at fp32-level rounding: per layer either fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equivalent to "
+               "an fp32 FMA chain) or the bf16 matrix pipe with EXACTLY split operands (3 bf16 pieces per fp32 value, 6 of the 9 cross "
+               "terms as v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms < 2^-22 of a product): fp32-level, not bit-identical "
+               "to an FMA chain (tests/test_gpu_x3.py); which layer runs which: config.kernels",
+    "fp32": "fp32 tensors, every contraction on fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-equivalent to an fp32 FMA chain (E2FGVI_X3=0)",
+    "bf16": "bf16 tensors between kernels, bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; flows, DCN offsets / masks, the "
+            "token residual stream and the output frames stay fp32 (DESIGN.md 1b)",
+}
+
+SECONDARY = [   # (label, model, H, W, clips, t, l_t, precision, x3, steps, warmup)
+    ("BASELINE.json configs[1] with E2FGVI_X3=0: every fp32 layer on fp32 MFMA (no split-operand kernels)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", False, 10, 2),
+    ("SURVEY.md 8(d) C2 second split: T=10 with 5 local + 5 reference frames (configs/train_e2fgvi.json:9-10)", "e2fgvi", 240, 432, 1, 10, 5, "fp32", True, 10, 2),
+    ("BASELINE.json configs[2] per-GPU work on ONE GPU: 8 clips per forward, no collective (the N = 1 point of the 8-GPU job)", "e2fgvi", 240, 432, 8, 10, 10, "fp32", True, 5, 2),
+    ("BASELINE.json configs[3]", "e2fgvi_hq", 720, 1296, 1, 10, 10, "bf16", True, 20, 3),
+    ("BASELINE.json configs[4] (one GPU's clip)", "e2fgvi_hq", 1080, 1944, 1, 20, 20, "bf16", True, 5, 2),
 ]
 
 
-def secondary_line(dev, model, H, W, t, precision, steps, warmup):
-    """One more configuration timed in the same process after the headline (inputs resident, HIP-graph replay, one clip
-    per forward, all frames local): BASELINE.json configs[3] / [4], which name e2fgvi_hq at 720p / 1080p with bf16 MFMA."""
+def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warmup):
+    """One more configuration timed in the same process after the headline (inputs resident, HIP-graph replay)."""
     import gc
     import importlib
+    from e2fgvi_amd import engine, ops
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
-    net = importlib.import_module("model." + model).InpaintGenerator()
-    net.load_state_dict(synth_state_dict(model, "default", 0))
-    net = net.to(dev).eval()
-    net.precision = precision
-    x = synth_clip(1, t, H, W, seed=0, smooth=False)[0].to(dev)
-    net(x, t)
-    torch.cuda.synchronize()
-    gflop_alg, gflop_issued, nlaunch = traced_work(net, x, t)
-    elapsed, dev_ms, graphed = time_local(net, x, t, steps, warmup)
+    saved = (ops.X3_ENABLED, engine.FC2_CONV)
+    if precision == "fp32" and not x3:
+        ops.X3_ENABLED, engine.FC2_CONV = False, os.environ.get("E2FGVI_FC2_CONV_FP32", "0") != "0"
+    try:
+        net = importlib.import_module("model." + model).InpaintGenerator()
+        net.load_state_dict(synth_state_dict(model, "default", 0))
+        net = net.to(dev).eval()
+        net.precision = precision
+        x = synth_clip(b, t, H, W, seed=0, smooth=False)[0].to(dev)
+        torch.cuda.reset_peak_memory_stats(dev)
+        net(x, lt)
+        torch.cuda.synchronize()
+        gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
+        kernels = dict(KERNELS)
+        elapsed, dev_ms, graphed = time_local(net, x, lt, steps, warmup)
+    finally:
+        ops.X3_ENABLED, engine.FC2_CONV = saved
     secs = dev_ms * 1e-3 / steps
     peak = PEAK_TFLOPS[precision]
-    line = {"config": {"workload": "BASELINE.json configs[%d]: %s %dx%d T=%d l_t=%d, 1 clip per forward on one GPU, random-init "
-                                   "weights, torch.rand frames + box mask (SURVEY.md 8d)" % (3 if t <= 10 else 4, model, W, H, t, t),
-                       "precision": precision, "hip_graph": graphed},
-            "metric": "inpainted frames/sec at %dx%d T=%d" % (W, H, t), "value": round(t * steps / elapsed, 3), "unit": "frames/s",
+    arith = "bf16" if precision == "bf16" else ("fp32+x3" if x3 and saved[0] else "fp32")
+    line = {"config": {"workload": "%s: %s %dx%d T=%d l_t=%d, %d clip(s) per forward on one GPU, random-init weights, torch.rand "
+                                   "frames + box mask (SURVEY.md 8d)" % (label, model, W, H, t, lt, b),
+                       "precision": precision, "arithmetic": ARITHMETIC[arith], "hip_graph": graphed},
+            "metric": "inpainted frames/sec at %dx%d T=%d" % (W, H, t), "value": round(b * t * steps / elapsed, 3), "unit": "frames/s",
             "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
             "dtype": "f32" if precision == "fp32" else "bf16",
             "roofline": {"bound": "mfma", "achieved": round(gflop_issued / secs / 1e3, 2), "peak": peak, "unit": "TFLOP/s",
@@ -153,6 +200,8 @@ def secondary_line(dev, model, H, W, t, precision, steps, warmup):
                          "gflop_per_forward": {"algorithmic": round(gflop_alg, 1), "issued": round(gflop_issued, 1),
                                                "mfma_launches": nlaunch}},
             "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+    if precision == "fp32" and not x3:
+        line["config"]["kernels"] = kernels
     del net, x
     gc.collect()
     torch.cuda.empty_cache()
@@ -190,7 +239,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import importlib
-    from e2fgvi_amd import runner
+    from e2fgvi_amd import ops, runner
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
 
     H, W = [int(v) for v in args.hw.lower().split("x")]
@@ -210,9 +259,11 @@ def main():
     x = x.to(dev)
     # Build the engine (weight re-layout, tile tuning, stream creation) BEFORE RCCL comes up: measured on MI355X, a
     # forward whose engine was built after init_process_group runs ~4 % slower (17.8 vs 17.15 ms)
+    torch.cuda.reset_peak_memory_stats(dev)
     net(x, lt)
     torch.cuda.synchronize()
     gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)      # per forward of b clips
+    kernels = dict(KERNELS)
     same_work = None
     if world > 1 or args.force_dist:
         # the like-for-like single-GPU number of this job's per-GPU work: the same clips, the same HIP-graph replay, no
@@ -285,6 +336,10 @@ def main():
                                "random-init weights, torch.rand frames + box mask (SURVEY.md 8d)"
                                % (config_no - 1, args.model, W, H, t, lt, b, b * world),
                    "clips_per_gpu": b, "precision": args.precision,
+                   "arithmetic": ARITHMETIC["bf16" if args.precision == "bf16" else ("fp32+x3" if ops.X3_ENABLED else "fp32")],
+                   "kernels": kernels,
+                   "kernel_selection": ("timed on this box (E2FGVI_AUTOTUNE=1)" if ops.AUTOTUNE else
+                                        "e2fgvi_amd/tile_table.py (checked in, deterministic: ops.py)"),
                    "parallelism": "clip-shard x%d + all-gather of the %s frames" % (world, args.gather) if dist is not None
                                   else "single GPU, no collective",
                    "hip_graph": bool(step.graphed)},
@@ -315,7 +370,7 @@ def main():
     elif b == 1 and (t, lt) == (10, 10) and hq and (H, W) == (720, 1296) and args.precision == "bf16":
         traffic_cfg = "_hq720_bf16"
     if traffic_cfg is not None:
-        for tag in ("r03", "r02", "r01"):
+        for tag in ("r04", "r03", "r02", "r01"):
             tfile = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (tag, traffic_cfg))
             if os.path.exists(tfile):
                 try:
@@ -346,8 +401,15 @@ def main():
                 except Exception:
                     pass
             out["roofline"]["dominant_kernel"] = dom
+        out["peak_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, args.model, H, W, t, lt)
+            # the frames of the timed configuration (clip 0 of this rank = the oracle's clip: synth_clip seed 0), computed by the
+            # very engine / kernel decisions / HIP graph that were timed
+            hip_frames = step.finish()
+            hip_frames = (hip_frames if hip_frames is not None else net(x, lt)[0])[:t].float().cpu() if not step.pack_u8 else None
+            out["cpu_baseline"], parity = cpu_baseline(sd, args.model, H, W, t, lt, hip_out=hip_frames)
+            if parity is not None:
+                out["parity"] = parity
     if same_work is not None:
         out["single_gpu_same_work"] = same_work
     if dist is not None:
@@ -362,12 +424,15 @@ def main():
             try:
                 out["secondary"].append(secondary_line(dev, *cfg))
             except Exception as e:                    # the headline line must survive a failure here
-                out["secondary"].append({"config": {"workload": "%s %dx%d T=%d %s" % (cfg[0], cfg[2], cfg[1], cfg[3], cfg[4])},
+                out["secondary"].append({"config": {"workload": "%s: %s %dx%d T=%d %s" % (cfg[0], cfg[1], cfg[3], cfg[2], cfg[5], cfg[7])},
                                          "error": str(e).splitlines()[0][:300]})
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)        # C stdio first (RCCL's banner), so that the JSON line is the last line on stdout
         print(json.dumps(out), flush=True)
+        if out.get("parity") and not out["parity"]["max_abs"] <= out["parity"]["bound_max_abs"]:
+            raise SystemExit("parity of the timed configuration: max |hip - oracle| = %g > %g"
+                             % (out["parity"]["max_abs"], out["parity"]["bound_max_abs"]))
 
 
 if __name__ == "__main__":

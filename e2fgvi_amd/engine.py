@@ -89,7 +89,11 @@ class _NotBuilt:
 
 class Engine(BF16Path):
     def __init__(self, state_dict, model="e2fgvi", device="cuda", precision="fp32", winograd=True, autotune=True):
-        """precision="fp32": every contraction on fp32 MFMA (the default and the parity configuration).
+        """precision="fp32": fp32 tensors, every contraction with fp32-level rounding (the default and the parity configuration):
+        on the fp32 MFMA instructions (bit-equivalent to an fp32 FMA chain) or -- ops.X3_ENABLED, the default -- on the bf16 matrix
+        pipe with exactly split operands (three bf16 pieces per fp32 value, six of the nine cross terms, fp32 accumulation: fp32-
+        level, not bit-identical to an FMA chain; tests/test_gpu_x3.py).  Which of the two a layer runs comes from the decision
+        table (ops.py); E2FGVI_X3=0 gives the pure fp32-MFMA configuration.
         precision="bf16": the bf16 data path of engine_x.py (BASELINE.json HQ configurations): bf16 activations in HBM,
         every conv / linear / attention product on bf16 MFMA with fp32 accumulation; SPyNet, the flows, the DCN offsets
         and masks, the deformable conv's arithmetic and the token residual stream stay fp32."""
@@ -221,9 +225,10 @@ class Engine(BF16Path):
         for lv, convs in enumerate(self.spy):
             for j, c in enumerate(convs):
                 c.name = "spynet.%d.%d" % (lv, j)
-        if autotune and precision == "fp32" and os.environ.get("E2FGVI_AUTOTUNE", "1") != "0":
+        if autotune and precision == "fp32":
             # GEMM-shaped layers (token Linears, soft split / composite): the best implicit-GEMM tile depends on the
-            # token count; time the candidates on the first call of each size (eager warm-up, never under graph capture)
+            # token count; their tile code comes from the decision table of ops.py (e2fgvi_amd/tile_table.py by default,
+            # timed on the first eager call of each size class under E2FGVI_AUTOTUNE=1)
             for blk in self.blocks:
                 for k in ("qkv", "proj", "fc1", "fc2"):
                     blk[k].tune = True
@@ -251,7 +256,7 @@ class Engine(BF16Path):
         # side stream is built without them (csrc/misc.hip and the `nopk` build of conv.hip, e2fgvi_amd/build.py).
         self.overlap_flows = True
         if self.bf16:
-            self.autotune_x = autotune and os.environ.get("E2FGVI_AUTOTUNE", "1") != "0"
+            self.autotune_x = autotune
             self._init_x(f)
         self._side = None
         torch.cuda.synchronize(self.device)

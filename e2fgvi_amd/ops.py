@@ -67,14 +67,21 @@ W3_BASE = 40000
 # (+ 1000: LDS-DMA patch staging with two stages of lookahead -- measured slower everywhere; 5132: four positions per wave in
 #  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
 #  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
-W3_CANDIDATES = (132, 164, 32, 5132, 6064)
-_TUNED = {}      # (layer geometry, input size) -> tile code; shared by all layers of the same geometry (the 8 blocks)
-# The decisions are persisted: read from / appended to a per-library-build file next to the library (e2fgvi_amd/.tile_cache/,
-# or $E2FGVI_CACHE_DIR), so that
-# a served model pays the ~20 tuning launches per layer and size class once per machine, every process (and every rank of
-# a sharded job) replays the same tiles, and a profiled run (rocprofv3, tools/profile.sh) contains no tuning launches.
-#   E2FGVI_TUNE_FILE=<path>   use that file instead          E2FGVI_TUNE_FILE=0 (or empty)   do not persist
-# The default file name carries the size and mtime of libe2fgvi_hip.so: a rebuilt library starts a new table.
+W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.environ.get("E2FGVI_W3_SKIP", "").split(","))     # E2FGVI_W3_SKIP=6064: A/B runs
+_TUNED = {}      # (layer geometry, input size class) -> tile code; shared by all layers of the same geometry (the 8 blocks)
+# Kernel selection is DETERMINISTIC by default (round 4): the decisions come from the checked-in table e2fgvi_amd/tile_table.py
+# (generated on an MI355X by tools/make_tile_table.py from timed runs of the BASELINE configurations), looked up by layer
+# geometry and size class; a geometry the table does not hold at this size takes its decision at the nearest tabled size class,
+# and one it does not hold at all runs the library's static default.  No timing, no files: two processes -- and every rank of a
+# sharded job -- run the same kernels in the same accumulation order and return the same bits.
+#   E2FGVI_AUTOTUNE=1   time the candidates on the first eager call of each (geometry, size class) instead (what generates the
+#                       table); those decisions are persisted per library build under e2fgvi_amd/.tile_cache/ (or
+#                       $E2FGVI_CACHE_DIR; E2FGVI_TUNE_FILE=<path> names the file, =0 disables) so that a profiled run replays them
+#   E2FGVI_TILE_TABLE=0 ignore the table (every layer on its static default kernel)
+AUTOTUNE = os.environ.get("E2FGVI_AUTOTUNE", "0") == "1"
+TUNE_REPS = max(1, int(os.environ.get("E2FGVI_TUNE_REPS", "1") or 1))      # x the timed launches per candidate (table generation: 4)
+TABLE_FORMAT = 2          # bump when the meaning of a key field or of a tile code changes: older tables / cache files are ignored
+_SIZE_FIELD = 8           # position of the size class in both key layouts (PackedConv / PackedConvX)
 
 
 def _default_tune_file():
@@ -82,24 +89,36 @@ def _default_tune_file():
         st = os.stat(_L.LIB_PATH)
         d = os.environ.get("E2FGVI_CACHE_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), ".tile_cache")
         os.makedirs(d, exist_ok=True)
-        return os.path.join(d, "tiles_%x_%x.txt" % (st.st_size, int(st.st_mtime)))
-    except OSError:
+        dev = "gpu"
+        if torch.cuda.is_available():
+            dev = "".join(ch for ch in torch.cuda.get_device_properties(0).gcnArchName.split(":")[0] if ch.isalnum())
+        return os.path.join(d, "tiles_v%d_%s_%x_%x.txt" % (TABLE_FORMAT, dev, st.st_size, int(st.st_mtime)))
+    except (OSError, RuntimeError):
         return None
 
 
-_TUNE_FILE = os.environ.get("E2FGVI_TUNE_FILE")
-if _TUNE_FILE is None:
-    _TUNE_FILE = _default_tune_file()
-elif _TUNE_FILE in ("", "0"):
-    _TUNE_FILE = None
-if _TUNE_FILE and os.path.exists(_TUNE_FILE):
-    import ast
-    for _line in open(_TUNE_FILE):
-        try:
-            _k, _v = ast.literal_eval(_line)
-            _TUNED[_k] = _v
-        except Exception:           # a torn line of a concurrent writer: that geometry is simply tuned again
-            pass
+_TUNE_FILE = None
+if AUTOTUNE:
+    _TUNE_FILE = os.environ.get("E2FGVI_TUNE_FILE")
+    if _TUNE_FILE is None:
+        _TUNE_FILE = _default_tune_file()
+    elif _TUNE_FILE in ("", "0"):
+        _TUNE_FILE = None
+    if _TUNE_FILE and os.path.exists(_TUNE_FILE):
+        import ast
+        for _line in open(_TUNE_FILE):
+            try:
+                _k, _v = ast.literal_eval(_line)
+                _TUNED[_k] = _v
+            except Exception:           # a torn line of a concurrent writer: that geometry is simply tuned again
+                pass
+elif os.environ.get("E2FGVI_TILE_TABLE", "1") != "0":
+    try:
+        from . import tile_table as _tt
+        if getattr(_tt, "TABLE_FORMAT", None) == TABLE_FORMAT:
+            _TUNED.update(_tt.TILES)
+    except ImportError:
+        pass
 
 
 def _remember(key, tile):
@@ -113,10 +132,29 @@ def _remember(key, tile):
     return tile
 
 
+def _decision(key):
+    """the tile code recorded for `key`; without timing-based tuning also the one of the nearest tabled size class of the same
+    geometry (a decision taken a quarter octave away is still a good one, and it is the same in every process)"""
+    best = _TUNED.get(key)
+    if best is not None or AUTOTUNE:
+        return best
+    hit = _NEAREST.get(key)
+    if hit is None:
+        sc = key[_SIZE_FIELD]
+        cands = [(abs(k[_SIZE_FIELD] - sc), k[_SIZE_FIELD], v) for k, v in _TUNED.items()
+                 if len(k) == len(key) and k[:_SIZE_FIELD] == key[:_SIZE_FIELD] and k[_SIZE_FIELD + 1:] == key[_SIZE_FIELD + 1:]]
+        hit = _NEAREST[key] = (min(cands)[2] if cands else -1)
+    return None if hit < 0 else hit
+
+
+_NEAREST = {}
+
+
 def sync_tile_decisions(group=None, src=0):
-    """Sharded jobs: every rank adopts rank `src`'s tile table, so that all ranks run the same kernels in the same
-    accumulation order (tile choices are timed per process and the row-shift / LDS-DMA alternatives order their K loop
-    differently: without this the ranks' frames could differ in the last bits).  Call after the first (tuning) forward."""
+    """Sharded jobs under E2FGVI_AUTOTUNE=1: every rank adopts rank `src`'s tile table, so that all ranks run the same kernels
+    in the same accumulation order (timed choices differ per process, and the alternatives order their K loop differently).
+    Call after the first (tuning) forward.  With the default table-driven selection every rank already holds the same table
+    and the broadcast only confirms it."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return False
@@ -124,6 +162,7 @@ def sync_tile_decisions(group=None, src=0):
     dist.broadcast_object_list(box, src=src, group=group)
     _TUNED.clear()
     _TUNED.update(box[0])
+    _NEAREST.clear()
     return True
 
 
@@ -135,9 +174,10 @@ class PackedConv:
     """
 
     def __init__(self, weight, bias, cpg, groups=1, stride=1, pad=0, bk=None, precision="fp32", algo="igemm"):
-        """precision: "fp32" only (fp32 MFMA, bit-equivalent to an fp32 FMA chain); the bf16 data path has its own layer
-        class, PackedConvX (round 1's "fp32 tensors, bf16 products" mode moved to tools/probe/ as the cross-stream
-        reproducer's aggressor).
+        """precision: "fp32" only: fp32 tensors and fp32-level rounding -- the layer's own kernels are fp32 MFMA (bit-equivalent
+        to an fp32 FMA chain); with try_x3 the decision table may hand the call to the split-operand kernels (three exact bf16
+        pieces per operand, six bf16 MFMA terms per product: fp32-level, not bit-identical).  The bf16 data path has its own
+        layer class, PackedConvX.
         algo: "igemm" (implicit GEMM), "winograd" (fp32 F(2x2,3x3) only; 3x3 / stride 1 / pad 1, every cpg % 4 == 0,
         even H and W at call time, NHWC output) or "auto" (both packings; Winograd whenever a call qualifies)."""
         lib = _L.load()
@@ -271,12 +311,14 @@ class PackedConv:
             if fn(C.byref(d), st) != 0:                          # not instantiated / not applicable to this packing
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(2):
-                fn(C.byref(d), st)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
+            ms = float("inf")
+            for _ in range(TUNE_REPS):                               # best of TUNE_REPS measurements of 2 launches
+                e0.record()
+                for _ in range(2):
+                    fn(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                ms = min(ms, e0.elapsed_time(e1))
             if ms < best_ms:
                 best, best_ms = code, ms
         d.tile = 0
@@ -395,6 +437,7 @@ class PackedConv:
                 raise ValueError("residual shape %s != [%d,%d,%d,*]" % (tuple(residual.shape), N, Ho, Wo))
             d.residual, d.res_ld, d.res_coff = residual.data_ptr(), residual.shape[3], res_coff
         d.act, d.slope, d.tile = act, slope, tile
+        tile0 = tile                                   # the static rule's kernel: what a rejected alternative falls back to
         w4c = W4_CODES.get(tile) if use_wino else None
 
         def launch_w3(shape):
@@ -423,10 +466,13 @@ class PackedConv:
         if auto_tile and (tile == 0 or not self.tune) and (self.tune or x3) and self.precision == "fp32" and N * Ho * Wo >= 2048:
             # one decision per (layer geometry, size class): row counts within a quarter octave share the tile, so the
             # slightly different window lengths of a video (t = 17 ... 21 frames) do not each pay for a tuning pass
+            # (the fp32 baseline the alternatives are measured against is part of the key: a tuned layer and an untuned one of the
+            #  same geometry, or the F(2x4) / F(2x2) Winograd baselines, do not share a verdict)
             key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk,
-                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino) + (("x3",) if x3 else ())
-            best = _TUNED.get(key)
-            if best is None and not torch.cuda.is_current_stream_capturing() and (
+                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino, bool(self.tune), int(tile)) + (("x3",) if x3 else ())
+            best = _decision(key)
+            from_table = best is not None
+            if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
                 best = self._autotune(lib, d, use_wino) if self.tune else d.tile
                 mine = None
@@ -434,12 +480,15 @@ class PackedConv:
                 def time_mine():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     launch()
-                    e0.record()
-                    for _ in range(3):
-                        launch()
-                    e1.record()
-                    e1.synchronize()
-                    return e0.elapsed_time(e1) / 3
+                    t = float("inf")
+                    for _ in range(TUNE_REPS):
+                        e0.record()
+                        for _ in range(3):
+                            launch()
+                        e1.record()
+                        e1.synchronize()
+                        t = min(t, e0.elapsed_time(e1) / 3)
+                    return t
                 if self.tune and not use_wino and not self.nopk and self._alt() is not None:
                     # the LDS-DMA fp32 kernel on the very same call: codes 2000 + its tile
                     d.tile = best
@@ -462,29 +511,41 @@ class PackedConv:
                         if launch_w3(shape)[0] != 0:
                             continue
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        for _ in range(3):
-                            launch_w3(shape)
-                        e1.record()
-                        e1.synchronize()
-                        w3[shape] = e0.elapsed_time(e1) / 3
+                        w3[shape] = float("inf")
+                        for _ in range(TUNE_REPS):
+                            e0.record()
+                            for _ in range(3):
+                                launch_w3(shape)
+                            e1.record()
+                            e1.synchronize()
+                            w3[shape] = min(w3[shape], e0.elapsed_time(e1) / 3)
                     # the margin is for leaving the fp32 kernel; among the block shapes of the split kernel the fastest wins
                     if w3 and min(w3.values()) < X3_MARGIN * mine:
                         best, mine = W3_BASE + min(w3, key=w3.get), min(w3.values())
                 best = _remember(key, best)
-            if best and best >= W3_BASE:
-                w3_tile = best - W3_BASE
-            elif best and best >= X3_BASE:
-                return self._alt3()(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
-                                    tile=best - X3_BASE, out_nchw=out_nchw)
-            if best and self.tune and 2000 <= best < 2100:
-                return self._alt()(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
-                                   tile=best - 2000, out_nchw=out_nchw)
-            if self.tune and w3_tile is None:
-                d.tile = best or 0
+            try:
+                if best and best >= W3_BASE and self._wino_x3() is not None:
+                    w3_tile = best - W3_BASE
+                elif best and X3_BASE <= best < W3_BASE and self._alt3() is not None:
+                    return self.alt3(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
+                                     tile=best - X3_BASE, out_nchw=out_nchw)
+                elif best and self.tune and 2000 <= best < 2100 and self._alt() is not None:
+                    return self.alt(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
+                                    tile=best - 2000, out_nchw=out_nchw)
+                elif self.tune and best is not None and best < 2000:
+                    d.tile = best
+            except _L.HipError:
+                # a decision taken at a neighbouring size class (or an older cache entry) that this call's shape rejects: the
+                # layer's own fp32 kernel runs instead
+                if not from_table:
+                    raise
+                w3_tile = None
         if _L.TRACE is not None:
             _L.annotate(**self._work(N, H, W, Ho, Wo, use_wino, d.tile if w3_tile is None else W3_BASE + w3_tile))
         rc, what = launch()
+        if rc != 0 and (w3_tile is not None or d.tile != tile0):
+            w3_tile, d.tile = None, tile0          # a tabled block shape this call's geometry rejects: the static default
+            rc, what = launch()
         _L.check(rc, what)
         return out
 
@@ -650,8 +711,8 @@ class PackedConvX:
         if tile == 0 and self.tune and N * Ho * Wo >= 2048:
             key = (("x3" if self.x3 else ("x32+3" if x3 else "x32")) if self.f32 else "x", self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups,
                    int(4.0 * math.log2(N * Ho * Wo)), _dt(out), out_nchw, self.taps)
-            best = _TUNED.get(key)
-            if best is None and not torch.cuda.is_current_stream_capturing() and (
+            best = _decision(key)
+            if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing() and (
                     residual is None or residual.data_ptr() != out.data_ptr()):
                 res = self._time_tiles(d)
                 best = min(res, key=res.get) if res else 0
@@ -660,10 +721,13 @@ class PackedConvX:
                     if res3 and (not res or min(res3.values()) < X3_MARGIN * min(res.values())):
                         best = X3_BASE + min(res3, key=res3.get)
                 best = _remember(key, best)
-            if best and best >= X3_BASE:
-                return self._alt3()(srcs, out=out, out_dtype=out_dtype, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act,
-                                    slope=slope, out2=out2, tile=best - X3_BASE, out_nchw=out_nchw)
-            d.tile = tile = best or 0
+            if best and best >= X3_BASE and self._alt3() is not None:
+                try:
+                    return self.alt3(srcs, out=out, out_dtype=out_dtype, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act,
+                                     slope=slope, out2=out2, tile=best - X3_BASE, out_nchw=out_nchw)
+                except _L.HipError:                       # a neighbouring size class's tile that this shape rejects
+                    best = 0
+            d.tile = tile = (best or 0) if (best or 0) < X3_BASE else 0
         if _L.TRACE is not None:
             cin_g, cout_g, K2 = sum(self.cpg), self.Cout // self.groups, self.KH * self.KW
             kc = 32 if self.f32 else 64
@@ -677,7 +741,11 @@ class PackedConvX:
                         # x3: six bf16 MACs per product, counted in fp32-pipe equivalents (a bf16 MAC occupies the matrix
                         # pipe for 157.3 / 2500 of the time of an fp32 MAC): `issued / fp32 peak` stays matrix-pipe time
                         issued=int(N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2 * (6 * 157.3 / 2500.0 if self.x3 else 1)))
-        _L.check(self._fn(C.byref(d), _stream()), "conv2d_x")
+        rc = self._fn(C.byref(d), _stream())
+        if rc != 0 and d.tile and self.tune:
+            d.tile = 0                                    # a tabled tile this call's geometry rejects: the library's default
+            rc = self._fn(C.byref(d), _stream())
+        _L.check(rc, "conv2d_x")
         return out
 
     def _time_tiles(self, d, reps=3, rounds=2):
@@ -688,7 +756,7 @@ class PackedConvX:
         d.tile = 0
         for _ in range(2):
             self._fn(C.byref(d), st)
-        for _ in range(rounds):
+        for _ in range(rounds * TUNE_REPS):
             rowshift = (self.KH, self.KW, self.stride, self.pad) == (3, 3, 1, 1) and not self.f32 and not self.taps
             for code in XTUNE_CANDIDATES + (XTUNE_ROWSHIFT if rowshift else ()):
                 if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers

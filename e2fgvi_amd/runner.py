@@ -63,11 +63,7 @@ class ShardedStep:
         self._gathered = None
         self._pending = None       # (work, gathered buffer) of the step whose gather is in flight
         self._last = None
-        if group_world > 1:
-            # every rank replays rank 0's tile choices (they are timed per process): same kernels, same accumulation order,
-            # bit-identical frames from every rank for identical clips -- before the graph capture freezes the choices
-            from . import ops
-            ops.sync_tile_decisions(group)
+        self._synced = group_world <= 1
 
     def _forward(self):
         out, _ = self.net(self.x, self.lt)
@@ -96,6 +92,18 @@ class ShardedStep:
             self.graph = None
             torch.cuda.synchronize()
 
+    def _sync_decisions(self):
+        """Every rank replays rank 0's tile decisions: same kernels, same accumulation order, bit-identical frames from every
+        rank for identical clips.  With the default table-driven selection (ops.py) the ranks agree by construction; under
+        E2FGVI_AUTOTUNE=1 each rank times its own candidates during its FIRST eager forward, so the broadcast has to come
+        after that forward and before the graph capture (or the second eager forward) freezes the choices: the first call of
+        run() is this rank's tuning forward, its output is recomputed with rank 0's table when the tables differed."""
+        from . import ops
+        self._synced = True
+        mine = dict(ops._TUNED)
+        if ops.sync_tile_decisions(self.group) and ops._TUNED != mine:
+            self.out = self._forward()
+
     def run(self):
         if self.use_graph and self.graph is None and self._calls >= 1:
             self._capture()
@@ -104,6 +112,8 @@ class ShardedStep:
             self.graph.replay()
         else:
             self.out = self._forward()
+            if not self._synced:
+                self._sync_decisions()
         if not self.gather:
             self._last = self.out
             return self.out

@@ -31,6 +31,12 @@ CASES = [
     # over the whole grid -- branches the small fixtures never reach.  Few frames keep the CPU run to minutes.
     ("g5_hq_stress_720x1296_t3_lt2", "e2fgvi_hq", "stress", (720, 1296), 3, 2, 1, 15),
     ("g6_hq_stress_1080x1944_t2_lt2", "e2fgvi_hq", "stress", (1080, 1944), 2, 2, 1, 16),
+    # round 4: the headline configuration itself (BASELINE.json configs[1]: 432x240, T = 10, all frames local) and SURVEY.md
+    # 8(d)'s second split (T = 10, 5 local + 5 reference frames, configs/train_e2fgvi.json:9-10) from the REAL reference,
+    # stress weights -- the kernels the engine selects only at full size (10-frame batches) are then checked against the
+    # reference's own output, not only against the port
+    ("g7_e2fgvi_stress_t10_lt10", "e2fgvi", "stress", (240, 432), 10, 10, 1, 17),
+    ("g8_e2fgvi_stress_t10_lt5", "e2fgvi", "stress", (240, 432), 10, 5, 1, 18),
 ]
 OUT_STRIDE, FLOW_STRIDE = 8, 4
 

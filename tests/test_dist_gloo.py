@@ -108,12 +108,29 @@ def _step_worker(rank, world, port, q):
         g = outs[k]
         ok = ok and bool((g[:2] == float(k)).all()) and bool((g[2:] == 100.0 + k).all())
     ok = ok and step.finish() is not None and bool((step.finish()[:2] == 4.0).all())       # idempotent
-    # tile decisions: the ranks tuned differently (per-process timing) -> after constructing a step all hold rank 0's table
+    # tile decisions: the table starts EMPTY on every rank and each rank's first (tuning) forward decides differently (per-process
+    # timing, stubbed: the net records a rank-dependent decision when it runs) -> the first run() ends with every rank holding
+    # rank 0's table and with its output recomputed under it (advisor, round 3: the sync used to sit in the constructor, before
+    # any tuning forward had run)
     from e2fgvi_amd import ops
     ops._TUNED.clear()
-    ops._TUNED.update({("geom", 1): 100 + rank, ("only-rank-%d" % rank,): 7})
-    ShardedStep(_StepNet(rank), torch.zeros(1, 2, 3, 4, 4), 2, group_world=world, use_graph=False)
-    ok = ok and ops._TUNED == {("geom", 1): 100, ("only-rank-0",): 7}
+
+    class _TuningNet(_StepNet):
+        def __call__(self, x, lt):
+            ops._TUNED.setdefault(("geom", 1), 1 + self.rank)            # what a timed first call does: a per-rank decision
+            ops._TUNED.setdefault(("only-rank-%d" % self.rank,), 7)
+            out, fl = super().__call__(x, lt)
+            return out + 1000.0 * ops._TUNED[("geom", 1)], fl             # the "kernel choice" shows in the output
+
+    tstep = ShardedStep(_TuningNet(rank), torch.zeros(1, 2, 3, 4, 4), 2, group_world=world, use_graph=False)
+    ok = ok and ops._TUNED == {}
+    ok = ok and tstep.run() is None
+    ok = ok and ops._TUNED[("geom", 1)] == 1 and ("only-rank-0",) in ops._TUNED       # rank 0's table, on both ranks
+    g1 = tstep.finish()
+    # rank 0 kept its first forward (call 1, decision 1: 1001); rank 1's first forward ran under its own decision (2101) and was
+    # recomputed under rank 0's (call 2: 100 + 2 + 1000)
+    ok = ok and bool((g1[:2] == 1001.0).all()) and bool((g1[2:] == 1102.0).all())
+    ops._TUNED.clear()
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

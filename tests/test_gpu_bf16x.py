@@ -472,8 +472,10 @@ def test_fp32_layers_may_pick_the_lds_dma_kernel(dev):
     lin = ops.PackedLinear(w.to(dev), b.to(dev))
     lin.tune = True
     ref = F.linear(x.double(), w.double(), b.double())
-    for _ in range(2):                        # first call tunes, second replays the decision
-        assert_close(lin(x.to(dev)).cpu(), ref, fp32_tol(512), "tuned linear")
+    from tests.util import timed_tuning
+    with timed_tuning():
+        for _ in range(2):                        # first call tunes, second replays the decision
+            assert_close(lin(x.to(dev)).cpu(), ref, fp32_tol(512), "tuned linear")
     key = [k for k in ops._TUNED if k[0] == 1536 and k[1] == (512,)]
     assert key, "no tuning decision recorded"
     print("qkv-shaped fp32 linear: tile code", ops._TUNED[key[0]])

@@ -104,6 +104,10 @@ E2E = [("e2fgvi", "stress", (240, 432), 3, 3, 1), ("e2fgvi", "default", (240, 43
        # non-square window grids: 3x2 windows (token grid 15x18), 1x2 windows, a single window
        ("e2fgvi_hq", "stress", (180, 216), 3, 3, 1), ("e2fgvi_hq", "stress", (60, 216), 4, 2, 1),
        ("e2fgvi_hq", "default", (60, 108), 2, 2, 3),
+       # SURVEY.md 8(d) C2, second split: T = 10 with 5 local + 5 reference frames (configs/train_e2fgvi.json:9-10) -- 10-frame
+       # batches in the encoder / transformer / decoder (the kernels the decision table selects only at full size), 5-frame
+       # propagation; and two clips of it
+       ("e2fgvi", "stress", (240, 432), 10, 5, 1), ("e2fgvi", "default", (240, 432), 10, 5, 1), ("e2fgvi", "stress", (240, 432), 10, 5, 2),
        # a single local frame (test.py on a 1-frame video): empty flow tensors, propagation without neighbours
        ("e2fgvi_hq", "stress", (60, 108), 3, 1, 1), ("e2fgvi", "stress", (240, 432), 1, 1, 1)]
 
@@ -130,7 +134,10 @@ def test_end_to_end(dev, model, kind, hw, t, lt, b):
     assert torch.isfinite(got).all()
     tag = "e2e %s %s %s t=%d lt=%d b=%d" % (model, kind, hw, t, lt, b)
     assert_bound(d, 1e-3, tag + " output max abs (north star 1e-3)")
-    assert_bound(r, 2e-2, tag + " output max abs / rms")
+    # measured on MI355X over four data sets: <= 2.1e-5 x rms (gpurun_out/soak, profiles/r03_gpu_suite_soak_summary.txt); the bound
+    # is 10 x that -- a 1e-3 absolute bound alone is 12 % of the output rms at default init and would let a 1 % bug in a kernel
+    # that only runs at full size pass
+    assert_bound(r, 2e-4, tag + " output max abs / rms")
 
 
 # --------------------------------------------------------------------------- golden fixtures (real reference)
@@ -161,7 +168,7 @@ def test_hip_matches_reference_golden(dev, path):
     print("golden %s: max abs %.3e (rms of reference %.3e)" % (os.path.basename(path), d, rms))
     tag = "golden " + os.path.basename(path)
     assert_bound(d, 1e-3, tag + " output max abs (north star 1e-3)")
-    assert_bound(d, 2e-2 * rms, tag + " output max abs vs 2 % of rms")
+    assert_bound(d, 2e-4 * rms, tag + " output max abs vs 2e-4 x rms (10 x the measured worst)")
     fmax = max(1.0, float(z["flow_fwd_stats"][3]))
     assert_bound(np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max(), 1e-3 * fmax, tag + " flow fwd")
     assert_bound(np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max(), 1e-3 * fmax, tag + " flow bwd")
@@ -207,7 +214,7 @@ def test_full_size_against_oracle(dev):
         d, r = err(got, ref)
         print("full size %s: max abs %.3e (%.2e x rms)" % (kind, d, r))
         assert_bound(d, 1e-3, "full size 432x240 T=10 %s output max abs (north star 1e-3)" % kind)
-        assert_bound(r, 2e-2, "full size 432x240 T=10 %s output max abs / rms" % kind)
+        assert_bound(r, 2e-4, "full size 432x240 T=10 %s output max abs / rms (10 x the measured worst)" % kind)
         assert_bound(err(ff, rf)[0], 1e-3 * max(1.0, rf.abs().max().item()), "full size %s flows" % kind)
 
 

@@ -167,8 +167,10 @@ def test_fp32_layers_may_pick_the_split_kernel(dev):
     ref = F.linear(x.double(), w.double(), b.double())
     lin = ops.PackedLinear(w.to(dev), b.to(dev))
     lin.tune = lin.try_x3 = True
-    for _ in range(2):                        # first call tunes, second replays the decision
-        assert_close(lin(x.to(dev)).cpu(), ref, fp32_tol(512), "tuned linear with the x3 alternative")
+    from tests.util import timed_tuning
+    with timed_tuning():
+        for _ in range(2):                        # first call tunes, second replays the decision
+            assert_close(lin(x.to(dev)).cpu(), ref, fp32_tol(512), "tuned linear with the x3 alternative")
     key = [k for k in ops._TUNED if k[0] == 1960 and k[1] == (512,) and k[-1] == "x3"]
     assert key, "no tuning decision recorded"
     print("fc1-shaped fp32 linear: tile code", ops._TUNED[key[0]])
@@ -178,14 +180,16 @@ def test_fp32_layers_may_pick_the_split_kernel(dev):
     conv = ops.PackedConv(wc.to(dev), None, [128], pad=1, algo="auto")
     conv.try_x3 = True
     refc = conv64(nchw(xc), wc, padding=1)
-    for _ in range(2):
-        assert_close(nchw(conv([xc.to(dev)]).cpu()), refc, 3e-5, "winograd layer with the x3 alternative")
+    with timed_tuning():
+        for _ in range(2):
+            assert_close(nchw(conv([xc.to(dev)]).cpu()), refc, 3e-5, "winograd layer with the x3 alternative")
     saved = ops.X3_ENABLED
     try:
         ops.X3_ENABLED = False
         lin2 = ops.PackedLinear(w.to(dev), b.to(dev))
         lin2.tune = lin2.try_x3 = True
-        lin2(x.to(dev))
+        with timed_tuning():
+            lin2(x.to(dev))
         assert lin2.alt3 is None
     finally:
         ops.X3_ENABLED = saved

@@ -58,3 +58,56 @@ def test_tennis_clip_bf16_path_in_db(dev):
     print("tennis e2fgvi_hq bf16 vs fp32 reference inside the holes: PSNR %.2f dB, max |diff| %d grey levels, mean |diff| %.3f"
           % (psnr, np.abs(d).max(), np.abs(d).mean()))
     assert psnr > 40.0
+
+
+RELEASED = {"e2fgvi": "E2FGVI-CVPR22.pth", "e2fgvi_hq": "E2FGVI-HQ-CVPR22.pth"}      # /root/reference/README.md:125-135
+
+
+def released_checkpoint(model):
+    """path of the released checkpoint of `model` if one has been put under release_model/ (the place the reference's README
+    names) or $E2FGVI_RELEASE_DIR, else None -- the files cannot be fetched in this environment (no network)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for d in (os.environ.get("E2FGVI_RELEASE_DIR"), os.path.join(root, "release_model")):
+        if d and os.path.exists(os.path.join(d, RELEASED[model])):
+            return os.path.join(d, RELEASED[model])
+    return None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["e2fgvi", "e2fgvi_hq"])
+def test_tennis_clip_with_released_checkpoint(dev, model):
+    """SURVEY.md 8(f) rank 2 in full, whenever a released checkpoint is present: the reference's demo clip through
+    video.inpaint_video with the RELEASED weights (load_checkpoint on the file test.py:119-120 loads), against the restated
+    test.py loop (oracle/video_ref.py) around the CPU oracle with the same weights on the first 11 frames -- real offsets, real
+    attention statistics.  Skipped while release_model/ holds no checkpoint."""
+    path = released_checkpoint(model)
+    if path is None:
+        pytest.skip("no released checkpoint under release_model/ (%s): cannot be fetched here" % RELEASED[model])
+    import torch
+    from e2fgvi_amd import video
+    from oracle import e2fgvi_oracle as O
+    from oracle import video_ref
+    z = np.load(GOLD)
+    n = 11
+    frames, masks_raw = z["frames"][:n], z["masks_raw"][:n]
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_checkpoint(path)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    net = net.to(dev).eval()
+    out = video.inpaint_video(net, frames, masks_raw)
+    masks = video.prepare_masks(masks_raw, frames.shape[1:3], dev).cpu().numpy()
+    ref = video_ref.run(lambda x, lt: O.forward(sd, x, lt, model)[0], [f for f in frames], [m for m in masks])
+    d = np.abs(out.astype(int) - ref.astype(int))
+    print("tennis %s, released weights: max grey-level diff %d, differing samples %.4f" % (model, d.max(), (d > 0).mean()))
+    assert d.max() <= 1 and (d > 0).mean() < 0.02
+
+
+def test_released_checkpoint_lookup(tmp_path, monkeypatch):
+    """the lookup the test above relies on: finds a file under $E2FGVI_RELEASE_DIR, returns None when there is none"""
+    monkeypatch.delenv("E2FGVI_RELEASE_DIR", raising=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "release_model", RELEASED["e2fgvi"])):
+        assert released_checkpoint("e2fgvi") is None
+    (tmp_path / RELEASED["e2fgvi_hq"]).write_bytes(b"x")
+    monkeypatch.setenv("E2FGVI_RELEASE_DIR", str(tmp_path))
+    assert released_checkpoint("e2fgvi_hq") == str(tmp_path / RELEASED["e2fgvi_hq"])

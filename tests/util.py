@@ -87,3 +87,19 @@ def assert_close_bf16(got, ref, what="", ulps=1.0, abs_rms=4e-3):
     _margin(what + " [bf16 elementwise]", ratio, 1.0)
     excess = ((got - ref).abs() - allowed).max().item()
     assert excess <= 0, "%s: error exceeds %.1f x 2^-8 relative + %.1e x rms by %.3e" % (what, ulps, abs_rms, excess)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def timed_tuning():
+    """timing-based kernel selection (E2FGVI_AUTOTUNE=1) for the duration of a test: the default is the checked-in decision
+    table (e2fgvi_amd/ops.py); decisions taken here stay in the process table only (no cache file)"""
+    from e2fgvi_amd import ops
+    saved = ops.AUTOTUNE
+    ops.AUTOTUNE = True
+    try:
+        yield
+    finally:
+        ops.AUTOTUNE = saved
