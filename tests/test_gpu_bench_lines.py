@@ -40,13 +40,50 @@ def test_multi_gpu_flow_with_one_rank(dev):
 
 
 def test_default_line_carries_the_hq_configs(dev):
-    """`python bench.py` (what the driver records): headline fields + `secondary` = e2fgvi_hq 720x1296 T=10 and 1080x1944 T=20, bf16"""
+    """`python bench.py` (what the driver records): headline fields incl. its own arithmetic tag and kernel map, and `secondary` =
+    the pure fp32-MFMA configuration (E2FGVI_X3=0), SURVEY.md 8(d)'s second split (T=10, l_t=5), config 3's per-GPU work on one
+    GPU (8 clips), e2fgvi_hq 720x1296 T=10 and 1080x1944 T=20 in bf16"""
     j = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert j["metric"].startswith("inpainted frames/sec at 432x240 T=10") and j["dtype"] == "f32" and j["value"] > 30
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    assert "split operands" in j["config"]["arithmetic"] and j["config"]["kernel_selection"].startswith("e2fgvi_amd/tile_table.py")
+    assert "encoder.layers.10" in j["config"]["kernels"] and j["peak_memory_gb"] > 0
     sec = j["secondary"]
-    assert len(sec) == 2 and all("error" not in s for s in sec), sec
-    assert "720" in sec[0]["metric"] and "T=10" in sec[0]["metric"] and sec[0]["dtype"] == "bf16" and sec[0]["value"] > 30
-    assert "1080" in sec[1]["metric"] and "T=20" in sec[1]["metric"] and sec[1]["dtype"] == "bf16" and sec[1]["value"] > 10
-    for s in sec:
+    assert len(sec) == 5 and all("error" not in s for s in sec), sec
+    x30, lt5, c8, hq720, hq1080 = sec
+    assert "E2FGVI_X3=0" in x30["config"]["workload"] and x30["dtype"] == "f32" and "fp32 MFMA" in x30["config"]["arithmetic"]
+    assert not any("x3" in k for k in x30["config"]["kernels"].values()), x30["config"]["kernels"]
+    assert "l_t=5" in lt5["config"]["workload"] and lt5["value"] > 30
+    assert "8 clip(s)" in c8["config"]["workload"] and c8["value"] > 30 and abs(c8["value"] - 80e3 / c8["ms_per_step"]) <= 1e-2 * c8["value"]
+    assert "720" in hq720["metric"] and "T=10" in hq720["metric"] and hq720["dtype"] == "bf16" and hq720["value"] > 30
+    assert "1080" in hq1080["metric"] and "T=20" in hq1080["metric"] and hq1080["dtype"] == "bf16" and hq1080["value"] > 10
+    for s in (hq720, hq1080):
         assert s["roofline"]["peak"] == 2500.0 and 0 < s["roofline"]["frac"] < 1 and s["config"]["hip_graph"] is True
+
+
+def test_bench_line_carries_its_own_parity(dev):
+    """with the CPU baseline on, the line compares the frames of the TIMED configuration with the oracle's on the same clip
+    (`parity`), and bench.py exits non-zero above the north-star bound"""
+    j = _bench("--steps", "3", "--warmup", "1", "--no-secondary")
+    p = j["parity"]
+    assert p["bound_max_abs"] == 1e-3 and 0 <= p["max_abs"] <= 1e-3 and p["max_abs_over_rms"] <= 2e-4, p
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+
+
+def test_two_processes_return_the_same_bits(dev):
+    """deterministic kernel selection (ops.py, e2fgvi_amd/tile_table.py): two fresh processes run the same kernels in the same
+    order on the headline configuration and return torch.equal frames"""
+    code = ("import sys, importlib, hashlib, torch; sys.path.insert(0, %r);"
+            "from e2fgvi_amd.synth import synth_clip, synth_state_dict;"
+            "net = importlib.import_module('model.e2fgvi').InpaintGenerator(); net.load_state_dict(synth_state_dict('e2fgvi', 'stress', 0));"
+            "net = net.cuda().eval(); x = synth_clip(1, 10, 240, 432, seed=5, moving=True)[0].cuda();"
+            "o, (ff, fb) = net(x, 10); torch.cuda.synchronize();"
+            "print('HASH', hashlib.sha256(o.cpu().numpy().tobytes() + ff.cpu().numpy().tobytes()).hexdigest())" % ROOT)
+    hashes = []
+    for _ in range(2):
+        env = dict(os.environ)
+        env.pop("E2FGVI_AUTOTUNE", None)
+        p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        hashes.append([ln for ln in p.stdout.splitlines() if ln.startswith("HASH")][-1])
+    assert hashes[0] == hashes[1], hashes
