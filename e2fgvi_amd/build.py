@@ -151,43 +151,13 @@ def check_kernel_waits(obj, name, ins):
     #   conv_wino_kernel<..., DMA = true, X3 = true> fetches TWO trips ahead (its wait carries two inter-wait intervals);
     #   conv_wino_x3w_kernel reloads its single-buffered weight planes in place and claims them group by group (below)
     two_ahead = re.search(r"conv_wino_kernelILi\d+ELi\d+ELi\d+ELb1ELb1E", name) is not None
-    rolling = "conv_wino_x3w_kernel" in name and "ELb1EE" not in name
-    pipelined = "conv_wino_x3w_kernel" in name and "ELb1EE" in name
+    rolling = "conv_wino_x3w_kernel" in name
     for lo, hi in spans:
         inner = [m for m in marks if lo <= m <= hi]
         if not inner or any(lo <= l2 and h2 <= hi and (l2, h2) != (lo, hi) and any(l2 <= m <= h2 for m in inner)
                             for l2, h2 in spans):
             continue                                   # no marked wait, or an inner loop owns them
         loops += 1
-        if pipelined:
-            # conv_wino_x3w_kernel<.., PIPE>: per trip [this wave's LDS-DMA pieces] wait(a = 0) wait(a = 1) [12 plane loads] wait(end).
-            # Every marked wait vmcnt(n) must leave exactly the right loads outstanding: walking back from the wait (cyclically),
-            # the n youngest vector-memory instructions and the one just older than them identify what it claims:
-            #   a = 0   youngest: the pieces, then the OTHER position's plane loads; claimed: a plane load
-            #   a = 1   youngest: only pieces;                                       claimed: a plane load
-            #   end     youngest: only plane loads (all of them);                    claimed: a piece
-            order = list(range(lo, hi + 1))
-            kinds = set()
-            for m in inner:
-                n = int(re.search(r"vmcnt\((\d+)\)", ins[m][2]).group(1))
-                pos = order.index(m)
-                back = [k for k in (order[:pos][::-1] + order[pos + 1:][::-1]) if vmem.match(ins[k][1])]
-                if len(back) <= n or any(ins[k][1] != "buffer_load_dwordx4" for k in back[:n + 1]):
-                    raise RuntimeError("%s: %s: wait at 0x%x: unexpected vector-memory instructions in the trip" % (obj, name[:60], ins[m][0]))
-                lds = [" lds" in ins[k][2] for k in back[:n + 1]]
-                young, claimed = lds[:n], lds[n]
-                if not any(young) and claimed and n == len([k for k in back if " lds" not in ins[k][2]]):
-                    kinds.add("end")
-                elif all(young) and not claimed:
-                    kinds.add("a1")
-                elif not claimed and young == sorted(young, reverse=True) and young.count(False) * 2 == len([k for k in back if " lds" not in ins[k][2]]):
-                    kinds.add("a0")
-                else:
-                    raise RuntimeError("%s: %s: explicit s_waitcnt vmcnt(%d) at 0x%x does not claim what the pipelined loop needs"
-                                       % (obj, name[:60], n, ins[m][0]))
-            if kinds != {"a0", "a1", "end"}:
-                raise RuntimeError("%s: %s: pipelined loop with waits %s" % (obj, name[:60], sorted(kinds)))
-            continue
         if rolling:
             # The plane loads of the next stage are the LAST vector-memory instructions of a trip, G per position; the next
             # trip claims them position by position with vmcnt(n_0 = (P - 1) G), ..., vmcnt(0), nothing issued in between.

@@ -1122,7 +1122,7 @@ __device__ __forceinline__ void wino_split4(const f32x4& v, unsigned (&H)[2], un
 // barrier and the next stage's first fragment phase to land.  Wave w owns the transform positions 2w, 2w + 1 as in the
 // eight-wave kernel; fragments are built one row-tile at a time, one channel quad at a time (12 fragment registers per
 // position), the patch of stage st + 1 is parked between the two row-tiles' MFMA blocks.
-template <int BN, bool PIPE>
+template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams p) {
     constexpr int MT = 2, SC = 2;
     constexpr int TN = BN / 32;
@@ -1181,34 +1181,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
     const float* w_src = p.src[0];
     unsigned w_bytes = p.src_bytes[0], w_ld4 = (unsigned)p.ld[0] * 4u, w_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
     int w_cpg = p.cpg[0];
-    // Per-lane state of the walk: the byte offset of the lane's unit of the NEXT chunk inside the source being walked (OOB for a
-    // padding unit / a pixel outside the image: a saturating add keeps it there), advanced by one chunk (32 bytes) per piece --
-    // one VALU per piece on the common path; the full address arithmetic runs only when the walk enters a new source.  dma_kq:
-    // the lanes whose unit belongs to channel quad 1 (they fetch zeros in the half chunk that ends a source of 4 (mod 8) channels).
-    unsigned dma_off[NPMAX];
-    unsigned long long dma_kq[NPMAX];
-    auto dma_enter = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NPMAX; ++j) {
-            const unsigned pix = dma_pix[j] & 0x3FFFFFFFu, kq = (dma_pix[j] >> 30) & 1u;
-            dma_off[j] = (int)dma_pix[j] >= 0 ? pix * w_ld4 + w_chan + kq * 16u : OOB;
-        }
-    };
-    dma_enter();
-#pragma unroll
-    for (int j = 0; j < NPMAX; ++j) dma_kq[j] = __builtin_amdgcn_ballot_w64((int)dma_pix[j] >= 0 && ((dma_pix[j] >> 30) & 1u));
     // the pieces of wave WV of the NEXT chunk of the walk -> LDS chunk area lds_chunk; exactly NPW vector-memory instructions
     auto dma_chunk = [&](auto W_, auto NPW_, unsigned lds_chunk) __attribute__((always_inline)) {
         constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
         const i32x4 rs = rsrc_words(w_src, w_bytes);
+        const unsigned chan = w_chan + (unsigned)w_c0 * 4u;
         const bool half = w_c0 + 4 >= w_cpg;         // a source may end in the middle of a chunk: its kq = 1 units are zeros
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            const unsigned long long zero_lanes = half ? dma_kq[j] : 0ull;
-            unsigned off;
-            asm volatile("v_cndmask_b32 %0, %1, -1, %2" : "=v"(off) : "v"(dma_off[j]), "s"(zero_lanes));
+            const unsigned pix = dma_pix[j] & 0x3FFFFFFFu, kq = (dma_pix[j] >> 30) & 1u;
+            unsigned off = ((int)dma_pix[j] >= 0 && !(half && kq)) ? pix * w_ld4 + chan + kq * 16u : OOB;
+            asm volatile("" : "+v"(off));
             dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
-            dma_off[j] = __builtin_elementwise_add_sat(dma_off[j], 32u);
         }
         w_c0 += 8;
         if (w_c0 >= w_cpg) {
@@ -1223,7 +1207,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 if (w_s == 0) E2_WALK_ARM(0) else if (w_s == 1) E2_WALK_ARM(1) else if (w_s == 2) E2_WALK_ARM(2) else E2_WALK_ARM(3)
 #undef E2_WALK_ARM
             }
-            dma_enter();
         }
     };
 
@@ -1241,15 +1224,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
     const unsigned u_step = 96u * (unsigned)p.Npad * 16u;
     const unsigned u_plane = 2u * (unsigned)p.Npad * 16u;
     unsigned u_lane = (unsigned)((h * p.Npad + n0 + i) * 16);
-    // the 3 TN plane loads of one position in ONE statement: every scalar operand is an input of the statement, so a restored
-    // SGPR is restored in front of it and one s_nop 4 covers all six loads
-    auto load_planes6 = [&](f32x4 (&q)[2][3], unsigned s0, unsigned s1, unsigned s2, unsigned s3, unsigned s4, unsigned s5) __attribute__((always_inline)) {
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %6, %7, %8 offen\n\tbuffer_load_dwordx4 %1, %6, %7, %9 offen\n\t"
-                     "buffer_load_dwordx4 %2, %6, %7, %10 offen\n\tbuffer_load_dwordx4 %3, %6, %7, %11 offen\n\t"
-                     "buffer_load_dwordx4 %4, %6, %7, %12 offen\n\tbuffer_load_dwordx4 %5, %6, %7, %13 offen"
-                     : "=&v"(q[0][0]), "=&v"(q[0][1]), "=&v"(q[0][2]), "=&v"(q[1][0]), "=&v"(q[1][1]), "=&v"(q[1][2])
-                     : "v"(u_lane), "s"(wrsrc), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5) : "memory");
-    };
     auto load_plane = [&](f32x4& v, unsigned soff) __attribute__((always_inline)) {
         // s_nop 4: the scalar offset may be a spilled SGPR that the compiler has just restored with v_readlane (a VALU write of an
         // SGPR needs 5 wait states before a vector-memory instruction reads it, and the hazard recognizer does not look inside an
@@ -1287,12 +1261,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
 #pragma unroll
         for (int c4 = 0; c4 < 2 * SC; ++c4)
             dma_chunk(IC<WV>{}, IC<NPW>{}, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
-        static_assert(TN == 2, "load_planes6: two column tiles");
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const unsigned ua = u_pos + (unsigned)(a * 3) * u_plane;
-            load_planes6(bw[a], ua + u_n[0], ua + u_plane + u_n[0], ua + 2 * u_plane + u_n[0], ua + u_n[1], ua + u_plane + u_n[1], ua + 2 * u_plane + u_n[1]);
-        }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    load_plane(bw[a][n][pl], u_pos + (unsigned)(a * 3 + pl) * u_plane + u_n[n]);
         u_lane += u_step;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1331,7 +1306,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
         auto mma = [&](auto M_, auto LAST_, const bf16x8 (&A)[6]) __attribute__((always_inline)) {
             constexpr int M = decltype(M_)::value;
             constexpr bool LAST = decltype(LAST_)::value != 0;
-            if (E2_WINO_VARIANT & 16) __builtin_amdgcn_s_setprio(3);      // experiment: the wave in an MFMA phase wins the issue port
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 if constexpr (!LAST) {
@@ -1368,176 +1342,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, uh[n], acc[a][M][n], 0, 0, 0);
                 if constexpr (LAST) {
                     __builtin_amdgcn_sched_barrier(0);
-                    {
-                        const unsigned ua = u_pos + (unsigned)(a * 3) * u_plane;
-                        load_planes6(bw[a], ua + u_n[0], ua + u_plane + u_n[0], ua + 2 * u_plane + u_n[0], ua + u_n[1], ua + u_plane + u_n[1],
-                                     ua + 2 * u_plane + u_n[1]);
-                    }
+                    // ONE load per asm statement, each behind its own s_nop 4.  Round 4 tried the six loads of a position back to back
+                    // in one statement (one s_nop), the reloads moved behind the other position's MFMA block / the stage barrier, the
+                    // pieces issued earlier in the stage: every such build returned wrong encoder blocks in one forward out of three
+                    // as soon as SPyNet ran beside the encoder on the side stream (single lanes groups 0-15 / 32-47 of single tile
+                    // rows; deterministic and correct without the side stream), this one did not in 60 forwards and 8 suite runs
+                    // (profiles/r04_x3w_plane_reload.txt).  The mechanism is not understood; the order below is the one that is
+                    // measured clean, and tests/test_gpu_model.py::test_stream_overlap_* is the tripwire.
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            load_plane(bw[a][n][pl], u_pos + (unsigned)(a * 3 + pl) * u_plane + u_n[n]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (E2_WINO_VARIANT & 16) __builtin_amdgcn_s_setprio(0);
         };
-        if constexpr (PIPE) {
-            // ---- software-pipelined wave (round 4): the fragment phase of one row-tile is issued BETWEEN the MFMAs of the other.
-            // Measured on the phase-by-phase loop below (tools/r4_variants.py timing): a wave spends ~950 cycles in each fragment
-            // phase (12 LDS reads + ~130 dependent VALU) and 770 / 1200 in each MFMA phase, ~4700 per stage, whatever its SIMD
-            // partner does (phase skew, s_setprio: +-3 %) -- two waves keep the matrix pipe 57 % busy.  A 32x32x16 MFMA occupies the
-            // pipe for 32 cycles = 8 issue slots, of which the wave's own instruction stream can use 5-8: here every MFMA is followed
-            // by one "step" of <= 8 VALU / <= 4 LDS reads of the fragment construction (22 steps per row-tile for 24 MFMAs), pinned
-            // in place by sched_barriers.  Segment A = M0(st) + the fragments of row-tile 1 of stage st; segment B = M1(st) (+ the
-            // plane reloads) + the fragments of row-tile 0 of stage st + 1 -- so the patch of stage st + 1 must be visible one stage
-            // early: its LDS-DMA pieces are issued at the START of stage st - 1 and waited for (vmcnt(12): everything but the 12
-            // plane loads behind them) in front of that stage's closing barrier.  Three LDS slots as before.
-            constexpr int NPC = SC * NPW;                     // LDS-DMA pieces of this wave per stage
-            unsigned Pa[6][4], Pb[6][4];                      // the two fragment sets (positions a = 0, 1 x planes hi, mid, lo)
-            f32x4 dA, dB, dC, dD, e0, e1, e2, va, vb;
-            unsigned xb[4], rb[4], r2b[4];
-            auto comb = [&](const f32x4& d0, const f32x4& d1) __attribute__((always_inline)) {
-                return XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
-            };
-            auto lds = [&](const unsigned char* rm, int kq, int col, int row) __attribute__((always_inline)) {
-                return *reinterpret_cast<const f32x4*>(rm + kq * (2 * PLANE_BYTES) + (col & 1) * PLANE_BYTES + (col >> 1) * 16 + row * PLANE_ROW * 16);
-            };
-            // step K (0 .. 21) of the construction of one row-tile's fragments from the patch at rm into P
-            auto build = [&](auto K_, const unsigned char* rm, unsigned (&P)[6][4]) __attribute__((always_inline)) {
-                constexpr int K = decltype(K_)::value;
-                if constexpr (K < 22) {
-                    constexpr int kq = K / 11, k = K % 11;
-                    if constexpr (k == 0) { dA = lds(rm, kq, CB, R0); dB = lds(rm, kq, CB, R1); dC = lds(rm, kq, CB + 1, R0); dD = lds(rm, kq, CB + 1, R1); }
-                    if constexpr (k == 1) { e0 = comb(dA, dB); dA = lds(rm, kq, CB + 2, R0); dB = lds(rm, kq, CB + 2, R1); }
-                    if constexpr (k == 2) e1 = comb(dC, dD);
-                    if constexpr (k == 3) { e2 = comb(dA, dB); va = PB ? e1 - e0 : e0 - e2; }
-                    if constexpr (k == 4) vb = PB ? e0 - e2 : e1 + e2;
-                    if constexpr (k == 5 || k == 8) {
-                        const f32x4 v = k == 5 ? va : vb;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            xb[j] = __builtin_bit_cast(unsigned, (float)v[j]);
-                            rb[j] = __builtin_bit_cast(unsigned, v[j] - __builtin_bit_cast(float, xb[j] & 0xFFFF0000u));
-                        }
-                    }
-                    if constexpr (k == 6 || k == 9) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            r2b[j] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, rb[j]) - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u));
-                    }
-                    if constexpr (k == 7 || k == 10) {
-                        constexpr int f = k == 7 ? 0 : 3;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            P[f][2 * kq + j] = __builtin_amdgcn_perm(xb[2 * j + 1], xb[2 * j], 0x07060302u);
-                            P[f + 1][2 * kq + j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
-                            P[f + 2][2 * kq + j] = __builtin_amdgcn_perm(r2b[2 * j + 1], r2b[2 * j], 0x07060302u);
-                        }
-                    }
-                }
-            };
-            // the 24 MFMAs of row-tile M on the fragments in P, step K of build(..., rmn, Pn) behind the K-th of them
-            auto segment = [&](auto M_, auto LAST_, const unsigned (&P)[6][4], const unsigned char* rmn, unsigned (&Pn)[6][4]) __attribute__((always_inline)) {
-                constexpr int M = decltype(M_)::value;
-                constexpr bool LAST = decltype(LAST_)::value != 0;
-                auto frag = [&](int f) __attribute__((always_inline)) {
-                    const u32x4 t = {P[f][0], P[f][1], P[f][2], P[f][3]};
-                    return __builtin_bit_cast(bf16x8, t);
-                };
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    if constexpr (!LAST) {
-                        // this position's 3 TN plane loads were issued a stage ago; behind them: the other position's (a = 0) and this
-                        // stage's LDS-DMA pieces (marked waits: build.verify_wino_waits)
-                        if (a == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(3 * TN + NPC) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
-#pragma unroll
-                        for (int n = 0; n < TN; ++n)
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[a][n][pl]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const bf16x8 xh = frag(3 * a), xm = frag(3 * a + 1), xl = frag(3 * a + 2);
-                    bf16x8 uh[TN], um[TN], ul[TN];
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) {
-                        uh[n] = __builtin_bit_cast(bf16x8, bw[a][n][0]);
-                        um[n] = __builtin_bit_cast(bf16x8, bw[a][n][1]);
-                        ul[n] = __builtin_bit_cast(bf16x8, bw[a][n][2]);
-                    }
-                    // smallest terms first; term t: (x plane, u plane)
-#pragma unroll
-                    for (int t = 0; t < 6; ++t)
-#pragma unroll
-                        for (int n = 0; n < TN; ++n) {
-                            const bf16x8 x = (t == 0) ? xl : (t == 2 || t == 3) ? xm : xh;
-                            const bf16x8 u = (t == 1) ? ul[n] : (t == 2 || t == 4) ? um[n] : uh[n];
-                            acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, u, acc[a][M][n], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            // (a, t, n) -> step: 24 MFMAs, 22 steps
-                            if (a == 0) {
-                                if (t == 0 && n == 0) build(IC<0>{}, rmn, Pn); if (t == 0 && n == 1) build(IC<1>{}, rmn, Pn);
-                                if (t == 1 && n == 0) build(IC<2>{}, rmn, Pn); if (t == 1 && n == 1) build(IC<3>{}, rmn, Pn);
-                                if (t == 2 && n == 0) build(IC<4>{}, rmn, Pn); if (t == 2 && n == 1) build(IC<5>{}, rmn, Pn);
-                                if (t == 3 && n == 0) build(IC<6>{}, rmn, Pn); if (t == 3 && n == 1) build(IC<7>{}, rmn, Pn);
-                                if (t == 4 && n == 0) build(IC<8>{}, rmn, Pn); if (t == 4 && n == 1) build(IC<9>{}, rmn, Pn);
-                                if (t == 5 && n == 0) build(IC<10>{}, rmn, Pn); if (t == 5 && n == 1) build(IC<11>{}, rmn, Pn);
-                            } else {
-                                if (t == 0 && n == 0) build(IC<12>{}, rmn, Pn); if (t == 0 && n == 1) build(IC<13>{}, rmn, Pn);
-                                if (t == 1 && n == 0) build(IC<14>{}, rmn, Pn); if (t == 1 && n == 1) build(IC<15>{}, rmn, Pn);
-                                if (t == 2 && n == 0) build(IC<16>{}, rmn, Pn); if (t == 2 && n == 1) build(IC<17>{}, rmn, Pn);
-                                if (t == 3 && n == 0) build(IC<18>{}, rmn, Pn); if (t == 3 && n == 1) build(IC<19>{}, rmn, Pn);
-                                if (t == 4 && n == 0) build(IC<20>{}, rmn, Pn); if (t == 4 && n == 1) build(IC<21>{}, rmn, Pn);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    if constexpr (LAST) {
-                        const unsigned ua = u_pos + (unsigned)(a * 3) * u_plane;
-                        load_planes6(bw[a], ua + u_n[0], ua + u_plane + u_n[0], ua + 2 * u_plane + u_n[0], ua + u_n[1], ua + u_plane + u_n[1],
-                                     ua + 2 * u_plane + u_n[1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            };
-            static_assert(TN == 2, "the step table of `segment` is written for two column tiles");
-            // fragments of row-tile 0 of stage 0 (nothing to overlap them with)
-            {
-                const unsigned char* rm0 = smem + a_lane;
-#pragma unroll
-                for (int K = 0; K < 22; ++K) {
-                    // (compile-time index through a lambda per step)
-                }
-                build(IC<0>{}, rm0, Pa); build(IC<1>{}, rm0, Pa); build(IC<2>{}, rm0, Pa); build(IC<3>{}, rm0, Pa); build(IC<4>{}, rm0, Pa);
-                build(IC<5>{}, rm0, Pa); build(IC<6>{}, rm0, Pa); build(IC<7>{}, rm0, Pa); build(IC<8>{}, rm0, Pa); build(IC<9>{}, rm0, Pa);
-                build(IC<10>{}, rm0, Pa); build(IC<11>{}, rm0, Pa); build(IC<12>{}, rm0, Pa); build(IC<13>{}, rm0, Pa); build(IC<14>{}, rm0, Pa);
-                build(IC<15>{}, rm0, Pa); build(IC<16>{}, rm0, Pa); build(IC<17>{}, rm0, Pa); build(IC<18>{}, rm0, Pa); build(IC<19>{}, rm0, Pa);
-                build(IC<20>{}, rm0, Pa); build(IC<21>{}, rm0, Pa);
-            }
-            int slot = 0;
-            for (int st = 0; st < nstages; ++st) {
-                const int slot1 = slot == 2 ? 0 : slot + 1;
-                const unsigned ahead = smem_lds + (unsigned)((slot == 0 ? 2 : slot - 1) * STAGE_BYTES);
-                // this wave's pieces of stage st + 2 (slot (st + 2) % 3: its last readers -- row-tile 1 of stage st - 1 -- passed the barrier)
-#pragma unroll
-                for (int q = 0; q < SC; ++q) dma_chunk(IC<WV>{}, IC<NPW>{}, ahead + (unsigned)(q * CHUNK_BYTES));
-                __builtin_amdgcn_sched_barrier(0);
-                segment(IC<0>{}, IC<0>{}, Pa, smem + slot * STAGE_BYTES + a_lane + 8 * PLANE_ROW * 16, Pb);
-                __builtin_amdgcn_sched_barrier(0);
-                segment(IC<1>{}, IC<1>{}, Pb, smem + slot1 * STAGE_BYTES + a_lane, Pa);
-                u_lane += u_step;
-                slot = slot1;
-                // the pieces issued at the top of this stage have landed (everything but the 12 plane loads behind them): the barrier
-                // publishes stage st + 2 one stage early, for the row-tile-0 fragments built under M1 of stage st + 1
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(6 * TN) : "memory");
-                __syncthreads();
-            }
-            return;
-        }
         // One stage = P0 (fragments of row-tile 0) M0 (its MFMAs) P1 (fragments of row-tile 1 + this wave's LDS-DMA pieces of stage
         // st + 2) M1 (its MFMAs + the plane reloads), one barrier per stage.  Stage st lives in LDS slot st % 3; stage st + 2 goes to
         // slot (st + 2) % 3, whose readers passed the last barrier.
-        // SKEW (waves 4-7, the SIMD partners of waves 0-3): the same phases shifted by one -- M1 of stage st runs BEHIND the
-        // stage's barrier, in front of P0 of stage st + 1 (its fragments wait in registers, where they are anyway) -- so that one
-        // wave of a SIMD is in a fragment phase (VALU, LDS) while the other is in an MFMA phase; without it the two go through the
-        // phases together (both were released by the same barrier) and the matrix pipe idles through both fragment phases.
-        constexpr bool SKEW = XI >= 2 && (E2_WINO_VARIANT & 8) != 0;
+        // (Measured and dropped, profiles/r04_x3w_variants.txt: the phases of waves 4-7 shifted by one against their SIMD partners,
+        //  s_setprio 3 around the MFMA blocks, both: all within +-3 %.)
+        constexpr bool SKEW = false;
         E2T(unsigned long long tsum[6]; for (int k_ = 0; k_ < 6; ++k_) tsum[k_] = 0; const unsigned long long t_k0 = E2T_NOW(); t_loop0 = t_k0;)
         int slot = 0;
         auto first_half = [&](bf16x8 (&A1)[6]) __attribute__((always_inline)) {
@@ -1884,7 +1710,7 @@ static int launch_wino_p4(WinoParams& p, int groups, hipStream_t st) {
 #endif
 
 #if E2_WINO_X3
-template <int BN, bool PIPE>
+template <int BN>
 static int launch_wino_w(WinoParams& p, int groups, hipStream_t st) {
     p.blocksY = cdiv(p.H, 16);
     p.blocksX = cdiv(p.W, 16);
@@ -1892,7 +1718,7 @@ static int launch_wino_w(WinoParams& p, int groups, hipStream_t st) {
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd_x3: grid too large");
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL((conv_wino_x3w_kernel<BN, PIPE>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_wino_x3w_kernel<BN>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd_x3 (wide tile)");
     return 0;
 }
@@ -1964,9 +1790,7 @@ static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
         // + 5000: four positions per wave, four-wave workgroups (two per CU)
         case 5132: return launch_wino_p4<32>(p, d->groups, st);
         // + 6000: 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place (round 4)
-        case 6064: return launch_wino_w<64, false>(p, d->groups, st);
-        // + 7000: the same block with the fragment phases issued BETWEEN the MFMAs of the other row-tile (software-pipelined wave)
-        case 7064: return launch_wino_w<64, true>(p, d->groups, st);
+        case 6064: return launch_wino_w<64>(p, d->groups, st);
         // + 1000: patch by LDS-DMA, patch and weights fetched two stages ahead (32-cout shapes: three weight buffers fit)
         case 1032: return launch_wino<2, 32, 2, true, true>(p, d->groups, st);
         case 1132: return launch_wino<1, 32, 2, true, true>(p, d->groups, st);

@@ -66,9 +66,7 @@ X3_BASE = 30000
 W3_BASE = 40000
 # (+ 1000: LDS-DMA patch staging with two stages of lookahead -- measured slower everywhere; 5132: four positions per wave in
 #  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
-#  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA; 7064: the same
-#  with the fragment construction of one row-tile issued between the MFMAs of the other -- measured equal to 6064 on every layer
-#  (profiles/r04_x3w_variants.txt: the SIMD is bound by its total instruction issue, not by the phase order), selectable, not timed)
+#  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
 W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.environ.get("E2FGVI_W3_SKIP", "").split(","))     # E2FGVI_W3_SKIP=6064: A/B runs
 _TUNED = {}      # (layer geometry, input size class) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # Kernel selection is DETERMINISTIC by default (round 4): the decisions come from the checked-in table e2fgvi_amd/tile_table.py
@@ -352,7 +350,7 @@ class PackedConv:
             # 16 positions per 4 pixels, six bf16 MACs per product, in fp32-pipe equivalents (see PackedConvX's trace record)
             issued = int(pix * (-(-cout_g // bn) * bn) * self.groups * cin_p * 4 * 6 * 157.3 / 2500.0)
             code = tile - W3_BASE
-            kern = ("conv_wino_x3w<%d,pipe>" % bn) if code >= 7000 else ("conv_wino_x3w<%d>" % bn) if code >= 6000 else ("conv_wino_x3p4<%d>" % bn) if code >= 5000 else "conv_wino_x3<%d,%d>" % (mt, bn)
+            kern = ("conv_wino_x3w<%d>" % bn) if code >= 6000 else ("conv_wino_x3p4<%d>" % bn) if code >= 5000 else "conv_wino_x3<%d,%d>" % (mt, bn)
         elif use_wino:
             if not tile:
                 big = N * -(-H // 16) * -(-W // 16) * -(-cout_g // 64) * self.groups

@@ -199,6 +199,24 @@ def test_fp32_layers_may_pick_the_split_kernel(dev):
 from tests.test_gpu_ops import WINO_CASES, _act_ref     # noqa: E402
 
 
+def _pattern_on_mismatch(out, fp32, shape, case):
+    """diagnostics for an intermittent wrong block: where (image, 16x16-pixel block, 32-cout tile, row / column parity) a split-
+    operand Winograd output leaves the fp32 Winograd kernel's -- printed before the assertion fails"""
+    d = (out - fp32).abs()
+    if d.max().item() <= 1e-2 * fp32.abs().max().item():
+        return
+    bad = d > 1e-2 * fp32.abs().max().item()
+    N, H, W, C = out.shape
+    print("MISMATCH shape %d case %s: max err %.3f, bad fraction %.4f" % (shape, case[:6], d.max().item(), bad.float().mean().item()))
+    print("  by image:", [round(bad[n].float().mean().item(), 4) for n in range(N)])
+    print("  by 32-cout tile:", [round(bad[..., c:c + 32].float().mean().item(), 4) for c in range(0, C, 32)])
+    print("  row parity:", [round(bad[:, p::2].float().mean().item(), 4) for p in (0, 1)], "col parity:",
+          [round(bad[:, :, p::2].float().mean().item(), 4) for p in (0, 1)])
+    for n in range(N):
+        print("  img %d by 16x16 block:" % n, [[round(bad[n, by * 16:(by + 1) * 16, bx * 16:(bx + 1) * 16].float().mean().item(), 3)
+                                                  for bx in range((W + 15) // 16)] for by in range((H + 15) // 16)])
+
+
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c[:8]))
 def test_conv3x3_winograd_x3(dev, case):
     """the fp32 Winograd kernel's own case list on the split-bf16 build (csrc/conv_wino.hip X3; tile codes ops.W3_BASE + block
@@ -217,7 +235,7 @@ def test_conv3x3_winograd_x3(dev, case):
     tol = fp32_tol(cin_g * 9, floor=3e-5)
     src_d = [nhwc(s_).to(dev) for s_ in srcs]
     fp32 = layer(src_d, act=act, slope=0.2, tile=132)
-    for shape in (132, 164, 32, 1132, 1032, 5132, 6064, 7064):
+    for shape in (132, 164, 32, 1132, 1032, 5132, 6064):
         if dst_ld is None:
             out = layer(src_d, act=act, slope=0.2, tile=ops.W3_BASE + shape)
         else:
@@ -226,11 +244,12 @@ def test_conv3x3_winograd_x3(dev, case):
             out = full[..., dst_coff:dst_coff + Cout]
             rest = torch.cat([full[..., :dst_coff], full[..., dst_coff + Cout:]], 3)
             assert (rest == 7.0).all(), "winograd x3 wrote outside its channel slice"
+        _pattern_on_mismatch(out, fp32, shape, case)
         assert_close(nchw(out.cpu()), ref, tol, "winograd x3 shape %d %s" % (shape, case))
         assert_close(out.cpu(), fp32.cpu(), 1.5 * tol, "winograd x3 vs fp32 winograd, shape %d %s" % (shape, case))
 
 
-@pytest.mark.parametrize("shape", [132, 164, 32, 1132, 1032, 5132, 6064, 7064])
+@pytest.mark.parametrize("shape", [132, 164, 32, 1132, 1032, 5132, 6064])
 def test_conv3x3_winograd_x3_epilogues(dev, shape):
     """residual (aligned and not) and ACT_DCNPOST on the split-bf16 Winograd kernel; reruns bit-identical"""
     from e2fgvi_amd import ops
