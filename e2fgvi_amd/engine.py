@@ -250,6 +250,13 @@ class Engine(BF16Path):
             for blk in self.blocks:
                 for k in ("qkv", "proj", "fc1", "fc2"):
                     blk[k].try_x3 = True
+        # layers that run with nothing beside them on the chip (behind the join of the two streams, one launch at a time): they may
+        # take the wide-tile split-operand Winograd kernel (ops.WIDE_X3_OK); the encoder, which shares the chip with SPyNet, may not
+        if not self.bf16:
+            for layer in self.dec[:3]:
+                layer.alone = True
+            for off, _dcn, bb in self.prop.values():
+                off[3].alone = True
         # SPyNet runs on a side stream next to the encoder, in both precision modes.  Round 1 found the side stream's
         # kernels corrupted beside bf16 MFMA tiles; round 2 traced it to packed-fp32 VALU instructions consuming freshly
         # loaded registers (tools/probe/overlap_probe.hip, DESIGN.md "Stream overlap"): every kernel that can run on the

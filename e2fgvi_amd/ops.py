@@ -68,6 +68,14 @@ W3_BASE = 40000
 #  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
 #  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
 W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.environ.get("E2FGVI_W3_SKIP", "").split(","))     # E2FGVI_W3_SKIP=6064: A/B runs
+# The wide-tile split-operand Winograd kernel (6064) is only taken by layers that run ALONE on the chip (PackedConv.alone: the
+# engine sets it on the layers behind the join of its two streams -- decoder, conv_offset.6) and only while WIDE_X3_OK: beside the
+# SPyNet side stream it returned wrong 16x16-pixel blocks in one forward out of three (builds of it; the shipped form in one
+# of ~20 two-clip forwards), unexplained after the experiments of profiles/r04_x3w_plane_reload.txt.  runner.ShardedStep clears
+# WIDE_X3_OK when an RCCL gather runs under the next forward.  W3_WIDE_FALLBACK: what such a layer runs instead.
+WIDE_X3_OK = os.environ.get("E2FGVI_W3_WIDE", "1") != "0"
+W3_WIDE = 6064
+W3_WIDE_FALLBACK = 164
 _TUNED = {}      # (layer geometry, input size class) -> tile code; shared by all layers of the same geometry (the 8 blocks)
 # Kernel selection is DETERMINISTIC by default (round 4): the decisions come from the checked-in table e2fgvi_amd/tile_table.py
 # (generated on an MI355X by tools/make_tile_table.py from timed runs of the BASELINE configurations), looked up by layer
@@ -196,6 +204,7 @@ class PackedConv:
         self.name = "conv"         # layer name for launch traces (the engine sets the checkpoint key)
         self.nopk = False          # True: the build without packed-fp32 VALU (side-stream launches beside bf16 MFMA tiles)
         self.try_x3 = False        # True: time the split-bf16 kernel (PackedConvX x3) against this layer's fp32 kernel, keep the faster
+        self.alone = False         # True: nothing else runs on the chip beside this layer's launches (see WIDE_X3_OK)
         self.alt = self.alt3 = None
         self._w_raw = w            # for the alternative LDS-DMA kernels (built on the first tuned call)
         if algo not in ("igemm", "winograd", "auto"):
@@ -469,7 +478,7 @@ class PackedConv:
             # (the fp32 baseline the alternatives are measured against is part of the key: a tuned layer and an untuned one of the
             #  same geometry, or the F(2x4) / F(2x2) Winograd baselines, do not share a verdict)
             key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk,
-                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino, bool(self.tune), int(tile)) + (("x3",) if x3 else ())
+                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino, bool(self.tune), int(tile)) + (("x3",) if x3 else ()) + (("alone",) if self.alone else ())
             best = _decision(key)
             from_table = best is not None
             if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing() and (
@@ -508,6 +517,8 @@ class PackedConv:
                     # ... and the Winograd kernel with split operands: codes W3_BASE + its block shape
                     w3 = {}
                     for shape in W3_CANDIDATES:
+                        if shape == W3_WIDE and not (self.alone and WIDE_X3_OK):
+                            continue
                         if launch_w3(shape)[0] != 0:
                             continue
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -526,6 +537,8 @@ class PackedConv:
             try:
                 if best and best >= W3_BASE and self._wino_x3() is not None:
                     w3_tile = best - W3_BASE
+                    if w3_tile == W3_WIDE and not (self.alone and WIDE_X3_OK):
+                        w3_tile = W3_WIDE_FALLBACK
                 elif best and X3_BASE <= best < W3_BASE and self._alt3() is not None:
                     return self.alt3(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
                                      tile=best - X3_BASE, out_nchw=out_nchw)
