@@ -402,6 +402,11 @@ def main():
                     pass
             out["roofline"]["dominant_kernel"] = dom
         out["peak_memory_gb"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
+        eng = getattr(net, "_engine", None)
+        if eng is not None:
+            # packed weights the layers hold after the timed run (each layer packs what the kernels it runs need) next to the checkpoint
+            out["weight_memory_gb"] = {"packed": round(eng.weight_bytes() / 2 ** 30, 3),
+                                       "checkpoint_fp32": round(sum(p.numel() * 4 for p in net.parameters()) / 2 ** 30, 3)}
         if world == 1 and not args.no_cpu_baseline:
             # the frames of the timed configuration (clip 0 of this rank = the oracle's clip: synth_clip seed 0), computed by the
             # very engine / kernel decisions / HIP graph that were timed

@@ -251,9 +251,10 @@ class Engine(BF16Path):
                 for k in ("qkv", "proj", "fc1", "fc2"):
                     blk[k].try_x3 = True
         # layers that run with nothing beside them on the chip (behind the join of the two streams, one launch at a time): they may
-        # take the wide-tile split-operand Winograd kernel (ops.WIDE_X3_OK); the encoder, which shares the chip with SPyNet, may not
+        # take the wide-tile split-operand Winograd kernel (ops.WIDE_X3_OK); encoder.layers.0..8, which share the chip with SPyNet,
+        # may not (the join sits in front of encoder.layers.10: encode())
         if not self.bf16:
-            for layer in self.dec[:3]:
+            for layer in list(self.dec[:3]) + list(self.enc[5:]):
                 layer.alone = True
             for off, _dcn, bb in self.prop.values():
                 off[3].alone = True
@@ -269,6 +270,31 @@ class Engine(BF16Path):
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ helpers
+    def weight_bytes(self):
+        """device bytes of the packed weights the layers hold right now (each layer packs what the kernels it has run need:
+        ops.PackedConv); the checkpoint's own tensors are not counted"""
+        seen, total = set(), 0
+
+        def walk(o):
+            nonlocal total
+            if id(o) in seen:
+                return
+            seen.add(id(o))
+            if isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v)
+            elif hasattr(o, "weight_bytes") and o is not self:
+                total += o.weight_bytes()
+            elif isinstance(getattr(o, "wpacked", None), torch.Tensor):
+                total += o.wpacked.numel() * o.wpacked.element_size()
+            elif hasattr(o, "__dict__") and type(o).__module__.startswith("e2fgvi_amd") and o is not self:
+                walk(list(vars(o).values()))
+        walk(list(vars(self).values()))
+        return total
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -334,7 +360,9 @@ class Engine(BF16Path):
         return fwd, bwd
 
     # ------------------------------------------------------------------ encoder
-    def encode(self, frames):
+    def encode(self, frames, join=None):
+        """join: called in front of encoder.layers.10 (the fork's other branch, SPyNet, has ended by then on every benchmark
+        shape -- profiles/r04_timeline.txt -- so the wait is free and layers 10..16 run alone on the chip: ops.WIDE_X3_OK)"""
         b, t, c, H, W = frames.shape
         x = ops.nchw_to_nhwc(frames.reshape(b * t, c, H, W).contiguous(), ld=4)
         e = self.enc
@@ -344,6 +372,8 @@ class Engine(BF16Path):
         x = e[2]([x], **lr)
         x0 = e[3]([x], **lr)
         x = e[4]([x0], **lr)
+        if join is not None:
+            join()
         for k in (5, 6, 7, 8):
             x = e[k]([x0, x], **lr)
         return x                                            # [b*t, h, w, 128]
@@ -477,8 +507,7 @@ class Engine(BF16Path):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 fwd, bwd = self.flows(frames, l_t)
-            enc = self.encode(frames)
-            main.wait_stream(side)
+            enc = self.encode(frames, join=lambda: main.wait_stream(side))
         else:
             fwd, bwd = self.flows(frames, l_t)
             enc = self.encode(frames)

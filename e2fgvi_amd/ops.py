@@ -215,36 +215,64 @@ class PackedConv:
         if algo == "auto":
             algo = "auto" if wino_ok else "igemm"
         self.algo = algo
-        self.wino_packed = None
         self._w4 = {}              # fy -> packed F(fy x 4, 3x3) weights, built on first use
         self._w_oihw = w if algo in ("winograd", "auto") else None
-        if algo in ("winograd", "auto"):
-            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
-            n = lib.e2fgvi_packed_winograd_weight_size(self.Cout, groups, len(self.cpg), arr)
-            if n < 0:
-                _L.check(int(n), "packed_winograd_weight_size")
-            self.wino_packed = torch.empty(int(n), dtype=torch.float32, device=w.device)
-            _L.check(lib.e2fgvi_pack_winograd_weight(_ptr(w), _ptr(self.wino_packed), self.Cout, groups, len(self.cpg), arr,
-                                                     _stream()), "pack_winograd_weight")
-            if algo == "winograd":
-                self.bk = 8
-                self.wpacked = None
-                self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
-                return
+        # every packing (implicit GEMM, Winograd F(2x2), F(2x4), the three-plane split ones, the LDS-DMA alternatives) is built from
+        # _w_raw on the first call that runs it: with the kernel table (tile_table.py) a layer holds the packing of the kernel it
+        # runs and nothing else; E2FGVI_AUTOTUNE=1 builds every candidate's (weight memory)
+        self._own = {}
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+        if algo in ("winograd", "auto"):       # a geometry the library rejects raises here, not on the first call
+            _L.check(min(0, int(lib.e2fgvi_packed_winograd_weight_size(self.Cout, groups, len(self.cpg), arr))), "packed_winograd_weight_size")
+        if algo == "winograd":
+            self.bk = 8
+            return
         if bk is None:
             # K-chunk granule: 32 unless padding every source up to a multiple of 32 wastes more than ~8 % of K
             pad32 = sum((c + 31) // 32 * 32 for c in self.cpg)
             pad16 = sum((c + 15) // 16 * 16 for c in self.cpg)
             bk = 32 if pad32 <= 1.08 * sum(self.cpg) else (16 if pad16 <= 1.08 * sum(self.cpg) else 8)
         self.bk = bk
-        arr = (C.c_int32 * len(self.cpg))(*self.cpg)
-        n = lib.e2fgvi_packed_conv_weight_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, bk)
-        if n < 0:
-            _L.check(int(n), "packed_conv_weight_size")
-        self.wpacked = torch.empty(int(n), dtype=torch.float32, device=w.device)
-        _L.check(lib.e2fgvi_pack_conv_weight(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW,
-                                             len(self.cpg), arr, bk, _stream()), "pack_conv_weight")
-        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        _L.check(min(0, int(lib.e2fgvi_packed_conv_weight_size(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, bk))),
+                 "packed_conv_weight_size")
+
+    @property
+    def wino_packed(self):
+        """packed weights of the fp32 F(2x2,3x3) kernel (conv_wino.hip), built on first use"""
+        t = self._own.get("wino")
+        if t is None and self.algo in ("winograd", "auto"):
+            lib = _L.load()
+            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+            n = lib.e2fgvi_packed_winograd_weight_size(self.Cout, self.groups, len(self.cpg), arr)
+            if n < 0:
+                _L.check(int(n), "packed_winograd_weight_size")
+            t = torch.empty(int(n), dtype=torch.float32, device=self._w_raw.device)
+            _L.check(lib.e2fgvi_pack_winograd_weight(_ptr(self._w_raw), _ptr(t), self.Cout, self.groups, len(self.cpg), arr,
+                                                     _stream()), "pack_winograd_weight")
+            self._own["wino"] = t
+        return t
+
+    @property
+    def wpacked(self):
+        """packed weights of the register-staged implicit GEMM (conv.hip), built on first use"""
+        t = self._own.get("igemm")
+        if t is None and self.algo != "winograd":
+            lib = _L.load()
+            arr = (C.c_int32 * len(self.cpg))(*self.cpg)
+            n = lib.e2fgvi_packed_conv_weight_size(self.Cout, self.groups, self.KH, self.KW, len(self.cpg), arr, self.bk)
+            if n < 0:
+                _L.check(int(n), "packed_conv_weight_size")
+            t = torch.empty(int(n), dtype=torch.float32, device=self._w_raw.device)
+            _L.check(lib.e2fgvi_pack_conv_weight(_ptr(self._w_raw), _ptr(t), self.Cout, self.groups, self.KH, self.KW,
+                                                 len(self.cpg), arr, self.bk, _stream()), "pack_conv_weight")
+            self._own["igemm"] = t
+        return t
+
+    def weight_bytes(self):
+        """device bytes of the packings this layer holds right now (the checkpoint tensor _w_raw not counted)"""
+        ts = list(self._own.values()) + list(self._w4.values()) + ([self._w3] if getattr(self, "_w3", None) is not None else [])
+        return sum(t.numel() * t.element_size() for t in ts) + sum(a.weight_bytes() for a in (self.alt, self.alt3) if a is not None)
 
     def _wino4(self, fy):
         """packed weights of the wide-tile Winograd kernel (conv_wino4.hip), built on first use"""
@@ -313,6 +341,7 @@ class PackedConv:
         st = _stream()
         d.tile = 0
         fn = lib.e2fgvi_conv3x3_winograd if wino else lib.e2fgvi_conv2d_nhwc
+        d.wpacked = (self.wino_packed if wino else self.wpacked).data_ptr()
         for _ in range(3):                                       # bring clocks / caches to steady state first
             fn(C.byref(d), st)
         for code in (WINO_CANDIDATES if wino else TUNE_CANDIDATES):
@@ -424,7 +453,7 @@ class PackedConv:
         if use_wino and tile == 0:
             tile = self._wino4_rule(N, H, W)
         w4 = W4_CODES.get(tile) if use_wino else None
-        d.wpacked = (self._wino4(w4[0]) if w4 else self.wino_packed if use_wino else self.wpacked).data_ptr()
+        d.wpacked = None                       # set by whatever launches: a layer packs the weights of the kernels it runs, only
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         dev = srcs[0][0].device
         if out is None:
@@ -459,6 +488,7 @@ class PackedConv:
         def launch():
             if w3_tile is not None:
                 return launch_w3(w3_tile)
+            d.wpacked = (self._wino4(w4c[0]) if w4c else self.wino_packed if use_wino else self.wpacked).data_ptr()
             if w4c:
                 t0 = d.tile
                 d.tile = w4c[1]
@@ -622,6 +652,28 @@ class PackedConvX:
         # (fp32 operands: only on request -- the one fp32 user is the FFN's second Linear as a conv, engine.py)
         self.taps = (len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 56 and self.KW > 1
                      and (taps is True if self.f32 else taps is not False) and os.environ.get("E2FGVI_TAPS", "1") != "0")
+        self._wdtype = wdtype
+        self._wp = None
+        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        if self._w_raw is None:
+            self._wp = self._pack(w)       # bf16 layers and the split-operand ones: packed now, the fp32 tensor is not kept
+        else:
+            self._pack(w, dry=True)        # a geometry the library rejects raises here, not on the first call
+
+    @property
+    def wpacked(self):
+        """packed weights; an fp32 layer (whose split-operand alternative alt3 may be what runs) packs its own on first use"""
+        if self._wp is None:
+            self._wp = self._pack(self._w_raw)
+        return self._wp
+
+    def weight_bytes(self):
+        return (0 if self._wp is None else self._wp.numel() * self._wp.element_size()) + (self.alt3.weight_bytes() if self.alt3 is not None else 0)
+
+    def _pack(self, w, dry=False):
+        lib = _L.load()
+        wdtype = self._wdtype
+        arr = (C.c_int32 * len(self.cpg))(*self.cpg)
         if self.taps:
             size_fn = ((lib.e2fgvi_packed_conv_weight_f32x3_taps_size if self.x3 else lib.e2fgvi_packed_conv_weight_f32x_taps_size)
                        if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_taps_size)
@@ -630,21 +682,25 @@ class PackedConvX:
             n = size_fn(self.Cout, self.KH, self.KW, self.cpg[0])
             if n < 0:
                 _L.check(int(n), "packed_conv_weight_x_taps_size")
-            self.wpacked = torch.empty(int(n), dtype=wdtype, device=w.device)
-            _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, self.KH, self.KW, self.cpg[0], _stream()),
+            if dry:
+                return None
+            t = torch.empty(int(n), dtype=wdtype, device=w.device)
+            _L.check(pack_fn(_ptr(w), _ptr(t), self.Cout, self.KH, self.KW, self.cpg[0], _stream()),
                      "pack_conv_weight_x_taps")
         else:
             size_fn = ((lib.e2fgvi_packed_conv_weight_f32x3_size if self.x3 else lib.e2fgvi_packed_conv_weight_f32x_size)
                        if self.f32 else lib.e2fgvi_packed_conv_weight_bf16x_size)
             pack_fn = ((lib.e2fgvi_pack_conv_weight_f32x3 if self.x3 else lib.e2fgvi_pack_conv_weight_f32x)
                        if self.f32 else lib.e2fgvi_pack_conv_weight_bf16x)
-            n = size_fn(self.Cout, groups, self.KH, self.KW, len(self.cpg), arr)
+            n = size_fn(self.Cout, self.groups, self.KH, self.KW, len(self.cpg), arr)
             if n < 0:
                 _L.check(int(n), "packed_conv_weight_x_size")
-            self.wpacked = torch.empty(int(n), dtype=wdtype, device=w.device)
-            _L.check(pack_fn(_ptr(w), _ptr(self.wpacked), self.Cout, groups, self.KH, self.KW, len(self.cpg), arr, _stream()),
+            if dry:
+                return None
+            t = torch.empty(int(n), dtype=wdtype, device=w.device)
+            _L.check(pack_fn(_ptr(w), _ptr(t), self.Cout, self.groups, self.KH, self.KW, len(self.cpg), arr, _stream()),
                      "pack_conv_weight_x")
-        self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
+        return t
 
     def out_hw(self, H, W):
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
@@ -671,7 +727,7 @@ class PackedConvX:
         d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout = self.groups, self.Cout
-        d.wpacked = self.wpacked.data_ptr()
+        d.wpacked = None if self._wp is None else self._wp.data_ptr()      # an fp32 layer's own packing: set by what launches it
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         _chk_any(out, "out")
         if out_nchw:
@@ -754,6 +810,7 @@ class PackedConvX:
                         # x3: six bf16 MACs per product, counted in fp32-pipe equivalents (a bf16 MAC occupies the matrix
                         # pipe for 157.3 / 2500 of the time of an fp32 MAC): `issued / fp32 peak` stays matrix-pipe time
                         issued=int(N * Ho * Wo * (-(-cout_g // 32) * 32) * self.groups * cin_p * K2 * (6 * 157.3 / 2500.0 if self.x3 else 1)))
+        d.wpacked = self.wpacked.data_ptr()
         rc = self._fn(C.byref(d), _stream())
         if rc != 0 and d.tile and self.tune:
             d.tile = 0                                    # a tabled tile this call's geometry rejects: the library's default
@@ -767,6 +824,7 @@ class PackedConvX:
         st = _stream()
         res = {}
         d.tile = 0
+        d.wpacked = self.wpacked.data_ptr()
         for _ in range(2):
             self._fn(C.byref(d), st)
         for _ in range(rounds * TUNE_REPS):
