@@ -257,7 +257,8 @@ class Engine(BF16Path):
             for layer in list(self.dec[:3]) + list(self.enc[5:]):
                 layer.alone = True
             for off, _dcn, bb in self.prop.values():
-                off[3].alone = True
+                for layer in list(off) + list(bb):      # (at one clip only conv_offset.6 is wide enough for the kernel to win)
+                    layer.alone = True
         # SPyNet runs on a side stream next to the encoder, in both precision modes.  Round 1 found the side stream's
         # kernels corrupted beside bf16 MFMA tiles; round 2 traced it to packed-fp32 VALU instructions consuming freshly
         # loaded registers (tools/probe/overlap_probe.hip, DESIGN.md "Stream overlap"): every kernel that can run on the
