@@ -251,3 +251,30 @@ def test_winograd_explicit_waits_are_checked_against_the_disassembly():
     import os
     if os.path.exists(build.OBJDUMP) and os.path.exists(os.path.join(build.CSRC, "build", "conv_wino.o")):
         assert build.verify_wino_waits() >= 32 + 28                 # 4 F(2x2) kernels x 8 wave roles + the wide-tile kernels
+
+
+def test_kernel_table_invariants_and_nearest_size_class_lookup(monkeypatch):
+    """deterministic kernel selection (ops._decision, e2fgvi_amd/tile_table.py): the table is in the format ops reads; the
+    wide-tile split-operand Winograd kernel is tabled only for layers that run alone on the chip; a size class the
+    table does not hold takes the decision of the nearest class of the same geometry, a geometry it does not hold at all none"""
+    from e2fgvi_amd import ops, tile_table
+    assert tile_table.TABLE_FORMAT == ops.TABLE_FORMAT and len(tile_table.TILES) > 100
+    wide = ops.W3_BASE + ops.W3_WIDE
+    assert any(v == wide for v in tile_table.TILES.values())
+    for k, v in tile_table.TILES.items():
+        assert isinstance(k, tuple) and isinstance(k[ops._SIZE_FIELD], int) and isinstance(v, int)
+        if v == wide:
+            assert k[-1] == "alone", k
+    if ops.AUTOTUNE:
+        return
+    monkeypatch.setattr(ops, "_TUNED", dict(tile_table.TILES))
+    monkeypatch.setattr(ops, "_NEAREST", {})
+    key = next(k for k in tile_table.TILES if k[0] != "x")
+    assert ops._decision(key) == tile_table.TILES[key]
+    same = sorted(k[ops._SIZE_FIELD] for k in tile_table.TILES
+                  if len(k) == len(key) and k[:ops._SIZE_FIELD] == key[:ops._SIZE_FIELD] and k[ops._SIZE_FIELD + 1:] == key[ops._SIZE_FIELD + 1:])
+    far = key[:ops._SIZE_FIELD] + (same[-1] + 3,) + key[ops._SIZE_FIELD + 1:]
+    top = key[:ops._SIZE_FIELD] + (same[-1],) + key[ops._SIZE_FIELD + 1:]
+    assert far not in tile_table.TILES and ops._decision(far) == tile_table.TILES[top]
+    unknown = (7777,) + key[1:]
+    assert ops._decision(unknown) is None
