@@ -41,7 +41,7 @@
 #endif
 
 #ifndef E2_WINO_VARIANT
-#define E2_WINO_VARIANT 0      // experiment switches (tools only): 1 = mid-stage prefetch of the upper waves, 2 = static s_setprio by SIMD partner, 4 = s_setprio around the MFMA block
+#define E2_WINO_VARIANT 0      // experiment switches (tools only): 1 = mid-stage prefetch of the upper waves, 2 = static s_setprio by SIMD partner, 4 = s_setprio around the MFMA block, 32 / 64 = M0 handling of dma_piece
 #endif
 #ifdef E2_WINO_TIMING
 // tools/wino_timing.py builds this file once more with -DE2_WINO_TIMING: every wave of the first 64 workgroups accumulates
@@ -164,10 +164,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 // build.verify_wino_waits() counts it in the disassembly like every other vector-memory instruction.  M0 is written in the
 // statement that reads it and restored (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void dma_piece(i32x4 rsrc, unsigned lds_dst, unsigned voff) {
-    unsigned keep;
     // (s_nop 2: five wait states between a v_readfirstlane / v_readlane that produced the resource words and the load that reads them)
+#if (E2_WINO_VARIANT & 32)
+    // experiment for DESIGN.md C4 (tools/c4_repro.py): M0 is NOT restored behind the piece -- if the piece reads M0 later than
+    // at issue (a stalled vector-memory queue), the restore of the product form below can overtake it
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+#elif (E2_WINO_VARIANT & 64)
+    // ... and the restore 32 idle cycles behind the piece (a bounded distance: tells a fixed latency from back-pressure)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+#else
+    unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+#endif
 }
 typedef __attribute__((address_space(3))) void wino_lds_void;
 
