@@ -72,6 +72,7 @@ def build(force=False, verbose=False, nopk_all=False, lib=None):
         verify_isa(objdir)
         if not nopk_all:
             verify_wino_waits(objdir)
+            verify_exit_reuse(objdir)
     return out
 
 
@@ -216,6 +217,68 @@ def verify_wino_waits(objdir=None, objects=("conv_wino.o", "conv_wino_x3.o", "co
     if not loops:
         raise RuntimeError("verify_wino_waits: no K loop with marked waits found (disassembly format changed?)")
     return loops
+
+
+def check_exit_reuse(obj, name, ins):
+    """For hipcc the destination of an inline-asm load is written when the statement ends.  The loads a K loop issues for the
+    stage PAST the end are still in flight when the loop exits; if the compiler reuses their registers (it did: for the
+    epilogue's address arithmetic, hoisted above the kernel's own `s_waitcnt vmcnt(0)`) the late data lands on top of the new
+    values whenever memory is slow -- DESIGN.md C4.  The source names those registers behind the wait; this check re-derives from
+    the disassembly that no vector instruction touches a weight register (a load destination that feeds an MFMA's B operand)
+    between a K-loop exit and the first vmcnt(0) behind it.  Applies to kernels whose non-LDS loads are all asm-issued."""
+    import re
+
+    def regs(o):
+        r = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", o):
+            r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", o):
+            r.add(int(m.group(1)))
+        return r
+
+    at = {a: i for i, (a, _, _) in enumerate(ins)}
+    exits = {}
+    for i, (a, m, o) in enumerate(ins[:-1]):
+        if m.startswith("s_cbranch") or m == "s_branch":
+            try:
+                off = int(o.split()[0])
+            except ValueError:
+                continue
+            off -= 65536 if off > 32767 else 0
+            tgt = ins[i + 1][0] + 4 * off
+            if tgt <= a and tgt in at and sum(1 for _, mm, _ in ins[at[tgt]:i + 1] if "mfma" in mm) >= 8 and i - at[tgt] < 3000:
+                exits[i] = min(exits.get(i, at[tgt]), at[tgt])
+    for e, s in exits.items():
+        body = ins[s:e + 1]
+        wregs = set()
+        for _, m, o in body:
+            if "mfma" in m:
+                wregs |= regs([x.strip() for x in o.split(",")][2])
+        dests = set()
+        for _, m, o in body:
+            if re.match(r"(buffer|global)_load", m) and o.split()[-1] != "lds" and regs(o.split(",")[0]) & wregs:
+                dests |= regs(o.split(",")[0])
+        for a, m, o in ins[e + 1:e + 801]:
+            if (m == "s_waitcnt" and "vmcnt(0)" in o) or m == "s_endpgm" or "mfma" in m:
+                break
+            if regs(o) & dests and not m.startswith("s_") and not re.match(r"(buffer|global)_load", m):
+                raise RuntimeError("%s: %s: 0x%x %s %s touches a register of a weight load that may still be in flight behind "
+                                   "the K loop (no vmcnt(0) yet)" % (obj, name[:60], a, m, o))
+    return len(exits)
+
+
+def verify_exit_reuse(objdir=None):
+    """check_exit_reuse over the kernels it applies to; returns the number of K-loop exits checked"""
+    objdir = objdir or os.path.join(CSRC, "build")
+    if not os.path.exists(OBJDUMP):
+        return 0
+    n = 0
+    for name, ins in _kernels(device_isa(os.path.join(objdir, "conv_wino_x3.o"))).items():
+        if "conv_wino_x3w_kernel" in name:
+            n += check_exit_reuse("conv_wino_x3.o", name, ins)
+    if not n:
+        raise RuntimeError("verify_exit_reuse: no K loop exit found in conv_wino_x3w_kernel (disassembly format changed?)")
+    return n
 
 
 if __name__ == "__main__":

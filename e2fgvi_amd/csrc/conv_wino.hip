@@ -1452,8 +1452,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
         case 6: k_loop(IC<3>{}, IC<0>{}); break;
         default: k_loop(IC<3>{}, IC<1>{}); break;
     }
-    // the planes and the patch pieces of the stages past the end are still in flight: they target registers and LDS the epilogue reuses
+    // The planes and the patch pieces of the stages past the end are still in flight: they target registers and LDS the epilogue
+    // reuses.  The plane registers are named behind the wait: for hipcc an asm load's destination is written when the statement
+    // ends, so without a later use it took bw's registers for the epilogue's address arithmetic and hoisted that above this
+    // wait -- the planes of the stage past the end (out of range: zeros) then landed ON TOP of those addresses whenever the memory
+    // system was slow enough to deliver them late: wrong output blocks beside a second stream (in every launch beside a device copy:
+    // tools/c4_repro.py), never alone.  DESIGN.md C4.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[a][n][pl]));
     __syncthreads();
 
     // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store

@@ -278,3 +278,38 @@ def test_kernel_table_invariants_and_nearest_size_class_lookup(monkeypatch):
     assert far not in tile_table.TILES and ops._decision(far) == tile_table.TILES[top]
     unknown = (7777,) + key[1:]
     assert ops._decision(unknown) is None
+
+
+def test_registers_of_loads_in_flight_behind_the_k_loop_are_not_reused():
+    """DESIGN.md C4 (round 4): for hipcc an inline-asm load's destination is written when the statement ends; the wide-tile kernel's
+    weight loads for the stage past the end were still in flight when the compiler reused their registers for the epilogue's
+    addresses.  build.check_exit_reuse re-derives from the disassembly that nothing touches such a register between a K-loop exit
+    and the first vmcnt(0): here on a synthetic kernel (clean / reused) and on the object of this build."""
+    from e2fgvi_amd import build
+
+    def isa(reuse):
+        a, out = [0], []
+
+        def emit(m, o=""):
+            out.append((a[0], m, o))
+            a[0] += 4
+        emit("s_mov_b32", "s0, 4")
+        top = a[0]
+        for _ in range(8):
+            emit("v_mfma_f32_32x32x16_bf16", "v[0:15], v[100:103], v[40:43], v[0:15]")
+        emit("buffer_load_dwordx4", "v[40:43], v200, s[8:11], s3 offen")
+        emit("s_cmp_lg_u32", "s0, 0")
+        off = (top - (a[0] + 4)) // 4
+        emit("s_cbranch_scc1", str(off & 0xFFFF))
+        if reuse:
+            emit("v_add_u32_e32", "v41, s2, v7")                 # the epilogue's arithmetic in a register the load still targets
+        emit("s_waitcnt", "vmcnt(0)")
+        emit("v_add_u32_e32", "v41, s2, v7")
+        emit("s_endpgm")
+        return out
+    assert build.check_exit_reuse("x.o", "k", isa(False)) == 1
+    with pytest.raises(RuntimeError):
+        build.check_exit_reuse("x.o", "k", isa(True))
+    import os
+    if os.path.exists(build.OBJDUMP) and os.path.exists(os.path.join(build.CSRC, "build", "conv_wino_x3.o")):
+        assert build.verify_exit_reuse() >= 8                      # the eight wave roles of conv_wino_x3w_kernel

@@ -17,6 +17,9 @@ from e2fgvi_amd import ops
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+# further arguments: Winograd tile codes of more victims on the encoder.8 shape (45132 = four positions per wave, 40164 / 40132 = round
+# 3's eight-wave split-operand shapes, 2464 = fp32 F(2x4), 64 = fp32 F(2x2)): every kernel with asm-issued weight prefetches
+more = [int(a) for a in sys.argv[3:]]
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(11)
 rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
@@ -46,10 +49,14 @@ def aggress(kind, n):
             p4([p4x], out=p4y, act=ops.ACT_LRELU, slope=0.2, tile=ops.W3_BASE + 5132)
 
 
+for code in more:
+    victims["encoder.8 tile %d" % code] = victims["encoder.8"][:2] + (384, code)
 side = torch.cuda.Stream(device=dev)
 main = torch.cuda.current_stream()
 print("library:", os.environ.get("E2FGVI_LIB", "in-tree"))
-for vname, (layer, srcs, cout) in victims.items():
+for vname, spec in victims.items():
+    layer, srcs, cout = spec[:3]
+    WIDE = spec[3] if len(spec) > 3 else ops.W3_BASE + ops.W3_WIDE
     ref = torch.empty(10, 60, 108, cout, device=dev)
     layer(srcs, out=ref, act=ops.ACT_LRELU, slope=0.2, tile=WIDE)
     torch.cuda.synchronize()
@@ -71,5 +78,5 @@ for vname, (layer, srcs, cout) in victims.items():
                     idx = d.nonzero()
                     for n_, y, x in idx[:: max(1, len(idx) // 8)].tolist():
                         blocks.add((n_, y // 16, x // 16))
-        print("%-11s beside %-7s: %4d of %4d launches differ from the launch alone%s"
+        print("%-22s beside %-7s: %4d of %4d launches differ from the launch alone%s"
               % (vname, kind, bad, rounds * per, ("   16x16 blocks (image, by, bx): %s" % sorted(blocks)[:8]) if bad else ""), flush=True)
