@@ -242,11 +242,6 @@ def main():
     from e2fgvi_amd import ops, runner
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
 
-    if world > 1 or args.force_dist:
-        # the sharded step runs its all-gather under the next forward: the kernel that must run alone on the chip is off from the
-        # first forward on (runner.ShardedStep would clear it later), so the FLOP trace, `config.kernels` and
-        # `single_gpu_same_work` describe the kernels the timed steps run
-        ops.WIDE_X3_OK = False
     H, W = [int(v) for v in args.hw.lower().split("x")]
     if H > W:                                            # tolerate WxH
         H, W = W, H

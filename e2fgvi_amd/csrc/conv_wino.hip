@@ -1353,13 +1353,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 for (int n = 0; n < TN; ++n) acc[a][M][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, uh[n], acc[a][M][n], 0, 0, 0);
                 if constexpr (LAST) {
                     __builtin_amdgcn_sched_barrier(0);
-                    // ONE load per asm statement, each behind its own s_nop 4.  Round 4 tried the six loads of a position back to back
-                    // in one statement (one s_nop), the reloads moved behind the other position's MFMA block / the stage barrier, the
-                    // pieces issued earlier in the stage: every such build returned wrong encoder blocks in one forward out of three
-                    // as soon as SPyNet ran beside the encoder on the side stream (single lanes groups 0-15 / 32-47 of single tile
-                    // rows; deterministic and correct without the side stream), this one did not in 60 forwards and 8 suite runs
-                    // (profiles/r04_x3w_plane_reload.txt).  The mechanism is not understood; the order below is the one that is
-                    // measured clean, and tests/test_gpu_model.py::test_stream_overlap_* is the tripwire.
+                    // ONE load per asm statement, each behind its own s_nop 4 (a restored scalar offset: load_plane).  The reloads of
+                    // the LAST stage target the stage past the end (out of range: zeros) and are still in flight behind the loop:
+                    // see the wait + register claims in front of the epilogue (the cause of round 4's wrong blocks beside a second
+                    // stream).
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
 #pragma unroll

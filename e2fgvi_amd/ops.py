@@ -68,11 +68,12 @@ W3_BASE = 40000
 #  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
 #  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
 W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.environ.get("E2FGVI_W3_SKIP", "").split(","))     # E2FGVI_W3_SKIP=6064: A/B runs
-# The wide-tile split-operand Winograd kernel (6064) is only taken by layers that run ALONE on the chip (PackedConv.alone: the
-# engine sets it on the layers behind the join of its two streams -- decoder, conv_offset.6) and only while WIDE_X3_OK: beside the
-# SPyNet side stream it returned wrong 16x16-pixel blocks in one forward out of three (builds of it; the shipped form in one
-# of ~20 two-clip forwards), unexplained after the experiments of profiles/r04_x3w_plane_reload.txt.  runner.ShardedStep clears
-# WIDE_X3_OK when an RCCL gather runs under the next forward.  W3_WIDE_FALLBACK: what such a layer runs instead.
+# The wide-tile split-operand Winograd kernel (6064) is, in this round's table, taken only by layers flagged PackedConv.alone (the
+# engine sets it on the layers behind the join of its two streams): beside the SPyNet stream it returned wrong 16x16-pixel blocks.
+# Root cause (found at the end of round 4): the weight loads for the stage past the end were in flight while the
+# compiler had reused their registers for the epilogue's addresses; fixed in conv_wino.hip (72 of 72 launches wrong beside device
+# copies before, 0 of 48 after: tools/c4_repro.py) and guarded by build.verify_exit_reuse().  The `alone` gate stays until the
+# table is re-timed on a GPU with the kernel allowed everywhere (tools/make_tile_table.py); E2FGVI_W3_WIDE=0 switches the kernel off.
 WIDE_X3_OK = os.environ.get("E2FGVI_W3_WIDE", "1") != "0"
 W3_WIDE = 6064
 W3_WIDE_FALLBACK = 164

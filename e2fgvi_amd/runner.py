@@ -64,10 +64,6 @@ class ShardedStep:
         self._pending = None       # (work, gathered buffer) of the step whose gather is in flight
         self._last = None
         self._synced = group_world <= 1
-        if self.gather:
-            # the all-gather of step k runs under the forward of step k + 1: the layers that otherwise run alone do not (ops.WIDE_X3_OK)
-            from . import ops
-            ops.WIDE_X3_OK = False
 
     def _forward(self):
         out, _ = self.net(self.x, self.lt)

@@ -85,17 +85,13 @@ def _step_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from e2fgvi_amd.runner import ShardedStep
-    from e2fgvi_amd import ops as _ops
-    _ops.WIDE_X3_OK = True
     step = ShardedStep(_StepNet(rank), torch.zeros(1, 2, 3, 4, 4), 2, group_world=world, use_graph=False)
-    # a gather runs under the next forward: the kernel that must run alone on the chip is off
-    wide_off = _ops.WIDE_X3_OK is False
     got = []
     for _ in range(3):
         r = step.run()                       # gathered frames of the PREVIOUS step (pipelined), None at first
         got.append(None if r is None else r.clone())
     last = step.finish().clone()
-    ok = got[0] is None and wide_off
+    ok = got[0] is None
     for k, g in ((1, got[1]), (2, got[2]), (3, last)):
         # step k: rank 0 contributed the value k, rank 1 the value 100 + k; rank-major order
         ok = ok and tuple(g.shape) == (world * 2, 3, 4, 4) and bool((g[:2] == float(k)).all()) and bool((g[2:] == 100.0 + k).all())

@@ -295,7 +295,7 @@ def test_stream_overlap_is_bit_identical_to_serial(dev):
     sd = synth_state_dict("e2fgvi", "stress", 0)
     # t = 4: many trials; t = 10, l_t = 10: the headline shapes, i.e. the kernels the decision table selects only for 10-frame
     # batches (round 4: conv_wino_x3w beside SPyNet -- builds of it that were clean alone returned wrong encoder blocks in one
-    # overlapped forward out of three, profiles/r04_x3w_plane_reload.txt)
+    # overlapped forward out of three: registers of loads in flight behind the K loop, reused by the compiler -- DESIGN.md C4)
     for precision, t, lt, trials in (("fp32", 4, 3, 200), ("bf16", 4, 3, 200), ("fp32", 10, 10, 40)):
         x = synth_clip(1, t, 240, 432, seed=3, moving=True)[0].to(dev)
         eng = Engine(sd, "e2fgvi", dev, precision=precision)
