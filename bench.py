@@ -82,13 +82,23 @@ def traced_work(net, x, lt):
     return 2e-9 * sum(r["macs"] for r in rows), 2e-9 * sum(r["issued"] for r in rows), len(rows)
 
 
-def cpu_baseline(sd, model, H, W, t, lt, hip_out=None):
+def _parity(hip_out, ref, what):
+    d = (hip_out.double() - ref.double()).abs()
+    rms = float(ref.double().pow(2).mean().sqrt())
+    return {"max_abs": float("%.3e" % d.max()), "max_abs_over_rms": float("%.3e" % (float(d.max()) / rms)),
+            "rms_of_reference": float("%.3e" % rms), "weights": what}
+
+
+def cpu_baseline(sd, model, H, W, t, lt, hip_out=None, stress=None):
     """The CPU restatement of the reference forward (oracle/e2fgvi_oracle.py, kind "port": the reference's own Python
     cannot travel to the GPU box) timed on this host's cores on a bounded sample of the same workload: ONE clip,
     1 warm-up + median of 3 forwards for the 432x240 workload; the HQ resolutions take minutes per
     clip on a CPU, there the sample is one un-warmed forward of a 2-frame clip of the same resolution.
     hip_out: the frames the TIMED configuration (same clip, same weights, the timed kernels) produced -- the oracle's output of
-    the first forward is compared with them and returned as the second value: the bench line carries its own parity."""
+    the first forward is compared with them and returned as the second value: the bench line carries its own parity.
+    stress: (state_dict, hip frames) of the same clip under the stress weights of SURVEY.md 8(c) T3 (O(1) activations, non-zero
+    conv_offset[-1]: real DCN offsets and masks) -- one more oracle forward, compared the same way (round 5: at default init
+    conv_offset[-1] == 0 makes offsets = flow and mask = 0.5, a regime in which a 1e-3 absolute bound is weak)."""
     from e2fgvi_amd.synth import synth_clip
     from oracle import e2fgvi_oracle as O
     host = os.cpu_count() or 1
@@ -106,12 +116,18 @@ def cpu_baseline(sd, model, H, W, t, lt, hip_out=None):
         ref, _ = O.forward(sd, x, ls, model)
         times.append(time.perf_counter() - t0)
         if k == 0 and hip_out is not None and tuple(hip_out.shape) == tuple(ref.shape):
-            d = (hip_out.double() - ref.double()).abs()
-            rms = float(ref.double().pow(2).mean().sqrt())
-            parity = {"max_abs": float("%.3e" % d.max()), "max_abs_over_rms": float("%.3e" % (float(d.max()) / rms)),
-                      "rms_of_reference": float("%.3e" % rms), "bound_max_abs": 1e-3, "vs": "oracle port (oracle/e2fgvi_oracle.py, torch CPU "
-                      "fp32) on the timed clip and weights; the HIP frames are those of the timed configuration (same engine, same "
-                      "kernel decisions as config.kernels)"}
+            parity = {"default": _parity(hip_out, ref, "reference's init_weights distribution (the timed weights)")}
+    if parity is not None and stress is not None:
+        ref, _ = O.forward(stress[0], x, ls, model)
+        if tuple(stress[1].shape) == tuple(ref.shape):
+            parity["stress"] = _parity(stress[1], ref, "stress weights (synth_state_dict 'stress': O(1) activations, non-zero "
+                                                       "conv_offset[-1], random sc.bias; SURVEY.md 8c T3)")
+    if parity is not None:
+        parity.update({"max_abs": max(v["max_abs"] for v in parity.values()),
+                       "max_abs_over_rms": max(v["max_abs_over_rms"] for v in parity.values()), "bound_max_abs": 1e-3,
+                       "vs": "oracle port (oracle/e2fgvi_oracle.py, torch CPU fp32) on the timed clip; the HIP frames are those of the "
+                             "timed configuration (same engine class, same kernel decisions as config.kernels; `default` = the very "
+                             "engine / HIP graph that was timed, `stress` = a second engine on the same clip)"})
     timed = times[1:] if small else times
     dt = statistics.median(timed)
     return {"value": round(ts / dt, 4), "unit": "frames/s", "cores": cores, "host_cores": host, "kind": "port",
@@ -362,27 +378,40 @@ def main():
                              "and the forward is bound by VALU / LDS-fill / launch latency instead (DESIGN.md section 6): `frac` "
                              "falls while frames/s rise; `frac_algorithmic` is the reference's FLOPs against the fp32 MFMA peak"},
     }
-    # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the
-    # summary of the last collection is committed under profiles/ and quoted here (bytes per forward of one clip)
+    # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the summary of the
+    # last collection is committed under profiles/ TOGETHER WITH the key of the library it measured (lib.library_key()), and it is
+    # quoted here only when that key is the key of the library this process has just timed -- a figure of an older library is
+    # named in the note and NOT reported as this tree's traffic (round 4's line carried round 3's number)
+    from e2fgvi_amd import lib as _lib
+    lib_key = _lib.library_key()
+    out["library_sha16"] = lib_key
     traffic_cfg = None
     if b == 1 and (t, lt) == (10, 10) and not hq and args.precision == "fp32":
         traffic_cfg = ""
     elif b == 1 and (t, lt) == (10, 10) and hq and (H, W) == (720, 1296) and args.precision == "bf16":
         traffic_cfg = "_hq720_bf16"
+    elif b == 1 and (t, lt) == (20, 20) and hq and (H, W) == (1080, 1944) and args.precision == "bf16":
+        traffic_cfg = "_hq1080_bf16"
     if traffic_cfg is not None:
-        for tag in ("r04", "r03", "r02", "r01"):
-            tfile = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (tag, traffic_cfg))
-            if os.path.exists(tfile):
-                try:
-                    tj = json.load(open(tfile))
-                    out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
-                    out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, "
-                                                       "separate passes (profiles/%s_hbm_traffic%s.json); fabric-side, includes "
-                                                       "Infinity-Cache hits; compulsory minimum (input + weights + output) is %s GB/clip"
-                                                       % (tag, traffic_cfg, "0.19" if not hq else "0.39"))
-                    break
-                except Exception:
-                    pass
+        import glob
+        stale = []
+        for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic%s.json" % traffic_cfg)), reverse=True):
+            try:
+                tj = json.load(open(tfile))
+            except Exception:
+                continue
+            if tj.get("library_sha16") != lib_key:
+                stale.append(os.path.basename(tfile))
+                continue
+            out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
+            out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, separate "
+                                               "passes (profiles/%s, measured on this library: sha16 %s); fabric-side, includes Infinity-"
+                                               "Cache hits; compulsory minimum (input + weights + output) is %s GB/clip"
+                                               % (os.path.basename(tfile), lib_key, "0.19" if not hq else "0.39"))
+            break
+        else:
+            out["roofline"]["traffic_note"] = ("no PMC collection of this library (sha16 %s) under profiles/: bash tools/pmc.sh <tag>; "
+                                               "collections of other builds, not quoted: %s" % (lib_key, ", ".join(stale) or "none"))
     if rank == 0:
         if not hq and args.precision == "fp32":
             dom = runner.dominant_kernel_probe(net, dev)
@@ -393,7 +422,7 @@ def main():
             for dfile in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_dominant_kernel_traffic*.json")), reverse=True):
                 try:
                     dj = json.load(open(dfile))
-                    if dj.get("kernel_tag", "conv_wino4<F(2x4),64>") != dom["kernel"].split(" (")[0]:
+                    if dj.get("kernel_tag", "conv_wino4<F(2x4),64>") != dom["kernel"].split(" (")[0] or dj.get("library_sha16") != lib_key:
                         continue
                     dom["traffic"] = round(dj["hbm_bytes_per_launch"])
                     dom["traffic_note"] = "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s)" % os.path.basename(dfile)
@@ -412,7 +441,17 @@ def main():
             # very engine / kernel decisions / HIP graph that were timed
             hip_frames = step.finish()
             hip_frames = (hip_frames if hip_frames is not None else net(x, lt)[0])[:t].float().cpu() if not step.pack_u8 else None
-            out["cpu_baseline"], parity = cpu_baseline(sd, args.model, H, W, t, lt, hip_out=hip_frames)
+            stress = None
+            if hip_frames is not None and (H, W) == (240, 432):
+                # the same clip under the stress weights: a second engine, the same (table-driven) kernel decisions
+                sd_s = synth_state_dict(args.model, "stress", 0)
+                net_s = importlib.import_module("model." + args.model).InpaintGenerator()
+                net_s.load_state_dict(sd_s)
+                net_s = net_s.to(dev).eval()
+                net_s.precision = args.precision
+                stress = (sd_s, net_s(x[:1], lt)[0][:t].float().cpu())
+                del net_s
+            out["cpu_baseline"], parity = cpu_baseline(sd, args.model, H, W, t, lt, hip_out=hip_frames, stress=stress)
             if parity is not None:
                 out["parity"] = parity
     if same_work is not None:

@@ -219,65 +219,182 @@ def verify_wino_waits(objdir=None, objects=("conv_wino.o", "conv_wino_x3.o", "co
     return loops
 
 
-def check_exit_reuse(obj, name, ins):
-    """For hipcc the destination of an inline-asm load is written when the statement ends.  The loads a K loop issues for the
-    stage PAST the end are still in flight when the loop exits; if the compiler reuses their registers (it did: for the
-    epilogue's address arithmetic, hoisted above the kernel's own `s_waitcnt vmcnt(0)`) the late data lands on top of the new
-    values whenever memory is slow -- DESIGN.md C4.  The source names those registers behind the wait; this check re-derives from
-    the disassembly that no vector instruction touches a weight register (a load destination that feeds an MFMA's B operand)
-    between a K-loop exit and the first vmcnt(0) behind it.  Applies to kernels whose non-LDS loads are all asm-issued."""
+def _vregs(text):
+    """vector registers named in an operand text"""
     import re
+    r = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        r.add(int(m.group(1)))
+    return r
 
-    def regs(o):
-        r = set()
-        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", o):
-            r.update(range(int(m.group(1)), int(m.group(2)) + 1))
-        for m in re.finditer(r"\bv(\d+)\b", o):
-            r.add(int(m.group(1)))
-        return r
 
-    at = {a: i for i, (a, _, _) in enumerate(ins)}
-    exits = {}
-    for i, (a, m, o) in enumerate(ins[:-1]):
-        if m.startswith("s_cbranch") or m == "s_branch":
-            try:
-                off = int(o.split()[0])
-            except ValueError:
-                continue
+def _successors(ins, at):
+    """control-flow successors (instruction indices) of every instruction of a kernel; objdump prints a branch target as the
+    unsigned 16-bit word offset from the next instruction.  Raises on an indirect jump (nothing here has one)."""
+    succ = []
+    for i, (a, m, o) in enumerate(ins):
+        if m in ("s_endpgm", "s_endpgm_saved"):
+            succ.append(())
+        elif m == "s_branch" or m.startswith("s_cbranch"):
+            off = int(o.split()[0])
             off -= 65536 if off > 32767 else 0
-            tgt = ins[i + 1][0] + 4 * off
-            if tgt <= a and tgt in at and sum(1 for _, mm, _ in ins[at[tgt]:i + 1] if "mfma" in mm) >= 8 and i - at[tgt] < 3000:
-                exits[i] = min(exits.get(i, at[tgt]), at[tgt])
-    for e, s in exits.items():
-        body = ins[s:e + 1]
-        wregs = set()
-        for _, m, o in body:
-            if "mfma" in m:
-                wregs |= regs([x.strip() for x in o.split(",")][2])
-        dests = set()
-        for _, m, o in body:
-            if re.match(r"(buffer|global)_load", m) and o.split()[-1] != "lds" and regs(o.split(",")[0]) & wregs:
-                dests |= regs(o.split(",")[0])
-        for a, m, o in ins[e + 1:e + 801]:
-            if (m == "s_waitcnt" and "vmcnt(0)" in o) or m == "s_endpgm" or "mfma" in m:
-                break
-            if regs(o) & dests and not m.startswith("s_") and not re.match(r"(buffer|global)_load", m):
-                raise RuntimeError("%s: %s: 0x%x %s %s touches a register of a weight load that may still be in flight behind "
-                                   "the K loop (no vmcnt(0) yet)" % (obj, name[:60], a, m, o))
-    return len(exits)
+            tgt = at.get(a + 4 + 4 * off)
+            if tgt is None:
+                raise RuntimeError("branch at 0x%x leaves the kernel" % a)
+            succ.append((tgt,) if m == "s_branch" else (tgt, i + 1))
+        elif m.startswith("s_setpc") or m.startswith("s_swappc"):
+            raise RuntimeError("indirect jump at 0x%x: control flow cannot be followed" % a)
+        else:
+            succ.append((i + 1,) if i + 1 < len(ins) else ())
+    return succ
 
 
-def verify_exit_reuse(objdir=None):
-    """check_exit_reuse over the kernels it applies to; returns the number of K-loop exits checked"""
+def check_exit_reuse(obj, name, ins, min_mfma=8):
+    """For hipcc the destination of an inline-asm load is written when the statement ends.  The weight loads a K loop issues for
+    the stage PAST the end are still in flight when the loop exits; if the compiler reuses their registers (it did: for the
+    epilogue's address arithmetic, hoisted above the kernel's own `s_waitcnt vmcnt(0)`) the late data lands on top of the new values
+    whenever memory is slow -- DESIGN.md C4.  The sources name those registers behind a post-loop wait; this check re-derives from
+    the disassembly that it worked:
+
+      * weight registers = destinations of non-LDS buffer loads that feed an MFMA's B operand anywhere in the kernel;
+      * K loops = the strongly connected components of the control-flow graph that hold >= min_mfma MFMAs;
+      * from every control-flow edge that LEAVES such a span the walk follows the code -- unconditional branches, both arms of
+        conditional ones -- until the first wait that contains vmcnt(0) on each path; any vector instruction on the way that
+        reads or writes a weight register is an error, and so is reaching s_endpgm (or another K loop) without that wait;
+      * the wave roles of these kernels (`switch (wave)`, wave = threadIdx.x >> 6) are compiled as exec-masked if / else regions
+        although every lane of a wave takes the same arm.  The walk carries that fact: passing the flip to an `else` arm
+        (s_andn2_saveexec_b64, or the s_xor_b64 exec, exec, ... that follows an s_or_saveexec_b64) with live lanes leaves none (the wave took the `then` arm with
+        all its lanes), until the region's end restores the mask (s_or_b64 exec, exec, ...); with no live lane vector instructions
+        do nothing, s_cbranch_execz is taken and s_cbranch_execnz is not.  Without this the walk would run from one role's loop
+        exit straight into the next role's prologue (the round-4 version of this check stopped there, at that prologue's wait,
+        and could pass without having seen the shared epilogue).
+
+    Returns the number of exit edges walked; raises RuntimeError on a violation."""
+    import re
+    at = {a: i for i, (a, _, _) in enumerate(ins)}
+    succ = _successors(ins, at)
+    is_mfma = [("mfma" in m) for _, m, _ in ins]
+    breg = set()
+    for (_, m, o), f in zip(ins, is_mfma):
+        if f:
+            breg |= _vregs([x.strip() for x in o.split(",")][2])
+    wregs = set()
+    for _, m, o in ins:
+        if re.match(r"buffer_load_dword", m) and not o.rstrip().endswith(" lds"):
+            d = _vregs(o.split(",")[0])
+            if d & breg:
+                wregs |= d
+    if not wregs:
+        return 0
+    # K loops: the strongly connected components of the control-flow graph that hold >= min_mfma MFMAs (Tarjan, iterative).  Address
+    # ranges of backward branches would not do: block placement puts parts of the epilogue in front of the loops.
+    n = len(ins)
+    index, low, comp = [-1] * n, [0] * n, [-1] * n
+    stack, onstack, counter, ncomp = [], [False] * n, 0, 0
+    for root in range(n):
+        if index[root] >= 0:
+            continue
+        work = [(root, 0)]
+        while work:
+            v, pi = work.pop()
+            if pi == 0:
+                index[v] = low[v] = counter
+                counter += 1
+                stack.append(v)
+                onstack[v] = True
+            recurse = False
+            for j in range(pi, len(succ[v])):
+                w = succ[v][j]
+                if index[w] < 0:
+                    work.append((v, j + 1))
+                    work.append((w, 0))
+                    recurse = True
+                    break
+                if onstack[w]:
+                    low[v] = min(low[v], index[w])
+            if recurse:
+                continue
+            if low[v] == index[v]:
+                while True:
+                    w = stack.pop()
+                    onstack[w] = False
+                    comp[w] = ncomp
+                    if w == v:
+                        break
+                ncomp += 1
+            if work:
+                u = work[-1][0]
+                low[u] = min(low[u], low[v])
+    members = {}
+    for k in range(n):
+        members.setdefault(comp[k], []).append(k)
+    loops = [m for m in members.values() if len(m) > 1 and sum(1 for k in m if is_mfma[k]) >= min_mfma]
+    inside = [False] * n
+    for m in loops:
+        for k in m:
+            inside[k] = True
+    edges = 0
+    for m in loops:
+        mine = set(m)
+        starts = set()
+        for k in m:
+            for t in succ[k]:
+                if t not in mine:
+                    starts.add(t)
+        for st in sorted(starts):
+            edges += 1
+            seen, todo = set(), [(st, False)]
+            while todo:
+                k, dead = todo.pop()                 # dead: no live lane (the wave is passing over another role's region)
+                if (k, dead) in seen:
+                    continue
+                seen.add((k, dead))
+                a, m, o = ins[k]
+                if m == "s_waitcnt" and "vmcnt(0)" in o:
+                    continue
+                if m.startswith("s_endpgm") or (inside[k] and not dead):
+                    raise RuntimeError("%s: %s: the path from the K-loop exit at 0x%x reaches 0x%x (%s) without an s_waitcnt vmcnt(0): "
+                                       "weight loads may still be in flight" % (obj, name[:60], ins[st][0], a,
+                                                                                "another K loop" if inside[k] else m))
+                if not dead and not m.startswith("s_") and _vregs(o) & wregs:
+                    raise RuntimeError("%s: %s: 0x%x %s %s touches a register of a weight load that may still be in flight behind the "
+                                       "K loop left at 0x%x (no vmcnt(0) yet)" % (obj, name[:60], a, m, o, ins[st][0]))
+                flip = m == "s_andn2_saveexec_b64" or (m == "s_xor_b64" and o.startswith("exec"))
+                if flip and not dead:
+                    dead = True
+                elif m in ("s_or_b64", "s_mov_b64") and o.startswith("exec"):
+                    dead = False
+                nxt = succ[k]
+                if dead and m == "s_cbranch_execz":
+                    nxt = nxt[:1]
+                elif dead and m == "s_cbranch_execnz":
+                    nxt = nxt[1:]
+                todo.extend((t, dead) for t in nxt)
+    return edges
+
+
+EXIT_REUSE_OBJECTS = ("conv_wino.o", "conv_wino_x3.o", "conv_wino4.o")
+
+
+def verify_exit_reuse(objdir=None, objects=EXIT_REUSE_OBJECTS):
+    """check_exit_reuse over every Winograd kernel of the library (all of them prefetch their weights past the end of the K loop
+    through inline asm); returns the number of K-loop exit edges walked"""
     objdir = objdir or os.path.join(CSRC, "build")
     if not os.path.exists(OBJDUMP):
         return 0
     n = 0
-    for name, ins in _kernels(device_isa(os.path.join(objdir, "conv_wino_x3.o"))).items():
-        if "conv_wino_x3w_kernel" in name:
-            n += check_exit_reuse("conv_wino_x3.o", name, ins)
+    for obj in objects:
+        for name, ins in _kernels(device_isa(os.path.join(objdir, obj))).items():
+            if "conv_wino" not in name or "pack_" in name:
+                continue
+            k = check_exit_reuse(obj, name, ins)
+            if not k:
+                raise RuntimeError("verify_exit_reuse: no K-loop exit found in %s: %s (disassembly format changed?)" % (obj, name[:60]))
+            n += k
     if not n:
-        raise RuntimeError("verify_exit_reuse: no K loop exit found in conv_wino_x3w_kernel (disassembly format changed?)")
+        raise RuntimeError("verify_exit_reuse: no Winograd kernel found")
     return n
 
 

@@ -40,20 +40,11 @@
 #define E2_WINO_X3 0           // 1: the split-bf16 build of this file (conv_wino_x3.o): only the X3 kernels and their entry points
 #endif
 
-#ifndef E2_WINO_VARIANT
-#define E2_WINO_VARIANT 0      // experiment switches (tools only): 1 = mid-stage prefetch of the upper waves, 2 = static s_setprio by SIMD partner, 4 = s_setprio around the MFMA block, 32 / 64 = M0 handling of dma_piece
-#endif
-#ifdef E2_WINO_TIMING
-// tools/wino_timing.py builds this file once more with -DE2_WINO_TIMING: every wave of the first 64 workgroups accumulates
-// the s_memtime cycles it spends in five segments of the K loop (waiting for its weights / transform + MFMA issue /
-// parking the next stage / issuing the stage after / the stage barrier) and writes the sums here at the end.  Diagnostics
-// only -- the product library is built without it.
-__device__ unsigned long long e2_wino_dbg[64 * 8 * 8];
-__device__ unsigned long long e2_wino_dbg2[64 * 8 * 4];      // conv_wino_x3w_kernel: cycles before the K loop / K loop / epilogue / whole kernel
-#define E2T_NOW() __builtin_readcyclecounter()
-#define E2T(...) __VA_ARGS__
-#else
-#define E2T(...)
+// The register claims behind the K loops: an empty asm that names a weight register as read and written, placed
+// behind the post-loop s_waitcnt vmcnt(0) -- the register stays allocated until the load that was in flight has landed.
+// tests/test_host_logic.py compiles this file once with the macro defined empty and expects build.check_exit_reuse() to reject it.
+#ifndef E2_CLAIM_AFTER_LOOP
+#define E2_CLAIM_AFTER_LOOP(r) asm volatile("" : "+v"(r))
 #endif
 
 namespace {
@@ -165,20 +156,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // statement that reads it and restored (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void dma_piece(i32x4 rsrc, unsigned lds_dst, unsigned voff) {
     // (s_nop 2: five wait states between a v_readfirstlane / v_readlane that produced the resource words and the load that reads them)
-#if (E2_WINO_VARIANT & 32)
-    // experiment for DESIGN.md C4 (tools/c4_repro.py): M0 is NOT restored behind the piece -- if the piece reads M0 later than
-    // at issue (a stalled vector-memory queue), the restore of the product form below can overtake it
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-#elif (E2_WINO_VARIANT & 64)
-    // ... and the restore 32 idle cycles behind the piece (a bounded distance: tells a fixed latency from back-pressure)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
-#endif
 }
 typedef __attribute__((address_space(3))) void wino_lds_void;
 
@@ -273,11 +253,15 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
     unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
     unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
     int cur_cpg = p.cpg[0];
+    int raw_left = p.nchunks;       // chunks of the walk still inside the layer (see load_raw)
     f32x4 rraw[SC][RAW_IT];
     auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
         const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
         const unsigned chan = cur_chan + (unsigned)c0 * 4u + raw_kq16;
-        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;   // a source may end in the middle of a chunk (cpg % 8 == 4)
+        // a source may end in the middle of a chunk (cpg % 8 == 4); chunks past the end (the prefetch runs a stage ahead of the K
+        // loop) fetch out of range: zeros, returned without a memory access -- the wait behind the K loop then costs nothing and
+        // the first chunks are not re-read for nothing
+        const bool cvalid = raw_left-- > 0 && c0 + (int)(raw_kq16 >> 2) < cur_cpg;
 #pragma unroll
         for (int it = 0; it < RAW_IT; ++it) {
             // a select, never control flow: exactly ONE load per item on every path (the explicit vmcnt counts rely on
@@ -318,8 +302,8 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
     // The chunk -> (source, channel) map is STATELESS here (chunk index -> source by comparing with the per-source chunk
     // prefixes, everything captured by value): with the running (source, channel) state of load_raw, mutated inside this
     // lambda from 48 inlined call sites, hipcc left the closure -- and with it the whole parameter block -- in scratch
-    // memory (hundreds of scratch loads + its own vmcnt waits in the K loop).  Chunks past the end re-read the last chunk:
-    // their weights are zeros.
+    // memory (hundreds of scratch loads + its own vmcnt waits in the K loop).  Chunks past the end take the last chunk's
+    // parameters and fetch out of range.
     const int dpre1 = (dsg0 + 7) / 8, dpre2 = dpre1 + (p.nsrc > 1 ? (dsg1 + 7) / 8 : 0), dpre3 = dpre2 + (p.nsrc > 2 ? (dsg2 + 7) / 8 : 0);
     const int dnsrc = p.nsrc, dlast = p.nchunks - 1;
     auto dma_chunk = [=, &dma_pix, &dma_kq16](auto W_, auto NPW_, int chunk, unsigned lds_chunk) __attribute__((always_inline)) {
@@ -349,7 +333,8 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
         const unsigned chan = cchan + (unsigned)cc0 * 4u;
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            const bool cvalid = cc0 + (int)(dma_kq16[j] >> 2) < ccpg;       // a source may end in the middle of a chunk
+            // a source may end in the middle of a chunk; chunks past the end fetch out of range (zeros, no memory access)
+            const bool cvalid = chunk <= dlast && cc0 + (int)(dma_kq16[j] >> 2) < ccpg;
             unsigned off = (cvalid && dma_pix[j] != OOB) ? dma_pix[j] * cld4 + chan + dma_kq16[j] : OOB;
             asm volatile("" : "+v"(off));
             dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
@@ -443,7 +428,6 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
         __syncthreads();
     }
 
-    E2T(unsigned long long tsum[5]; for (int k_ = 0; k_ < 5; ++k_) tsum[k_] = 0; const unsigned long long t_k0 = E2T_NOW();)
     // the K loop, specialised on the wave's role so that the input transform is plain adds / subtracts
     auto k_loop = [&](auto XI_, auto PB_) __attribute__((always_inline)) {
         constexpr int XI = decltype(XI_)::value;
@@ -454,7 +438,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
         // therefore do it in the MIDDLE of the stage, under the MFMAs of their SIMD partners, and vice versa.  The target
         // buffer is free for the whole stage (its readers passed the previous barrier) and the stage barrier still follows
         // every wave's stores.
-        constexpr bool LATE = XI >= 2 && (E2_WINO_VARIANT & 1);
+        constexpr bool LATE = false;      // (mid-stage parking of the upper waves: measured neutral, profiles/r02_wino_timing.txt)
         if constexpr (X3) {
             // one iteration per LDS stage (16 channels): the stage's weights (2 positions x TN column tiles x 3 planes) were
             // issued a stage ago; since then: the patch prefetch of the stage after (SC * RAW_IT loads) and the next weights
@@ -573,29 +557,21 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             // matrix pipe, phase serialisation inside a SIMD, weight / patch latency, instruction fetch.
             auto stage_body = [&](auto CUR_, int st) __attribute__((always_inline)) {
                 constexpr int CUR = decltype(CUR_)::value;
-                E2T(const unsigned long long t_a = E2T_NOW();)
                 load_b3(st + 1, bw[CUR ^ 1]);
                 wait_vmcnt<6 * TN + SC * RAW_IT>();
                 claim3(bw[CUR]);
                 __builtin_amdgcn_sched_barrier(0);
-                E2T(const unsigned long long t_b = E2T_NOW(); tsum[0] += t_b - t_a;)
                 {
                     bf16x8 A[MT][6];
                     x3_prep(smem + CUR * STAGE_BYTES, A);
                     // (timing build only: fragments complete before the first MFMA issues, so that the two segments separate)
-                    E2T(_Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) _Pragma("unroll") for (int f_ = 0; f_ < 6; ++f_) asm volatile("" : "+v"(A[m_][f_]));
-                        __builtin_amdgcn_sched_barrier(0); const unsigned long long t_c = E2T_NOW(); tsum[1] += t_c - t_b;)
                     x3_mma(A, bw[CUR]);
-                    E2T(__builtin_amdgcn_sched_barrier(0); tsum[2] += E2T_NOW() - t_c;)
                 }
-                E2T(const unsigned long long t_d = E2T_NOW();)
                 // the registers hold stage st + 1: park it in the other buffer (its readers passed the previous barrier)
                 store_raw(CUR ^ 1);
 #pragma unroll
                 for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
-                E2T(__builtin_amdgcn_sched_barrier(0); const unsigned long long t_e = E2T_NOW(); tsum[3] += t_e - t_d;)
                 __syncthreads();
-                E2T(tsum[4] += E2T_NOW() - t_e;)
             };
             for (int st = 0; st < nstages; st += 2) {
                 stage_body(IC<0>{}, st);
@@ -655,12 +631,10 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             __syncthreads();
             return;
         }
-        if (E2_WINO_VARIANT & 2) __builtin_amdgcn_s_setprio(XI >= 2 ? 1 : 2);      // static priority by SIMD partner
         for (int st = 0; st < nstages; ++st) {
             const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
             for (int q = 0; q < SC; ++q) {
-                E2T(const unsigned long long t_a = E2T_NOW();)
                 load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);            // next chunk's weights land during this chunk
                 // loads issued after this chunk's weights: the next chunk's (2 TN) and, across a stage boundary, the
                 // patch prefetch (SC * RAW_IT)
@@ -668,9 +642,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
                 if ((q == 0) != LATE) claim_b(IC<2 * TN + SC * RAW_IT>{}, bq[q & 1]);
                 else claim_b(IC<2 * TN>{}, bq[q & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                E2T(const unsigned long long t_b = E2T_NOW(); tsum[0] += t_b - t_a;)
                 const unsigned char* raw = stage + q * CHUNK_BYTES;
-                if (E2_WINO_VARIANT & 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const unsigned char* rm = raw + m * (8 * PLANE_ROW * 16);
@@ -691,20 +663,14 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
                             acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q & 1][1][n][k], acc[1][m][n], 0, 0, 0);
                         }
                 }
-                E2T(__builtin_amdgcn_sched_barrier(0); tsum[1] += E2T_NOW() - t_b;)
                 if ((q == 0 && LATE) || (q == SC - 1 && !LATE)) {
                     // the registers hold stage st+1: park it in the other buffer (its readers passed the previous barrier)
-                    E2T(const unsigned long long t_c = E2T_NOW();)
                     store_raw((st & 1) ^ 1);
-                    E2T(__builtin_amdgcn_sched_barrier(0); const unsigned long long t_d = E2T_NOW(); tsum[2] += t_d - t_c;)
 #pragma unroll
                     for (int q2 = 0; q2 < SC; ++q2) load_raw(rraw[q2]);
-                    E2T(__builtin_amdgcn_sched_barrier(0); tsum[3] += E2T_NOW() - t_d;)
                 }
             }
-            E2T(const unsigned long long t_e = E2T_NOW();)
             __syncthreads();
-            E2T(tsum[4] += E2T_NOW() - t_e;)
         }
     };
     switch (wave) {          // wave-uniform
@@ -717,11 +683,30 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
         case 6: k_loop(IC<3>{}, IC<0>{}); break;
         default: k_loop(IC<3>{}, IC<1>{}); break;
     }
+    // The weight loads the last trip issued for the stage PAST the end (out of range: zeros) are still in flight.  For hipcc the
+    // destination of an asm load is written when the statement ends, so without a later use it may hand those registers to the
+    // epilogue's address arithmetic and schedule that above any wait: the late zeros then land on top of the addresses whenever
+    // memory is slow (what conv_wino_x3w_kernel did beside a second stream).  Wait, then name the registers --
+    // they stay allocated until the data has landed; build.verify_exit_reuse() re-derives it from the disassembly.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (X3) {
+#pragma unroll
+        for (int b_ = 0; b_ < ((X3 && DMA) ? 3 : 2); ++b_)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int n = 0; n < (X3 ? TN : 1); ++n)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) E2_CLAIM_AFTER_LOOP(bw[b_][a][n][pl]);
+    } else {
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) E2_CLAIM_AFTER_LOOP(bq[b_][a][n]);
+    }
 
-#ifdef E2_WINO_TIMING
-    const unsigned long long t_k1 = E2T_NOW();
-    const unsigned long long t_start = t_k0;
-#endif
     // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
     float* E = reinterpret_cast<float*>(smem);
     const int HW = p.H * p.W;
@@ -798,15 +783,6 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             }
         }
     }
-#ifdef E2_WINO_TIMING
-    if (blockIdx.x < 64 && blockIdx.y == 0 && lane == 0) {
-        unsigned long long* o = e2_wino_dbg + (blockIdx.x * 8 + wave) * 8;
-        for (int k = 0; k < 5; ++k) o[k] = tsum[k];
-        o[5] = t_k1 - t_start;                     // the whole K loop
-        o[6] = E2T_NOW() - t_k1;                   // the epilogue
-        o[7] = (unsigned long long)nstages;
-    }
-#endif
 }
 
 #if E2_WINO_X3
@@ -869,11 +845,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
     unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
     unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
     int cur_cpg = p.cpg[0];
+    int raw_left = p.nchunks;       // chunks of the walk still inside the layer: past the end the prefetch fetches out of range
     f32x4 rraw[SC][RAW_IT];
     auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
         const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(cur_src, cur_bytes);
         const unsigned chan = cur_chan + (unsigned)c0 * 4u + raw_kq16;
-        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;
+        const bool cvalid = raw_left-- > 0 && c0 + (int)(raw_kq16 >> 2) < cur_cpg;
 #pragma unroll
         for (int it = 0; it < RAW_IT; ++it) {
             unsigned off = (cvalid && raw_off[it] != OOB) ? raw_off[it] * cur_ld4 + chan : OOB;
@@ -1016,7 +993,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
         case 2: k_loop(IC<2>{}); break;
         default: k_loop(IC<3>{}); break;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the weights of the stage past the end
+    // the weights of the stage past the end are still in flight: wait, then name their registers so that they stay allocated until
+    // the data has landed (see conv_wino_kernel)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) E2_CLAIM_AFTER_LOOP(bw[b_][a][n][pl]);
 
     // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
     float* E = reinterpret_cast<float*>(smem);
@@ -1152,7 +1139,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
-    E2T(const unsigned long long t_entry = E2T_NOW();)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y;
@@ -1187,21 +1173,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
     const unsigned smem_lds = (unsigned)(unsigned long long)(wino_lds_void*)smem;
     // The source walk of the pieces (chunks are fetched strictly in order: 0, 1, 2, ...): the parameters of the source being
     // walked live in scalar registers and are re-read from the kernel arguments only when the walk crosses into the next source
-    // (past the last chunk it wraps to the first source: those stages' weights are out of range = zeros).
+    // (past the last chunk the pieces fetch out of range, and so do those stages' weights: zeros).
     int w_s = 0, w_c0 = 0;
     const float* w_src = p.src[0];
     unsigned w_bytes = p.src_bytes[0], w_ld4 = (unsigned)p.ld[0] * 4u, w_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
     int w_cpg = p.cpg[0];
+    int w_left = p.nchunks;         // chunks of the walk still inside the layer: the pieces of the two stages past the end fetch out of range
     // the pieces of wave WV of the NEXT chunk of the walk -> LDS chunk area lds_chunk; exactly NPW vector-memory instructions
     auto dma_chunk = [&](auto W_, auto NPW_, unsigned lds_chunk) __attribute__((always_inline)) {
         constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
         const i32x4 rs = rsrc_words(w_src, w_bytes);
         const unsigned chan = w_chan + (unsigned)w_c0 * 4u;
         const bool half = w_c0 + 4 >= w_cpg;         // a source may end in the middle of a chunk: its kq = 1 units are zeros
+        const bool live = w_left-- > 0;              // past the end: zeros without a memory access (before: the first source re-read)
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
             const unsigned pix = dma_pix[j] & 0x3FFFFFFFu, kq = (dma_pix[j] >> 30) & 1u;
-            unsigned off = ((int)dma_pix[j] >= 0 && !(half && kq)) ? pix * w_ld4 + chan + kq * 16u : OOB;
+            unsigned off = (live && (int)dma_pix[j] >= 0 && !(half && kq)) ? pix * w_ld4 + chan + kq * 16u : OOB;
             asm volatile("" : "+v"(off));
             dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
         }
@@ -1253,7 +1241,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
 
     const int nstages = (p.nchunks + SC - 1) / SC;
-    E2T(unsigned long long t_loop0 = 0, t_loop1 = 0;)
 
     auto k_loop = [&](auto XI_, auto PB_) __attribute__((always_inline)) {
         constexpr int XI = decltype(XI_)::value;
@@ -1372,43 +1359,32 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
         // (Measured and dropped, profiles/r04_x3w_variants.txt: the phases of waves 4-7 shifted by one against their SIMD partners,
         //  s_setprio 3 around the MFMA blocks, both: all within +-3 %.)
         constexpr bool SKEW = false;
-        E2T(unsigned long long tsum[6]; for (int k_ = 0; k_ < 6; ++k_) tsum[k_] = 0; const unsigned long long t_k0 = E2T_NOW(); t_loop0 = t_k0;)
         int slot = 0;
         auto first_half = [&](bf16x8 (&A1)[6]) __attribute__((always_inline)) {
             const unsigned char* rm = smem + slot * STAGE_BYTES + a_lane;
             const unsigned ahead = smem_lds + (unsigned)((slot == 0 ? 2 : slot - 1) * STAGE_BYTES);
-            E2T(const unsigned long long t_a = E2T_NOW();)
             {
                 bf16x8 A[6];
                 prep(rm, A);
                 __builtin_amdgcn_sched_barrier(0);
-                E2T(const unsigned long long t_b = E2T_NOW(); tsum[0] += t_b - t_a;)
                 mma(IC<0>{}, IC<0>{}, A);
-                E2T(__builtin_amdgcn_sched_barrier(0); tsum[1] += E2T_NOW() - t_b;)
             }
             __builtin_amdgcn_sched_barrier(0);
-            E2T(const unsigned long long t_c = E2T_NOW();)
             prep(rm + 8 * PLANE_ROW * 16, A1);
             __builtin_amdgcn_sched_barrier(0);
-            E2T(const unsigned long long t_d = E2T_NOW(); tsum[2] += t_d - t_c;)
             // this wave's pieces of stage st + 2: in front of the plane loads, so that the next stage's first plane wait also
             // retires them (loads return in order); the barrier at the end of the next stage publishes them
 #pragma unroll
             for (int q = 0; q < SC; ++q) dma_chunk(IC<WV>{}, IC<NPW>{}, ahead + (unsigned)(q * CHUNK_BYTES));
             __builtin_amdgcn_sched_barrier(0);
-            E2T(tsum[3] += E2T_NOW() - t_d;)
         };
         auto second_half = [&](const bf16x8 (&A1)[6]) __attribute__((always_inline)) {
-            E2T(const unsigned long long t_e = E2T_NOW();)
             mma(IC<1>{}, IC<1>{}, A1);
             u_lane += u_step;
             slot = slot == 2 ? 0 : slot + 1;
-            E2T(__builtin_amdgcn_sched_barrier(0); tsum[4] += E2T_NOW() - t_e;)
         };
         auto stage_barrier = [&]() __attribute__((always_inline)) {
-            E2T(const unsigned long long t_f = E2T_NOW();)
             __syncthreads();
-            E2T(tsum[5] += E2T_NOW() - t_f;)
         };
         if constexpr (SKEW) {
             bf16x8 A1[6];
@@ -1429,15 +1405,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 stage_barrier();
             }
         }
-#ifdef E2_WINO_TIMING
-        if (blockIdx.x < 64 && blockIdx.y == 0 && lane == 0) {
-            unsigned long long* o = e2_wino_dbg + (blockIdx.x * 8 + wave) * 8;
-            for (int k = 0; k < 6; ++k) o[k] = tsum[k];
-            o[6] = E2T_NOW() - t_k0;                   // the whole K loop
-            o[7] = (unsigned long long)nstages;
-        }
-        t_loop1 = E2T_NOW();
-#endif
     };
     switch (wave) {          // wave-uniform
         case 0: k_loop(IC<0>{}, IC<0>{}); break;
@@ -1461,7 +1428,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
 #pragma unroll
         for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(bw[a][n][pl]));
+            for (int pl = 0; pl < 3; ++pl) E2_CLAIM_AFTER_LOOP(bw[a][n][pl]);
     __syncthreads();
 
     // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
@@ -1537,13 +1504,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             }
         }
     }
-#ifdef E2_WINO_TIMING
-    if (blockIdx.x < 64 && blockIdx.y == 0 && lane == 0) {
-        unsigned long long* o2 = e2_wino_dbg2 + (blockIdx.x * 8 + wave) * 4;
-        const unsigned long long t_end = E2T_NOW();
-        o2[0] = t_loop0 - t_entry; o2[1] = t_loop1 - t_loop0; o2[2] = t_end - t_loop1; o2[3] = t_end - t_entry;
-    }
-#endif
 }
 #endif
 
@@ -1846,11 +1806,3 @@ extern "C" int e2fgvi_conv3x3_winograd_x3(const e2fgvi_conv_desc* d, void* strea
 extern "C" int e2fgvi_conv3x3_winograd(const e2fgvi_conv_desc* d, void* stream) { return wino_run(d, stream, false); }
 #endif
 
-#ifdef E2_WINO_TIMING
-extern "C" int e2fgvi_wino_timing_read2(unsigned long long* host_dst, int32_t n) {
-    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(e2_wino_dbg2), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
-}
-extern "C" int e2fgvi_wino_timing_read(unsigned long long* host_dst, int32_t n) {
-    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(e2_wino_dbg), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
-}
-#endif

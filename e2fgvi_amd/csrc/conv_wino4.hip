@@ -32,6 +32,11 @@
 #include "common.h"
 #include <utility>
 
+// register claims behind the K loop (conv_wino.hip)
+#ifndef E2_CLAIM_AFTER_LOOP
+#define E2_CLAIM_AFTER_LOOP(r) asm volatile("" : "+v"(r))
+#endif
+
 namespace {
 
 struct W4Params {
@@ -209,11 +214,13 @@ __global__ __launch_bounds__(128 * (FY + 2), (FY == 4 ? 3 : 2)) void conv_wino4_
     unsigned cur_ld4 = (unsigned)p.ld[0] * 4u;
     unsigned cur_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
     int cur_cpg = p.cpg[0];
+    int raw_left = p.nchunks;       // chunks of the walk still inside the layer
     f32x4 rraw[SC][RAW_IT];
     auto load_raw = [&](f32x4 (&q)[RAW_IT]) {
         const __amdgpu_buffer_rsrc_t arsrc = w4_rsrc(cur_src, cur_bytes);
         const unsigned chan = cur_chan + (unsigned)c0 * 4u + raw_kq16;
-        const bool cvalid = c0 + (int)(raw_kq16 >> 2) < cur_cpg;
+        // chunks past the end (the prefetch runs a stage ahead of the K loop) fetch out of range: zeros, no memory access
+        const bool cvalid = raw_left-- > 0 && c0 + (int)(raw_kq16 >> 2) < cur_cpg;
 #pragma unroll
         for (int it = 0; it < RAW_IT; ++it) {
             // a select, never control flow: exactly ONE load per item on every path (the explicit vmcnt counts rely on it)
@@ -449,6 +456,16 @@ __global__ __launch_bounds__(128 * (FY + 2), (FY == 4 ? 3 : 2)) void conv_wino4_
             }
             break;
     }
+    // The weight loads issued for the chunk PAST the end (out of range: zeros) are still in flight, and for hipcc an asm load's
+    // destination is written when the statement ends: wait, then name the registers, so that nothing of the epilogue is allocated
+    // on top of them before the data has landed (conv_wino.hip; checked by build.verify_exit_reuse()).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) E2_CLAIM_AFTER_LOOP(bq[b_][a][n]);
 
     // ---- epilogue: 16 tiles at a time: the positions meet in LDS, inverse transform, bias, residual, activation, store
     float* E = reinterpret_cast<float*>(smem);

@@ -250,16 +250,6 @@ class Engine(BF16Path):
             for blk in self.blocks:
                 for k in ("qkv", "proj", "fc1", "fc2"):
                     blk[k].try_x3 = True
-        # layers that run with nothing beside them on the chip (behind the join of the two streams, one launch at a time): the ones
-        # this round's kernel table lets take the wide-tile split-operand Winograd kernel (ops.PackedConv.alone).  The gate dates
-        # from before that kernel's fault beside a second stream was found and fixed and goes with the next re-timing
-        # of the table; the join sits in front of encoder.layers.10 (encode())
-        if not self.bf16:
-            for layer in list(self.dec[:3]) + list(self.enc[5:]):
-                layer.alone = True
-            for off, _dcn, bb in self.prop.values():
-                for layer in list(off) + list(bb):      # (at one clip only conv_offset.6 is wide enough for the kernel to win)
-                    layer.alone = True
         # SPyNet runs on a side stream next to the encoder, in both precision modes.  Round 1 found the side stream's
         # kernels corrupted beside bf16 MFMA tiles; round 2 traced it to packed-fp32 VALU instructions consuming freshly
         # loaded registers (tools/probe/overlap_probe.hip, DESIGN.md "Stream overlap"): every kernel that can run on the
@@ -364,7 +354,7 @@ class Engine(BF16Path):
     # ------------------------------------------------------------------ encoder
     def encode(self, frames, join=None):
         """join: called in front of encoder.layers.10 (the fork's other branch, SPyNet, has ended by then on every benchmark
-        shape -- profiles/r04_timeline.txt -- so the wait is free and layers 10..16 run alone on the chip: PackedConv.alone)"""
+        shape -- profiles/r04_timeline.txt -- so the wait is free and the widest layers, 10..16, have the chip to themselves)"""
         b, t, c, H, W = frames.shape
         x = ops.nchw_to_nhwc(frames.reshape(b * t, c, H, W).contiguous(), ld=4)
         e = self.enc

@@ -203,6 +203,17 @@ class HipError(RuntimeError):
     pass
 
 
+def library_key():
+    """sha256[:16] of the shared library that is (or would be) loaded: PMC / rocprof summaries under profiles/ carry the key of the
+    library they measured, and bench.py quotes a traffic figure only when it belongs to the library it has just timed"""
+    import hashlib
+    try:
+        with open(LIB_PATH, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().e2fgvi_last_error()

@@ -68,12 +68,12 @@ W3_BASE = 40000
 #  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
 #  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
 W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.environ.get("E2FGVI_W3_SKIP", "").split(","))     # E2FGVI_W3_SKIP=6064: A/B runs
-# The wide-tile split-operand Winograd kernel (6064) is, in this round's table, taken only by layers flagged PackedConv.alone (the
-# engine sets it on the layers behind the join of its two streams): beside the SPyNet stream it returned wrong 16x16-pixel blocks.
-# Root cause (found at the end of round 4): the weight loads for the stage past the end were in flight while the
-# compiler had reused their registers for the epilogue's addresses; fixed in conv_wino.hip (72 of 72 launches wrong beside device
-# copies before, 0 of 48 after: tools/c4_repro.py) and guarded by build.verify_exit_reuse().  The `alone` gate stays until the
-# table is re-timed on a GPU with the kernel allowed everywhere (tools/make_tile_table.py); E2FGVI_W3_WIDE=0 switches the kernel off.
+# The wide-tile split-operand Winograd kernel (6064) is a candidate of every 3x3 layer, whatever runs beside it (round 5).  Round 4
+# restricted it to layers with the chip to themselves (a per-layer flag): beside the SPyNet stream it returned wrong 16x16-pixel
+# blocks.  Root cause: the weight loads for the stage past the end were in flight while the compiler had reused their
+# registers for the epilogue's addresses; fixed in conv_wino.hip for every Winograd kernel, guarded by build.verify_exit_reuse() and
+# by tests/test_gpu_hazards.py (every selectable kernel beside device copies, bit-equal to the unaccompanied launch).
+# E2FGVI_W3_WIDE=0 switches the kernel off (A/B runs).
 WIDE_X3_OK = os.environ.get("E2FGVI_W3_WIDE", "1") != "0"
 W3_WIDE = 6064
 W3_WIDE_FALLBACK = 164
@@ -175,6 +175,16 @@ def sync_tile_decisions(group=None, src=0):
     return True
 
 
+def _no_capture(what):
+    """Weight packings are built lazily, on the first call that runs their kernel.  That first call must be an eager one: under
+    HIP-graph capture the allocation would come from the graph's private pool and the pack kernel would be captured -- re-packed on
+    every replay, dangling for eager calls once the graph is freed (advisor finding of round 4).  runner.ShardedStep runs an eager
+    forward before it captures; a caller that captures without one is told so here instead of getting a stale pointer later."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("%s: first use of this kernel's weight packing under HIP-graph capture -- run one eager forward of the "
+                           "same shapes before capturing (runner.ShardedStep does)" % what)
+
+
 class PackedConv:
     """A conv / linear layer with weights re-laid-out once for the MFMA kernel.
 
@@ -205,7 +215,6 @@ class PackedConv:
         self.name = "conv"         # layer name for launch traces (the engine sets the checkpoint key)
         self.nopk = False          # True: the build without packed-fp32 VALU (side-stream launches beside bf16 MFMA tiles)
         self.try_x3 = False        # True: time the split-bf16 kernel (PackedConvX x3) against this layer's fp32 kernel, keep the faster
-        self.alone = False         # True: nothing else runs on the chip beside this layer's launches (see WIDE_X3_OK)
         self.alt = self.alt3 = None
         self._w_raw = w            # for the alternative LDS-DMA kernels (built on the first tuned call)
         if algo not in ("igemm", "winograd", "auto"):
@@ -243,6 +252,7 @@ class PackedConv:
         """packed weights of the fp32 F(2x2,3x3) kernel (conv_wino.hip), built on first use"""
         t = self._own.get("wino")
         if t is None and self.algo in ("winograd", "auto"):
+            _no_capture(self.name + " (Winograd F(2x2,3x3) weights)")
             lib = _L.load()
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
             n = lib.e2fgvi_packed_winograd_weight_size(self.Cout, self.groups, len(self.cpg), arr)
@@ -259,6 +269,7 @@ class PackedConv:
         """packed weights of the register-staged implicit GEMM (conv.hip), built on first use"""
         t = self._own.get("igemm")
         if t is None and self.algo != "winograd":
+            _no_capture(self.name + " (implicit-GEMM weights)")
             lib = _L.load()
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
             n = lib.e2fgvi_packed_conv_weight_size(self.Cout, self.groups, self.KH, self.KW, len(self.cpg), arr, self.bk)
@@ -279,6 +290,7 @@ class PackedConv:
         """packed weights of the wide-tile Winograd kernel (conv_wino4.hip), built on first use"""
         t = self._w4.get(fy)
         if t is None:
+            _no_capture(self.name + " (Winograd F(%dx4,3x3) weights)" % fy)
             lib = _L.load()
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
             n = lib.e2fgvi_packed_winograd4_weight_size(self.Cout, self.groups, len(self.cpg), arr, fy)
@@ -309,6 +321,7 @@ class PackedConv:
     def _alt(self):
         """the LDS-DMA fp32 kernel (conv_bf16x.hip, F32 variant) as a tuning alternative of the implicit GEMM"""
         if self.alt is None and getattr(self, "_w_raw", None) is not None:
+            _no_capture(self.name + " (LDS-DMA fp32 alternative)")
             self.alt = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
                                    dtype=torch.float32)
             self.alt.name = self.name
@@ -317,6 +330,7 @@ class PackedConv:
     def _wino_x3(self):
         """packed weights of the split-bf16 Winograd kernel (three bf16 planes of the transformed weights), built on first use"""
         if getattr(self, "_w3", None) is None and self._w_oihw is not None:
+            _no_capture(self.name + " (split-operand Winograd weights)")
             lib = _L.load()
             arr = (C.c_int32 * len(self.cpg))(*self.cpg)
             n = lib.e2fgvi_packed_winograd_weight_x3_size(self.Cout, self.groups, len(self.cpg), arr)
@@ -330,6 +344,7 @@ class PackedConv:
     def _alt3(self):
         """the same layer on the bf16 matrix pipe (three-way split operands, six exact bf16 MFMA terms per product)"""
         if self.alt3 is None and getattr(self, "_w_raw", None) is not None and not any(c % 4 for c in self.cpg):
+            _no_capture(self.name + " (split-operand GEMM alternative)")
             self.alt3 = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
                                     dtype=torch.float32, x3=True)
             self.alt3.name = self.name
@@ -509,7 +524,7 @@ class PackedConv:
             # (the fp32 baseline the alternatives are measured against is part of the key: a tuned layer and an untuned one of the
             #  same geometry, or the F(2x4) / F(2x2) Winograd baselines, do not share a verdict)
             key = (self.Cout, tuple(self.cpg), self.KH, self.KW, self.stride, self.pad, self.groups, self.bk,
-                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino, bool(self.tune), int(tile)) + (("x3",) if x3 else ()) + (("alone",) if self.alone else ())
+                   int(4.0 * math.log2(N * Ho * Wo)), residual is not None, act, use_wino, bool(self.tune), int(tile)) + (("x3",) if x3 else ())
             best = _decision(key)
             from_table = best is not None
             if best is None and AUTOTUNE and not torch.cuda.is_current_stream_capturing() and (
@@ -548,7 +563,7 @@ class PackedConv:
                     # ... and the Winograd kernel with split operands: codes W3_BASE + its block shape
                     w3 = {}
                     for shape in W3_CANDIDATES:
-                        if shape == W3_WIDE and not (self.alone and WIDE_X3_OK):
+                        if shape == W3_WIDE and not WIDE_X3_OK:
                             continue
                         if launch_w3(shape)[0] != 0:
                             continue
@@ -568,7 +583,7 @@ class PackedConv:
             try:
                 if best and best >= W3_BASE and self._wino_x3() is not None:
                     w3_tile = best - W3_BASE
-                    if w3_tile == W3_WIDE and not (self.alone and WIDE_X3_OK):
+                    if w3_tile == W3_WIDE and not WIDE_X3_OK:
                         w3_tile = W3_WIDE_FALLBACK
                 elif best and X3_BASE <= best < W3_BASE and self._alt3() is not None:
                     return self.alt3(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
@@ -665,6 +680,7 @@ class PackedConvX:
     def wpacked(self):
         """packed weights; an fp32 layer (whose split-operand alternative alt3 may be what runs) packs its own on first use"""
         if self._wp is None:
+            _no_capture(self.name + " (LDS-DMA GEMM weights)")
             self._wp = self._pack(self._w_raw)
         return self._wp
 
@@ -709,6 +725,7 @@ class PackedConvX:
     def _alt3(self):
         """this fp32 layer on the bf16 matrix pipe (x3=True), built on first use"""
         if self.alt3 is None and self._w_raw is not None:
+            _no_capture(self.name + " (split-operand GEMM alternative)")
             self.alt3 = PackedConvX(self._w_raw, self.bias, self.cpg, groups=self.groups, stride=self.stride, pad=self.pad,
                                     dtype=torch.float32, taps=self._taps_arg, x3=True)
             self.alt3.name = self.name

@@ -20,7 +20,7 @@ def pytest_configure(config):
 # real-reference fixtures at the BASELINE sizes, then the stages, then the fp32 kernels those are made of), the section-8(f)
 # rows after them, the bf16 data path and the tuning alternatives last -- so that `pytest -x` can never again stop in an
 # auxiliary kernel test before the fp32 1e-3 checks have run (round 2's driver record).
-_FILE_ORDER = ["test_gpu_model.py", "test_gpu_ops.py", "test_gpu_tail.py", "test_gpu_wino4.py", "test_gpu_fused.py", "test_gpu_x3.py",
+_FILE_ORDER = ["test_gpu_model.py", "test_gpu_hazards.py", "test_gpu_ops.py", "test_gpu_tail.py", "test_gpu_wino4.py", "test_gpu_fused.py", "test_gpu_x3.py",
                "test_video_driver.py", "test_tennis.py", "test_gpu_bench_lines.py", "test_gpu_bf16x.py"]
 _FIRST = ["test_full_size_against_oracle", "test_hip_matches_reference_golden", "test_end_to_end", "test_stage_"]
 

@@ -67,6 +67,12 @@ def test_bench_line_carries_its_own_parity(dev):
     j = _bench("--steps", "3", "--warmup", "1", "--no-secondary")
     p = j["parity"]
     assert p["bound_max_abs"] == 1e-3 and 0 <= p["max_abs"] <= 1e-3 and p["max_abs_over_rms"] <= 2e-4, p
+    # round 5: the default-init weights (conv_offset[-1] == 0: offsets = flow, mask = 0.5) AND the stress weights
+    for k in ("default", "stress"):
+        assert 0 <= p[k]["max_abs"] <= 1e-3 and p[k]["max_abs_over_rms"] <= 2e-4, (k, p[k])
+    assert p["stress"]["rms_of_reference"] > 10 * p["default"]["rms_of_reference"]
+    # the traffic figure is this library's or absent (never another build's)
+    assert j["library_sha16"] and (j["roofline"]["traffic"] is None or j["library_sha16"] in j["roofline"]["traffic_note"])
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
 
 

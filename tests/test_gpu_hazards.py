@@ -1,0 +1,101 @@
+"""Second-stream aggressor tests: every Winograd kernel the decision table can select runs
+on one stream while plain device copies of 256 MB run on another -- the condition under which round 4's wide-tile kernel returned
+wrong 16x16-pixel blocks in 72 of 72 launches (profiles/r04_c4_repro.txt: a memory system slow enough for the weight loads issued
+past the end of the K loop to land AFTER the compiler had reused their registers) -- and every launch must return the bits of the
+unaccompanied launch.  The static side of the same guarantee is build.verify_exit_reuse() (tests/test_host_logic.py)."""
+import pytest
+import torch
+
+from tests.util import gen
+
+pytestmark = pytest.mark.gpu
+
+LAUNCHES = 200          # per (kernel, shape): a 3 % per-launch event is missed with p < 1 %
+PER_ROUND = 8
+
+
+def _codes():
+    from e2fgvi_amd import ops
+    w3 = [ops.W3_BASE + c for c in (6064, 5132, 164, 132, 32)]         # split-operand: wide tile, four positions per wave, 8-wave shapes
+    return w3 + [2464, 2432, 4432] + [64, 32, 164, 132]               # fp32 F(2x4) / F(4x4) and the fp32 F(2x2) block shapes
+
+
+# (name, Cout, cpg, groups, N): the two encoder shapes the fault was found on (one source; two sources in two groups) and the
+# one-frame propagation shape (the launches that run under the previous step's all-gather in a sharded job)
+SHAPES = [("encoder.layers.8", 384, [256], 1, 10), ("encoder.layers.10", 512, [128, 192], 2, 10), ("conv_offset.2", 128, [128], 1, 1)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_winograd_kernels_beside_device_copies_return_the_bits_of_the_launch_alone(dev, shape):
+    from e2fgvi_amd import lib as L, ops
+    name, cout, cpg, groups, n = shape
+    g = gen(1100 + len(name))
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    layer = ops.PackedConv(rnd(cout, sum(cpg), 3, 3) * 0.05, rnd(cout), cpg, groups=groups, pad=1, algo="winograd")
+    srcs = [rnd(n, 60, 108, c * groups) for c in cpg]
+    big_a, big_b = torch.empty(64 << 20, device=dev), torch.empty(64 << 20, device=dev)
+    big_a.normal_()
+    side, main = torch.cuda.Stream(device=dev), torch.cuda.current_stream()
+    ran = []
+    for code in _codes():
+        ref = torch.empty(n, 60, 108, cout, device=dev)
+        try:
+            layer(srcs, out=ref, act=ops.ACT_LRELU, slope=0.2, tile=code)
+        except L.HipError:
+            continue                                    # a block shape this geometry rejects (e.g. F(4x4) needs H % 4 == 0)
+        torch.cuda.synchronize()
+        outs = [torch.empty_like(ref) for _ in range(PER_ROUND)]
+        bad = 0
+        for _ in range(LAUNCHES // PER_ROUND):
+            for o in outs:
+                o.fill_(float("nan"))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(3 * PER_ROUND if n > 1 else PER_ROUND):
+                    big_b.copy_(big_a, non_blocking=True)
+            for o in outs:
+                layer(srcs, out=o, act=ops.ACT_LRELU, slope=0.2, tile=code)
+            main.wait_stream(side)
+            torch.cuda.synchronize()
+            bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+        assert bad == 0, "%s, tile code %d: %d of %d launches beside device copies differ from the launch alone" % (name, code, bad, LAUNCHES)
+        ran.append(code)
+    assert len(ran) >= 8 and ops.W3_BASE + ops.W3_WIDE in ran, ran          # the kernels were really exercised, not skipped
+
+
+def test_wide_kernel_runs_beside_spynet_in_the_headline_forward(dev):
+    """With round 4's per-layer gate gone the table may hand encoder.layers.2 / 6 / 8 -- which overlap the SPyNet stream in every
+    forward -- to the wide-tile kernel.  Whatever the table says today, this test FORCES the kernel onto those three layers (so
+    that it really runs beside the second stream at T = 10; `test_stream_overlap_is_bit_identical_to_serial` only sees the table's
+    choice) and compares 60 overlapped forwards with the serial one, bit for bit."""
+    from e2fgvi_amd import lib as L, ops
+    from e2fgvi_amd.engine import Engine
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    if not ops.X3_ENABLED:
+        pytest.skip("split-operand kernels switched off")
+    sd = synth_state_dict("e2fgvi", "stress", 0)
+    x = synth_clip(1, 10, 240, 432, seed=5, moving=True)[0].to(dev)
+    eng = Engine(sd, "e2fgvi", dev, precision="fp32")
+    wide = ops.W3_BASE + ops.W3_WIDE
+
+    def forced(layer):
+        def call(sources, **kw):
+            return layer(sources, tile=wide, **kw)
+        call.name = layer.name
+        return call
+    for k in (1, 3, 4):                                  # encoder.layers.2 / .6 / .8
+        eng.enc[k] = forced(eng.enc[k])
+    eng.overlap_flows = False
+    L.TRACE = []
+    try:
+        base, (bf, bb) = eng.forward(x, 10)
+        torch.cuda.synchronize()
+        kern = {r["meta"]["layer"]: r["meta"]["kernel"] for r in L.TRACE if r.get("meta") and "kernel" in r["meta"]}
+    finally:
+        L.TRACE = None
+    assert all(kern.get("encoder.layers.%d" % i, "").startswith("conv_wino_x3w") for i in (2, 6, 8)), kern
+    eng.overlap_flows = True
+    for _ in range(60):
+        got, (ff, fb) = eng.forward(x, 10)
+        torch.cuda.synchronize()
+        assert torch.equal(ff, bf) and torch.equal(fb, bb) and torch.equal(got, base)

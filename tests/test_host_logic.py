@@ -254,17 +254,17 @@ def test_winograd_explicit_waits_are_checked_against_the_disassembly():
 
 
 def test_kernel_table_invariants_and_nearest_size_class_lookup(monkeypatch):
-    """deterministic kernel selection (ops._decision, e2fgvi_amd/tile_table.py): the table is in the format ops reads; the
-    wide-tile split-operand Winograd kernel is tabled only for layers that run alone on the chip; a size class the
-    table does not hold takes the decision of the nearest class of the same geometry, a geometry it does not hold at all none"""
+    """deterministic kernel selection (ops._decision, e2fgvi_amd/tile_table.py): the table is in the format ops reads; no key
+    carries round 4's `alone` suffix any more (the wide-tile kernel is a candidate everywhere since DESIGN.md C4 is closed); a size
+    class the table does not hold takes the decision of the nearest class of the same geometry, a geometry it does not hold at all
+    none"""
     from e2fgvi_amd import ops, tile_table
     assert tile_table.TABLE_FORMAT == ops.TABLE_FORMAT and len(tile_table.TILES) > 100
     wide = ops.W3_BASE + ops.W3_WIDE
     assert any(v == wide for v in tile_table.TILES.values())
     for k, v in tile_table.TILES.items():
         assert isinstance(k, tuple) and isinstance(k[ops._SIZE_FIELD], int) and isinstance(v, int)
-        if v == wide:
-            assert k[-1] == "alone", k
+        assert "alone" not in k, k
     if ops.AUTOTUNE:
         return
     monkeypatch.setattr(ops, "_TUNED", dict(tile_table.TILES))
@@ -280,36 +280,98 @@ def test_kernel_table_invariants_and_nearest_size_class_lookup(monkeypatch):
     assert ops._decision(unknown) is None
 
 
-def test_registers_of_loads_in_flight_behind_the_k_loop_are_not_reused():
-    """DESIGN.md C4 (round 4): for hipcc an inline-asm load's destination is written when the statement ends; the wide-tile kernel's
-    weight loads for the stage past the end were still in flight when the compiler reused their registers for the epilogue's
-    addresses.  build.check_exit_reuse re-derives from the disassembly that nothing touches such a register between a K-loop exit
-    and the first vmcnt(0): here on a synthetic kernel (clean / reused) and on the object of this build."""
-    from e2fgvi_amd import build
+def _synthetic_k_loop(reuse, where="fallthrough", wait=True):
+    """a toy kernel: K loop of 8 MFMAs that reloads its weight registers in place, then an epilogue.  reuse: the epilogue's
+    arithmetic takes one of those registers BEFORE the post-loop wait -- directly behind the loop, behind an unconditional branch,
+    or behind another wave role's exec-masked region (the layout hipcc gives `switch (wave)`)"""
+    a, out = [0], []
 
-    def isa(reuse):
-        a, out = [0], []
+    def emit(m, o=""):
+        out.append([a[0], m, o])
+        a[0] += 4
+        return len(out) - 1
 
-        def emit(m, o=""):
-            out.append((a[0], m, o))
-            a[0] += 4
-        emit("s_mov_b32", "s0, 4")
-        top = a[0]
+    def patch(i, target_index_addr):
+        out[i][2] = str(((target_index_addr - (out[i][0] + 4)) // 4) & 0xFFFF)
+    emit("s_mov_b32", "s0, 4")
+    top = a[0]
+    for _ in range(8):
+        emit("v_mfma_f32_32x32x16_bf16", "v[0:15], v[100:103], v[40:43], v[0:15]")
+    emit("buffer_load_dwordx4", "v[40:43], v200, s[8:11], s3 offen")
+    emit("s_cmp_lg_u32", "s0, 0")
+    patch(emit("s_cbranch_scc1"), top)
+    bad = ("v_add_u32_e32", "v41, s2, v7")              # the epilogue's arithmetic in a register the load still targets
+    if where == "fallthrough":
+        if reuse:
+            emit(*bad)
+    elif where == "branch":
+        br = emit("s_branch")
+        emit("v_add_u32_e32", "v41, s2, v7")            # dead code in address order: never on the path
+        emit("s_endpgm")
+        patch(br, a[0])
+        if reuse:
+            emit(*bad)
+    elif where == "role":
+        # this role's `then` arm ends: flip to the `else` arm (no lane of this wave is in it), whose body is the next role:
+        # its prologue loads the same registers and runs its own K loop.  The walk must pass over it and find the epilogue.
+        emit("s_andn2_saveexec_b64", "s[4:5], s[4:5]")
+        skip = emit("s_cbranch_execz")
+        emit("buffer_load_dwordx4", "v[40:43], v200, s[8:11], s3 offen")
+        emit("s_waitcnt", "vmcnt(0)")
+        top2 = a[0]
         for _ in range(8):
             emit("v_mfma_f32_32x32x16_bf16", "v[0:15], v[100:103], v[40:43], v[0:15]")
         emit("buffer_load_dwordx4", "v[40:43], v200, s[8:11], s3 offen")
-        emit("s_cmp_lg_u32", "s0, 0")
-        off = (top - (a[0] + 4)) // 4
-        emit("s_cbranch_scc1", str(off & 0xFFFF))
+        patch(emit("s_cbranch_scc1"), top2)
+        patch(skip, a[0])
+        emit("s_or_b64", "exec, exec, s[4:5]")
         if reuse:
-            emit("v_add_u32_e32", "v41, s2, v7")                 # the epilogue's arithmetic in a register the load still targets
+            emit(*bad)
+    if wait:
         emit("s_waitcnt", "vmcnt(0)")
-        emit("v_add_u32_e32", "v41, s2, v7")
-        emit("s_endpgm")
-        return out
-    assert build.check_exit_reuse("x.o", "k", isa(False)) == 1
-    with pytest.raises(RuntimeError):
-        build.check_exit_reuse("x.o", "k", isa(True))
-    import os
+    emit("v_add_u32_e32", "v41, s2, v7" if wait else "v9, s2, v7")
+    emit("s_endpgm")
+    return [tuple(x) for x in out]
+
+
+def test_registers_of_loads_in_flight_behind_the_k_loop_are_not_reused():
+    """for hipcc an inline-asm load's destination is written when the statement ends; the Winograd kernels' weight
+    loads for the stage past the end are still in flight when the K loop exits, and the compiler reused their registers for the
+    epilogue's addresses above the kernels' own wait.  build.check_exit_reuse walks the control flow from every K-loop exit to the
+    first vmcnt(0) (round 5: follows branches and carries the wave-uniform role regions, advisor finding of round 4): synthetic
+    kernels here, the objects of this build, and -- below -- a build of the real source without the register claims."""
+    from e2fgvi_amd import build
+    for where in ("fallthrough", "branch", "role"):
+        assert build.check_exit_reuse("x.o", "k", _synthetic_k_loop(False, where)) >= 1
+        with pytest.raises(RuntimeError, match="touches a register"):
+            build.check_exit_reuse("x.o", "k", _synthetic_k_loop(True, where))
+        with pytest.raises(RuntimeError, match="without an s_waitcnt vmcnt"):
+            build.check_exit_reuse("x.o", "k", _synthetic_k_loop(False, where, wait=False))
     if os.path.exists(build.OBJDUMP) and os.path.exists(os.path.join(build.CSRC, "build", "conv_wino_x3.o")):
-        assert build.verify_exit_reuse() >= 8                      # the eight wave roles of conv_wino_x3w_kernel
+        # every Winograd kernel of the three objects: 8 (or 4, or 12) wave roles each
+        assert build.verify_exit_reuse() >= 100
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_exit_reuse_check_rejects_the_real_kernels_built_without_their_register_claims(tmp_path):
+    """The regression fixture the advisor asked for: the split-operand Winograd unit compiled from the shipped source with the
+    post-loop register claims defined away (-D'E2_CLAIM_AFTER_LOOP(r)=') is the pre-fix kernel of round 4 -- the check must raise
+    on it (it does for all five register-staged kernels: hipcc hoists epilogue address arithmetic into the weight registers above
+    the wait), and must pass on the same source built as shipped (test above)."""
+    import subprocess
+    from e2fgvi_amd import build
+    obj = str(tmp_path / "conv_wino_x3_noclaim.o")
+    subprocess.check_call([build._hipcc()] + build.FLAGS + build.NOPK + ["-DE2_WINO_X3=1", "-DE2_CLAIM_AFTER_LOOP(r)=", "-c",
+                          os.path.join(build.CSRC, "conv_wino.hip"), "-o", obj], stderr=subprocess.DEVNULL)
+    raised = {}
+    for name, ins in build._kernels(build.device_isa(obj)).items():
+        if "conv_wino" in name and "pack_" not in name:
+            try:
+                build.check_exit_reuse("noclaim", name, ins)
+                raised[name] = False
+            except RuntimeError as e:
+                assert "touches a register of a weight load" in str(e)
+                raised[name] = True
+    wide = [n for n in raised if "conv_wino_x3w_kernel" in n]
+    assert wide and all(raised[n] for n in wide), raised          # the kernel that failed on the chip in round 4
+    assert sum(raised.values()) >= 3, raised

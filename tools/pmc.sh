@@ -8,16 +8,15 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the tile choices of the benchmark (written by a first un-profiled run), no tuning launches inside the counted forwards
-export E2FGVI_TUNE_FILE=$OUT/tune.txt
-rm -f $E2FGVI_TUNE_FILE
-python $REPO/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 2 "$@" > $OUT/tune_run.log 2>&1
+# kernel selection is the checked-in table (e2fgvi_amd/tile_table.py): the counted forwards run the benchmark's kernels, no tuning launches
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-secondary --no-graph --steps 2 --warmup 2 "$@" > $OUT/$C.log 2>&1 || true
 done
+cd $REPO
 python - "$OUT" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, sys, collections, os
 out = sys.argv[1]
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.getcwd())
 res = {}
 per_kernel = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -37,7 +36,7 @@ forwards = 6   # engine-building forward + FLOP-trace forward + 2 warm-ups + 2 t
 fetch_b = res["FETCH_SIZE"] * 1024 * 2 / forwards     # gfx950: x2 on the read side
 write_b = res["WRITE_SIZE"] * 1024 / forwards
 js = {"fetch_bytes_per_forward": fetch_b, "write_bytes_per_forward": write_b, "hbm_bytes_per_forward": fetch_b + write_b,
-      "raw_kib": res, "forwards": forwards,
+      "raw_kib": res, "forwards": forwards, "library_sha16": __import__("e2fgvi_amd.lib", fromlist=["x"]).library_key(),
       "note": "FETCH_SIZE/WRITE_SIZE (KiB) summed over all dispatches of bench.py --no-graph --steps 2 --warmup 2, / 6 forwards; "
               "read side doubled per the gfx950 calibration in MI355X_MICROARCH.md",
       "top_fetch_kernels_kib": per_kernel["FETCH_SIZE"], "top_write_kernels_kib": per_kernel["WRITE_SIZE"]}

@@ -10,8 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o pmc -- python $REPO/tools/wino_one.py 5 $TILE > $OUT/run_$c.log 2>&1 || tail -3 $OUT/run_$c.log
 done
+cd $REPO
 python - "$OUT" "$TILE" "$TAG" <<'PY' | tee $OUT/traffic.json
-import csv, glob, sys, json, collections
+import csv, glob, sys, json, collections, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.getcwd())
 out = sys.argv[1]
 acc = collections.defaultdict(collections.Counter); calls = collections.Counter()
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
@@ -29,6 +31,6 @@ alg = (10 * 60 * 108 * 640 + 10 * 60 * 108 * 512) * 4 + (512 * 320 * 16 * 6 if "
 print(json.dumps({"kernel": k[:120] + " on encoder.layers.10 (3x3 640->512 g2, 10x60x108), tools/wino_one.py 5 " + tile, "kernel_tag": tag, "launches": n,
                   "FETCH_SIZE_KiB_total": acc[k]["FETCH_SIZE"], "WRITE_SIZE_KiB_total": acc[k]["WRITE_SIZE"],
                   "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
-                  "algorithmic_bytes_per_launch": alg,
+                  "algorithmic_bytes_per_launch": alg, "library_sha16": __import__("e2fgvi_amd.lib", fromlist=["x"]).library_key(),
                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_dom.sh), KiB units, read side doubled per the gfx950 calibration of MI355X_MICROARCH.md; fabric-side (includes Infinity-Cache hits)"}, indent=1))
 PY

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_mfma_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export E2FGVI_AUTOTUNE=0     # no tuning launches inside the counted forwards
+# (kernel selection is the checked-in table: no tuning launches inside the counted forwards)
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 1 > $OUT/run.log 2>&1 || true
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -1,14 +1,12 @@
 #!/bin/bash
-# rocprofv3 kernel trace + stats of the benchmark forward, with the SAME tile choices the benchmark uses: a first,
-# un-profiled run writes the autotuner's decisions to a file, the profiled run reads them (no tuning launches inside).
+# rocprofv3 kernel trace + stats of the benchmark forward, with the tile choices the benchmark uses (the checked-in
+# table e2fgvi_amd/tile_table.py: no tuning launches inside).
 # Usage (on the GPU box, from the repo root):   bash tools/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 TAG=${1:-run}; shift || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export E2FGVI_TUNE_FILE=$OUT/tune.txt
-rm -f $E2FGVI_TUNE_FILE
 python $REPO/bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" > $OUT/bench_graph.log 2>&1
 tail -1 $OUT/bench_graph.log > $OUT/bench_line.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python $REPO/bench.py --no-cpu-baseline --no-graph --steps 5 --warmup 2 "$@" > $OUT/bench.log 2>&1 || true

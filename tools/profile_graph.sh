@@ -6,7 +6,6 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profg_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export E2FGVI_TUNE_FILE=$OUT/tune.txt
 python $REPO/bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 2 "$@" > $OUT/warm.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o prof -- python $REPO/bench.py --no-cpu-baseline --no-secondary --steps 4 --warmup 2 "$@" > $OUT/bench.log 2>&1 || true
 tail -1 $OUT/bench.log | cut -c1-200
