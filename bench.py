@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (self-test)")
+    ap.add_argument("--no-dominant-probe", action="store_true",
+                    help="skip the 21 extra launches of encoder.layers.10 behind the timed region (PMC passes count whole processes: "
+                         "tools/pmc.sh divides by the number of forwards)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the BASELINE configs[3] / [4] lines (e2fgvi_hq 720x1296 T=10 and 1080x1944 T=20, bf16) that the "
                          "default single-GPU invocation times after the headline and attaches as `secondary`")
@@ -413,7 +416,7 @@ def main():
             out["roofline"]["traffic_note"] = ("no PMC collection of this library (sha16 %s) under profiles/: bash tools/pmc.sh <tag>; "
                                                "collections of other builds, not quoted: %s" % (lib_key, ", ".join(stale) or "none"))
     if rank == 0:
-        if not hq and args.precision == "fp32":
+        if not hq and args.precision == "fp32" and not args.no_dominant_probe:
             dom = runner.dominant_kernel_probe(net, dev)
             dom["traffic"] = None
             # PMC traffic of the kernel that runs: the newest profiles/*dominant_kernel_traffic*.json whose kernel_tag is this

@@ -1,0 +1,99 @@
+// Probe (round 5): a cheaper exact three-way bf16 split of an fp32 value for the split-operand ("x3") kernels.
+//   product form (conv_wino.hip wino_split4):  hi = x & 0xFFFF0000 (truncation), r = x - hi, mid = r & 0xFFFF0000, lo = r - mid,
+//                                              then 3 v_perm per value pair: 22 VALU per 4 values
+//   candidate:   H = v_cvt_pk_bf16_f32(x0, x1)  (round to nearest even, two values per instruction)
+//                r0 = v_dot2c_f32_bf16(H, {-1, 0}, x0), r1 = v_dot2c_f32_bf16(H, {0, -1}, x1)      (unpack + subtract in ONE instruction)
+//                M = cvt_pk(r0, r1); s = dot2c(M, ...); L = cvt_pk(s0, s1):                         14 VALU per 4 values
+// What has to hold on the chip: hi + mid + lo == x exactly (in exact arithmetic) for every finite x that is not within 2^-8 of
+// overflow, each piece a bf16; i.e. v_dot2c_f32_bf16 must not round or flush in this use (every partial sum is representable).
+//   hipcc --offload-arch=gfx950 -O3 tools/probe/split_probe.hip -o gpurun_out/split_probe && gpurun_out/split_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk(float a, float b) {
+    bf16x2 h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b;            // v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float sub_lo(unsigned H, float x) {
+    const bf16x2 m = {(__bf16)-1.0f, (__bf16)0.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, H), m, x, false);
+}
+__device__ __forceinline__ float sub_hi(unsigned H, float x) {
+    const bf16x2 m = {(__bf16)0.0f, (__bf16)-1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, H), m, x, false);
+}
+
+// out[6 i .. 6 i + 5] = hi, mid, lo (as fp32 bit patterns of the bf16 pieces << 16) of x[2 i], then of x[2 i + 1] interleaved:
+// layout [pair][piece][which]
+__global__ void split_kernel(const float* __restrict__ x, unsigned* __restrict__ out, int npairs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const float x0 = x[2 * i], x1 = x[2 * i + 1];
+    const unsigned H = pk(x0, x1);
+    const float r0 = sub_lo(H, x0), r1 = sub_hi(H, x1);
+    const unsigned M = pk(r0, r1);
+    const float s0 = sub_lo(M, r0), s1 = sub_hi(M, r1);
+    const unsigned L = pk(s0, s1);
+    out[6 * i + 0] = H << 16; out[6 * i + 1] = H & 0xFFFF0000u;
+    out[6 * i + 2] = M << 16; out[6 * i + 3] = M & 0xFFFF0000u;
+    out[6 * i + 4] = L << 16; out[6 * i + 5] = L & 0xFFFF0000u;
+}
+
+static float bits(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static unsigned ubits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+
+int main() {
+    std::vector<float> h;
+    // edge cases: zeros, powers of two, all-ones significands, ties of the bf16 rounding, smallest normals, denormals, large values
+    const unsigned edge[] = {0x00000000u, 0x80000000u, 0x3F800000u, 0xBF800000u, 0x3F7FFFFFu, 0x3F808000u, 0x3F818000u, 0x3F808001u,
+                             0x3F80FFFFu, 0x3FFFFFFFu, 0x00800000u, 0x00800001u, 0x00FFFFFFu, 0x01000000u, 0x04000000u, 0x0C7FFFFFu,
+                             0x00000001u, 0x007FFFFFu, 0x7E7FFFFFu, 0x7EFFFFFFu, 0x7F000000u, 0x7F7F0000u, 0x42F6E979u, 0xC2F6E979u,
+                             0x3F80807Fu, 0x3F808080u, 0x3F80807Eu, 0x3F817F80u, 0x3F817F7Fu, 0x3F817F81u};
+    for (unsigned e : edge) h.push_back(bits(e));
+    srand(12345);
+    auto r32 = []() { return ((unsigned)rand() & 0xFFFF) | (((unsigned)rand() & 0xFFFF) << 16); };
+    const int NR = 1 << 22;
+    for (int i = 0; i < NR; ++i) {
+        unsigned u = r32();
+        unsigned ex = (u >> 23) & 0xFF;
+        if (ex == 0xFF) u &= ~(1u << 30);                      // no inf / NaN
+        if (i % 4 == 0) u = (u & 0x807FFFFFu) | ((100u + (u >> 23) % 56u) << 23);       // exponents around 1.0 (activations)
+        if (i % 16 == 1) u = (u & 0x807FFFFFu) | (((u >> 23) % 24u) << 23);             // tiny normals and denormals
+        h.push_back(bits(u));
+    }
+    if (h.size() & 1) h.push_back(0.f);
+    const int n = (int)h.size(), np = n / 2;
+    float* dx; unsigned* dout;
+    hipMalloc(&dx, n * 4); hipMalloc(&dout, (size_t)np * 6 * 4);
+    hipMemcpy(dx, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(split_kernel, dim3((np + 255) / 256), dim3(256), 0, 0, dx, dout, np);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+    std::vector<unsigned> o((size_t)np * 6);
+    hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost);
+    long bad = 0, bad_normal = 0, bad_small = 0, bad_big = 0; int shown = 0;
+    double worst_rel = 0;
+    for (int i = 0; i < n; ++i) {
+        const int p = i / 2, w = i & 1;
+        const float hi = bits(o[6 * p + 0 + w]), mid = bits(o[6 * p + 2 + w]), lo = bits(o[6 * p + 4 + w]);
+        const double sum = (double)hi + (double)mid + (double)lo;
+        const double x = (double)h[i];
+        if (sum != x) {
+            ++bad;
+            const double ax = fabs(x);
+            if (ax >= ldexp(1.0, -100) && ax < ldexp(1.0, 127)) { ++bad_normal; if (x != 0) worst_rel = fmax(worst_rel, fabs(sum - x) / ax); }
+            else if (ax < ldexp(1.0, -100)) ++bad_small; else ++bad_big;
+            if (shown < 12) { printf("  x=%08x (%.9g): hi=%08x mid=%08x lo=%08x  sum-x=%.3g\n", ubits(h[i]), h[i], ubits(hi), ubits(mid), ubits(lo), sum - x); ++shown; }
+        }
+    }
+    printf("split_probe: %d values, %ld inexact (|x| in [2^-100, 2^127): %ld, worst relative %.3g; below 2^-100: %ld; at the top of the range: %ld)\n",
+           n, bad, bad_normal, worst_rel, bad_small, bad_big);
+    printf("VERDICT %s\n", bad_normal == 0 ? "EXACT on the normal range" : "NOT EXACT");
+    return bad_normal == 0 ? 0 : 1;
+}
