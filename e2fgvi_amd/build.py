@@ -42,13 +42,18 @@ def _stale(out, deps):
     return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
-def build(force=False, verbose=False, nopk_all=False, lib=None):
+def build(force=False, verbose=False, nopk_all=False, lib=None, tag=None, defines=()):
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path.
-    nopk_all: build every unit without packed-fp32 VALU (A/B measurements) into ``lib``."""
+    nopk_all: build every unit without packed-fp32 VALU (A/B measurements) into ``lib``.
+    tag / defines: an A/B build with extra -D flags into csrc/build_<tag>/ and csrc/libe2fgvi_hip_<tag>.so (run it with
+    E2FGVI_LIB=<that path>); the product library is the build without either."""
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build_nopk" if nopk_all else "build")
+    if tag:
+        nopk_all = False
+    objdir = os.path.join(CSRC, ("build_" + tag) if tag else ("build_nopk" if nopk_all else "build"))
     os.makedirs(objdir, exist_ok=True)
-    out = lib or (os.path.join(CSRC, "libe2fgvi_hip_nopk.so") if nopk_all else LIB)
+    out = lib or (os.path.join(CSRC, "libe2fgvi_hip_%s.so" % tag) if tag else
+                  os.path.join(CSRC, "libe2fgvi_hip_nopk.so") if nopk_all else LIB)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "e2fgvi_hip.h"), os.path.abspath(__file__)]
     jobs = []
     for src, obj, extra in UNITS:
@@ -56,7 +61,7 @@ def build(force=False, verbose=False, nopk_all=False, lib=None):
         if nopk_all and not any(f == "-packed-fp32-ops" for f in extra):
             extra = extra + NOPK
         if force or _stale(op, [sp] + headers):
-            jobs.append([hipcc] + FLAGS + extra + ["-c", sp, "-o", op])
+            jobs.append([hipcc] + FLAGS + extra + list(defines) + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -74,6 +79,11 @@ def build(force=False, verbose=False, nopk_all=False, lib=None):
             verify_wino_waits(objdir)
             verify_exit_reuse(objdir)
     return out
+
+
+def build_variant(tag, *defines):
+    """python -c 'from e2fgvi_amd import build; build.build_variant("trunc", "-DE2_SPLIT_RNE=0")'"""
+    return build(tag=tag, defines=defines)
 
 
 def device_isa(obj):

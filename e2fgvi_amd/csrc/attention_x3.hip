@@ -48,29 +48,9 @@ __device__ __forceinline__ x_i32x4 x_rsrc_words(const void* base, unsigned bytes
     return r;
 }
 
-// x = hi + mid + lo with bf16 pieces (conv_bf16x.hip::split8)
+// x = hi + mid + lo with bf16 pieces (common.h, e2_split8)
 __device__ __forceinline__ void x_split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    unsigned x[8], rb[8], r2b[8];
-    const u32x4 b0 = __builtin_bit_cast(u32x4, v0), b1 = __builtin_bit_cast(u32x4, v1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[j] = b0[j]; x[4 + j] = b1[j]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float r = __builtin_bit_cast(float, x[j]) - __builtin_bit_cast(float, x[j] & 0xFFFF0000u);
-        rb[j] = __builtin_bit_cast(unsigned, r);
-        const float r2 = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
-        r2b[j] = __builtin_bit_cast(unsigned, r2);
-    }
-    u32x4 H, M, L;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        H[j] = __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], 0x07060302u);
-        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
-        L[j] = __builtin_amdgcn_perm(r2b[2 * j + 1], r2b[2 * j], 0x07060302u);
-    }
-    hi = __builtin_bit_cast(bf16x8, H);
-    mid = __builtin_bit_cast(bf16x8, M);
-    lo = __builtin_bit_cast(bf16x8, L);
+    e2_split8(v0, v1, hi, mid, lo);
 }
 
 // k / v columns (512 .. 1535) of `rows` fp32 qkv rows -> three bf16 planes [3][rows][1024]; one thread per 8 columns

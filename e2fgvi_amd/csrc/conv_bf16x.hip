@@ -70,30 +70,9 @@ __device__ __forceinline__ float dcn_post(float v, int co, int C, const f32x4& f
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-// x = hi + mid + lo with bf16 pieces: hi / mid by clearing the low 16 bits (so x - hi and (x - hi) - mid are exact fp32
-// differences), lo = the rest (<= 8 significant bits: its bf16 conversion is exact too).  Non-finite inputs give NaN.
+// x = hi + mid + lo with bf16 pieces (common.h, e2_split8).  Non-finite inputs give NaN.
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    unsigned x[8], rb[8];
-    float r2[8];
-    const u32x4 b0 = __builtin_bit_cast(u32x4, v0), b1 = __builtin_bit_cast(u32x4, v1);   // (whole vectors: a bit_cast of one
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[j] = b0[j]; x[4 + j] = b1[j]; }                       //  ELEMENT of a vector reference reads element 0)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float r = __builtin_bit_cast(float, x[j]) - __builtin_bit_cast(float, x[j] & 0xFFFF0000u);
-        rb[j] = __builtin_bit_cast(unsigned, r);
-        r2[j] = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
-    }
-    u32x4 H, M, L;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                                // element 2j in the low half of dword j
-        H[j] = __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], 0x07060302u);
-        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
-        L[j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2[2 * j + 1]), __builtin_bit_cast(unsigned, r2[2 * j]), 0x07060302u);
-    }
-    hi = __builtin_bit_cast(bf16x8, H);
-    mid = __builtin_bit_cast(bf16x8, M);
-    lo = __builtin_bit_cast(bf16x8, L);
+    e2_split8(v0, v1, hi, mid, lo);
 }
 
 // Two LDS stages: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.

@@ -52,30 +52,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// x = hi + mid + lo with bf16 pieces (conv_bf16x.hip::split8): hi / mid by clearing the low 16 bits of the value / of the
-// exact remainder, lo = what is left (<= 8 significant bits)
+// x = hi + mid + lo with bf16 pieces: common.h, e2_split2 / e2_split8
 __device__ __forceinline__ void wino_split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    unsigned x[8], rb[8], r2b[8];
-    const u32x4 b0 = __builtin_bit_cast(u32x4, v0), b1 = __builtin_bit_cast(u32x4, v1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[j] = b0[j]; x[4 + j] = b1[j]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float r = __builtin_bit_cast(float, x[j]) - __builtin_bit_cast(float, x[j] & 0xFFFF0000u);
-        rb[j] = __builtin_bit_cast(unsigned, r);
-        const float r2 = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
-        r2b[j] = __builtin_bit_cast(unsigned, r2);
-    }
-    u32x4 H, M, L;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        H[j] = __builtin_amdgcn_perm(x[2 * j + 1], x[2 * j], 0x07060302u);
-        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
-        L[j] = __builtin_amdgcn_perm(r2b[2 * j + 1], r2b[2 * j], 0x07060302u);
-    }
-    hi = __builtin_bit_cast(bf16x8, H);
-    mid = __builtin_bit_cast(bf16x8, M);
-    lo = __builtin_bit_cast(bf16x8, L);
+    e2_split8(v0, v1, hi, mid, lo);
 }
 
 struct WinoParams {
@@ -1086,24 +1065,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3p4_kernel(const WinoParams
 
 // x = hi + mid + lo for four fp32 values (the half of wino_split8 that belongs to one channel quad): two packed bf16 pairs per plane
 __device__ __forceinline__ void wino_split4(const f32x4& v, unsigned (&H)[2], unsigned (&M)[2], unsigned (&L)[2]) {
-    const u32x4 bv = __builtin_bit_cast(u32x4, v);
-    // (plain scalars first: __builtin_bit_cast of a vector-element lvalue reads element 0 for every index with this hipcc)
-    unsigned b[4], rb[4], r2b[4];
+    // (plain scalars first: __builtin_bit_cast / element access through a vector reference)
+    float x[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = bv[j];
+    for (int j = 0; j < 4; ++j) x[j] = v[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float r = __builtin_bit_cast(float, b[j]) - __builtin_bit_cast(float, b[j] & 0xFFFF0000u);
-        rb[j] = __builtin_bit_cast(unsigned, r);
-        const float r2 = r - __builtin_bit_cast(float, rb[j] & 0xFFFF0000u);
-        r2b[j] = __builtin_bit_cast(unsigned, r2);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        H[j] = __builtin_amdgcn_perm(b[2 * j + 1], b[2 * j], 0x07060302u);
-        M[j] = __builtin_amdgcn_perm(rb[2 * j + 1], rb[2 * j], 0x07060302u);
-        L[j] = __builtin_amdgcn_perm(r2b[2 * j + 1], r2b[2 * j], 0x07060302u);
-    }
+    for (int j = 0; j < 2; ++j) e2_split2(x[2 * j], x[2 * j + 1], H[j], M[j], L[j]);
 }
 
 // ---- split-operand Winograd, WIDE tile (round 4): one eight-wave workgroup = a 16x16-pixel block (64 Winograd tiles, two MFMA

@@ -329,21 +329,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                 }
                 const f32x4 v = c00[S][ia] * w00[S][ia] + c01[S][ia] * w01[S][ia] + c10[S][ia] * w10[S][ia] + c11[S][ia] * w11[S][ia];
                 if constexpr (X3) {
-                    // hi / mid / lo of the four blended values: 8-byte writes into the three A planes
-                    const u32x4 xb = __builtin_bit_cast(u32x4, v);
-                    unsigned rb[4], r2b[4];
+                    // hi / mid / lo of the four blended values (common.h, e2_split2): 8-byte writes into the three A planes
+                    float xv[4];                         // (scalar copies: element access through a vector reference)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned xe = xb[e];       // (a scalar copy: bit_cast of a vector ELEMENT reads element 0, see conv_bf16x.hip)
-                        const float r = __builtin_bit_cast(float, xe) - __builtin_bit_cast(float, xe & 0xFFFF0000u);
-                        rb[e] = __builtin_bit_cast(unsigned, r);
-                        const float r2 = r - __builtin_bit_cast(float, rb[e] & 0xFFFF0000u);
-                        r2b[e] = __builtin_bit_cast(unsigned, r2);
-                    }
+                    for (int e = 0; e < 4; ++e) xv[e] = v[e];
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 ph = {(xb[1] & 0xFFFF0000u) | (xb[0] >> 16), (xb[3] & 0xFFFF0000u) | (xb[2] >> 16)};
-                    const u32x2 pm = {(rb[1] & 0xFFFF0000u) | (rb[0] >> 16), (rb[3] & 0xFFFF0000u) | (rb[2] >> 16)};
-                    const u32x2 pl = {(r2b[1] & 0xFFFF0000u) | (r2b[0] >> 16), (r2b[3] & 0xFFFF0000u) | (r2b[2] >> 16)};
+                    u32x2 ph, pm, pl;
+                    {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        e2_split2(xv[0], xv[1], h0, m0, l0);
+                        e2_split2(xv[2], xv[3], h1, m1, l1);
+                        ph[0] = h0; ph[1] = h1; pm[0] = m0; pm[1] = m1; pl[0] = l0; pl[1] = l1;
+                    }
                     __bf16* a16 = reinterpret_cast<__bf16*>(sA) + it_row[ia] * LDA16 + it_uu[ia] * 16 + it_c4[ia] * 4;
                     *reinterpret_cast<u32x2*>(a16) = ph;
                     *reinterpret_cast<u32x2*>(a16 + BM * LDA16) = pm;

@@ -7,6 +7,7 @@ product-side rewrite replaces a reference expression by an equal one, and these 
   * GELU applied before the unfold == after it (the unfold is a gather with zero padding and GELU(0) = 0);
   * the decoder's Conv2d(64, 3, 3, padding=1) (model/e2fgvi.py:99-103) == one [pixels x 64] x [64 x 27] product followed
     by a shifted nine-term sum (csrc/conv_tail.hip)."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -91,21 +92,34 @@ def test_softcomp_fold_is_nine_phase_convolutions_of_the_token_grid():
     assert torch.allclose(out, ref, rtol=0, atol=1e-11)
 
 
-def _split3(x):
-    """the kernels' split (conv_bf16x.hip::split8, mdcn.hip, attention_x3.hip, conv_wino.hip): hi = x with its low 16 bits
-    cleared, mid = the same of the exact remainder, lo = the rest; returned as fp64 values of the three bf16 numbers"""
+def _split3(x, rne=False):
+    """the kernels' splits, returned as fp64 values of the three bf16 numbers (+ the two fp32 remainders):
+    rne=False  weights at packing time (conv_bf16x.hip / conv_wino.hip / mdcn.hip pack kernels, split3_kv): hi = x with its low
+               16 bits cleared, mid = the same of the exact remainder, lo = the rest;
+    rne=True   activations in the kernels since round 5 (csrc/common.h e2_split2): hi = RNE_bf16(x), mid = RNE_bf16(x - hi),
+               lo = x - hi - mid, the remainders formed by v_dot2c_f32_bf16 (exact: every partial sum is representable)"""
     import numpy as np
     x = np.asarray(x, dtype=np.float32)
-    hi = (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    def piece(v):
+        u = v.view(np.uint32)
+        if not rne:
+            return (u & np.uint32(0xFFFF0000)).view(np.float32)
+        # round to nearest even on the upper 16 bits (v_cvt_pk_bf16_f32)
+        r = (u.astype(np.uint64) + np.uint64(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)).astype(np.uint64)) & np.uint64(0xFFFF0000)
+        return r.astype(np.uint32).view(np.float32)
+    hi = piece(x)
     r = (x - hi).astype(np.float32)
-    mid = (r.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    mid = piece(r)
     r2 = (r - mid).astype(np.float32)
-    lo = (r2.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    lo = piece(r2)
     return hi.astype(np.float64), mid.astype(np.float64), lo.astype(np.float64), r, r2
 
 
-def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level():
-    """the arithmetic behind the split-operand ("x3") kernels, on the CPU: (1) hi + mid + lo == x bit for bit and every piece is
+@pytest.mark.parametrize("rne", [False, True], ids=["truncating (weights)", "round-to-nearest (activations)"])
+def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level(rne):
+    """the arithmetic behind the split-operand ("x3") kernels, on the CPU, for both forms of the split (weights are split by
+    truncation when they are packed, activations by round-to-nearest in the kernels; a product pairs one of each): (1) hi + mid + lo == x bit for bit and every piece is
     a bf16 number (16 low bits zero), for random, tiny, huge, negative and few-bit values -- both remainders are exact fp32
     differences and the last one has at most 8 significant bits; (2) the six partial products the kernels issue differ from
     the exact product by less than 2^-21 |ab| (the three dropped ones: mid*lo, lo*mid, lo*lo), i.e. below one fp32 rounding
@@ -118,7 +132,7 @@ def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level():
                         (rng.standard_normal(2000) * 1e30).astype(np.float32),
                         np.array([0.0, -0.0, 1.0, -1.0, 3.0, 1 + 2.0 ** -23, -(1 + 2.0 ** -16), 65504.0, 2.0 ** -126, 2.0 ** -120,
                                   1 - 2.0 ** -24, 255.0, 256.5], dtype=np.float32)])
-    hi, mid, lo, r, r2 = _split3(x)
+    hi, mid, lo, r, r2 = _split3(x, rne)
     assert np.array_equal(hi + mid + lo, x.astype(np.float64)), "the three pieces do not sum to the value"
     assert np.array_equal(r.astype(np.float64), x.astype(np.float64) - hi) and np.array_equal(r2.astype(np.float64), r.astype(np.float64) - mid), \
         "a remainder was rounded"
@@ -126,11 +140,11 @@ def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level():
     for piece in (hi, mid, lo):
         assert not (piece.astype(np.float32).view(np.uint32) & np.uint32(0xFFFF)).any()
     tiny = (rng.standard_normal(5000) * 1e-36).astype(np.float32)
-    th, tm, tl, _, _ = _split3(tiny)
+    th, tm, tl, _, _ = _split3(tiny, rne)
     assert np.max(np.abs(th + tm + tl - tiny.astype(np.float64))) < 2.0 ** -133
     a = rng.standard_normal(100000).astype(np.float32)
     b = rng.standard_normal(100000).astype(np.float32)
-    ah, am, al, _, _ = _split3(a)
+    ah, am, al, _, _ = _split3(a, rne)
     bh, bm, bl, _, _ = _split3(b)
     six = al * bh + ah * bl + am * bm + am * bh + ah * bm + ah * bh            # exact in fp64: each term has <= 16 significant bits
     exact = a.astype(np.float64) * b.astype(np.float64)
@@ -142,7 +156,7 @@ def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level():
     ref = A.astype(np.float64) @ B.astype(np.float64)
     plain = np.zeros(n, np.float32)
     split = np.zeros(n, np.float32)
-    Ah, Am, Al, _, _ = _split3(A)
+    Ah, Am, Al, _, _ = _split3(A, rne)
     Bh, Bm, Bl, _, _ = _split3(B)
     for k in range(K):
         plain = (plain + A[:, k] * B[k]).astype(np.float32)

@@ -21,12 +21,30 @@ __device__ __forceinline__ unsigned pk(float a, float b) {
     h[0] = (__bf16)a; h[1] = (__bf16)b;            // v_cvt_pk_bf16_f32
     return __builtin_bit_cast(unsigned, h);
 }
+// OPAQUE = 0: the constant pair as a literal the compiler may fold -- hipcc (ROCm 7.2) turns (-1, 0) into the inline constant -1.0,
+// which v_dot2c_f32_bf16 expands as the fp32 pattern = the pair (0, -1): first run of this probe, 57 % of the values inexact.
+// OPAQUE = 1 (what csrc/common.h ships): the pair in a scalar register.
+#ifndef OPAQUE
+#define OPAQUE 1
+#endif
 __device__ __forceinline__ float sub_lo(unsigned H, float x) {
+#if OPAQUE
+    unsigned k = 0x0000BF80u;
+    asm volatile("" : "+s"(k));
+    const bf16x2 m = __builtin_bit_cast(bf16x2, k);
+#else
     const bf16x2 m = {(__bf16)-1.0f, (__bf16)0.0f};
+#endif
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, H), m, x, false);
 }
 __device__ __forceinline__ float sub_hi(unsigned H, float x) {
+#if OPAQUE
+    unsigned k = 0xBF800000u;
+    asm volatile("" : "+s"(k));
+    const bf16x2 m = __builtin_bit_cast(bf16x2, k);
+#else
     const bf16x2 m = {(__bf16)0.0f, (__bf16)-1.0f};
+#endif
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, H), m, x, false);
 }
 
