@@ -90,44 +90,15 @@ __device__ __forceinline__ float e2_fast_tanh(float x) {
 // ---------------------------------------------------------------------------------------------
 // Exact three-way bf16 split of fp32 values, two at a time: x = hi + mid + lo in exact arithmetic, every piece a bf16 -- what the
 // split-operand ("x3") kernels feed to v_mfma_f32_32x32x16_bf16.  H / M / L hold the pieces of x0 in their low and
-// of x1 in their high half.
-//   E2_SPLIT_RNE = 1 (round 5): hi = RNE(x), mid = RNE(x - hi), lo = x - hi - mid.  v_cvt_pk_bf16_f32 rounds two values per
-//   instruction, v_dot2c_f32_bf16 with the constant pair (-1, 0) / (0, -1) expands one half of the packed pieces and subtracts it in
-//   ONE instruction (every partial sum is representable, nothing rounds: tools/probe/split_probe.hip checks it on the chip):
-//   7 VALU per value pair against 11 of the truncating form (and, sub, and, sub per value + 3 perms).  The remainders are exact:
-//   |x - hi| <= half a bf16 ulp of x and a multiple of ulp_fp32(x), so it has <= 16 significant bits; one more step leaves <= 8.
-//   Pieces may differ in sign; |mid| <= 2^-9 |x|, |lo| <= 2^-17 |x| (tighter than truncation's 2^-8 / 2^-16: the three dropped
-//   cross terms of a product are < 2^-25 of it).  |x| >= (2 - 2^-8) 2^127 rounds hi to inf (truncation cannot; no activation is
-//   near it); below 2^-110 the last piece may be flushed (< 2^-133 absolute), as before.
-//   E2_SPLIT_RNE = 0: rounds 3-4's truncating split (hi / mid by clearing the low 16 bits).
+// of x1 in their high half.  hi = x with its low 16 bits cleared, mid = the same of the exact remainder, lo = the rest (<= 8
+// significant bits): and, sub, and, sub per value + three v_perm per pair = 11 full-rate VALU instructions per pair.
+// Measured and rejected (round 5, profiles/r05_split_rne_ab.txt): a round-to-nearest split on v_cvt_pk_bf16_f32 + v_dot2c_f32_bf16
+// (the dot product with the constant pair (-1, 0) / (0, -1) expands one half of a packed pair and subtracts it in one
+// instruction: 7 instructions per pair, exact on the chip per tools/probe/split_probe.hip) is SLOWER -- the wide-tile Winograd
+// kernel +4 ... +11 %, everything else within +-4 % -- the two instructions do not issue at the full VALU rate.  (The probe also
+// found that hipcc folds the packed constant (-1, 0) into the inline constant -1.0, which the instruction reads as (0, -1).)
 // ---------------------------------------------------------------------------------------------
-#ifndef E2_SPLIT_RNE
-#define E2_SPLIT_RNE 1
-#endif
-typedef __bf16 e2_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned e2_pk_bf16(float a, float b) {
-    e2_bf16x2 h;
-    h[0] = (__bf16)a;
-    h[1] = (__bf16)b;                                  // one v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, h);
-}
 __device__ __forceinline__ void e2_split2(float x0, float x1, unsigned& H, unsigned& M, unsigned& L) {
-#if E2_SPLIT_RNE
-    // The constant pairs (-1, 0) and (0, -1) as packed bf16 words.  They are made opaque to the compiler on purpose: hipcc (ROCm
-    // 7.2) folds the pair (-1, 0) = 0x0000BF80 into the INLINE constant -1.0 of v_dot2c_f32_bf16, which the hardware expands as the
-    // fp32 pattern 0xBF800000 = the pair (0, -1): the instruction then subtracts the OTHER half (found on the chip by
-    // tools/probe/split_probe.hip, round 5: x = 123.456 came back as 123.5 + 247 + 247).  A register operand has no such reading.
-    unsigned k_lo = 0x0000BF80u, k_hi = 0xBF800000u;
-    asm("" : "+s"(k_lo), "+s"(k_hi));          // (not volatile: one pair of scalar registers per kernel, not per call)
-    const e2_bf16x2 take_lo = __builtin_bit_cast(e2_bf16x2, k_lo), take_hi = __builtin_bit_cast(e2_bf16x2, k_hi);
-    H = e2_pk_bf16(x0, x1);
-    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(e2_bf16x2, H), take_lo, x0, false);
-    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(e2_bf16x2, H), take_hi, x1, false);
-    M = e2_pk_bf16(r0, r1);
-    const float s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(e2_bf16x2, M), take_lo, r0, false);
-    const float s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(e2_bf16x2, M), take_hi, r1, false);
-    L = e2_pk_bf16(s0, s1);                            // exact: <= 8 significant bits
-#else
     const unsigned b0 = __builtin_bit_cast(unsigned, x0), b1 = __builtin_bit_cast(unsigned, x1);
     const float r0 = x0 - __builtin_bit_cast(float, b0 & 0xFFFF0000u), r1 = x1 - __builtin_bit_cast(float, b1 & 0xFFFF0000u);
     const unsigned rb0 = __builtin_bit_cast(unsigned, r0), rb1 = __builtin_bit_cast(unsigned, r1);
@@ -135,7 +106,6 @@ __device__ __forceinline__ void e2_split2(float x0, float x1, unsigned& H, unsig
     H = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
     M = __builtin_amdgcn_perm(rb1, rb0, 0x07060302u);
     L = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
-#endif
 }
 // eight values (two channel quads) -> three operand fragments of eight bf16 each, element j of the pair in position j
 typedef __bf16 e2_bf16x8 __attribute__((ext_vector_type(8)));

@@ -94,10 +94,11 @@ def test_softcomp_fold_is_nine_phase_convolutions_of_the_token_grid():
 
 def _split3(x, rne=False):
     """the kernels' splits, returned as fp64 values of the three bf16 numbers (+ the two fp32 remainders):
-    rne=False  weights at packing time (conv_bf16x.hip / conv_wino.hip / mdcn.hip pack kernels, split3_kv): hi = x with its low
-               16 bits cleared, mid = the same of the exact remainder, lo = the rest;
-    rne=True   activations in the kernels since round 5 (csrc/common.h e2_split2): hi = RNE_bf16(x), mid = RNE_bf16(x - hi),
-               lo = x - hi - mid, the remainders formed by v_dot2c_f32_bf16 (exact: every partial sum is representable)"""
+    rne=False  what the kernels and the weight packers do (csrc/common.h e2_split2): hi = x with its low 16 bits cleared, mid = the
+               same of the exact remainder, lo = the rest;
+    rne=True   the round-to-nearest variant measured and rejected in round 5 (hi = RNE_bf16(x), mid = RNE_bf16(x - hi), lo = the
+               rest; v_cvt_pk_bf16_f32 + v_dot2c_f32_bf16: fewer but slower instructions, profiles/r05_split_rne_ab.txt) -- kept
+               here because its exactness argument is the one tools/probe/split_probe.hip checks on the chip"""
     import numpy as np
     x = np.asarray(x, dtype=np.float32)
 
@@ -116,10 +117,10 @@ def _split3(x, rne=False):
     return hi.astype(np.float64), mid.astype(np.float64), lo.astype(np.float64), r, r2
 
 
-@pytest.mark.parametrize("rne", [False, True], ids=["truncating (weights)", "round-to-nearest (activations)"])
+@pytest.mark.parametrize("rne", [False, True], ids=["truncating (the kernels)", "round-to-nearest (rejected variant)"])
 def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level(rne):
-    """the arithmetic behind the split-operand ("x3") kernels, on the CPU, for both forms of the split (weights are split by
-    truncation when they are packed, activations by round-to-nearest in the kernels; a product pairs one of each): (1) hi + mid + lo == x bit for bit and every piece is
+    """the arithmetic behind the split-operand ("x3") kernels, on the CPU, for the split the kernels use and for the
+    round-to-nearest variant of round 5's probe: (1) hi + mid + lo == x bit for bit and every piece is
     a bf16 number (16 low bits zero), for random, tiny, huge, negative and few-bit values -- both remainders are exact fp32
     differences and the last one has at most 8 significant bits; (2) the six partial products the kernels issue differ from
     the exact product by less than 2^-21 |ab| (the three dropped ones: mid*lo, lo*mid, lo*lo), i.e. below one fp32 rounding
