@@ -74,7 +74,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // chunks past the end read as zero through the buffer bounds, so the loop has no branches.
 // BF: the sampled slab and the weights are held in LDS as bf16 and multiplied on v_mfma_f32_32x32x16_bf16 (the bf16 data
 // path); the gather, the bilinear blend and the accumulation are fp32 either way.
-//   bf16 LDS images: A [BM rows][32 k (+8 pad)] (80-byte rows: conflict-free b128 reads), B [4 k-octets][BN][8]
+//   bf16 LDS image: A [BM rows][32 k (+8 pad)] (80-byte rows: conflict-free b128 reads).  The B operand (weights) does NOT go
+//   through LDS (round 5): the packed layout [chunk][plane][4 k-octets][Npad][8] is exactly the MFMA's B operand per lane (lane
+//   (n = l & 31, half = l >> 5) of k-step kk needs the 16 bytes of octet 2 kk + half, column n), so every wave fetches the
+//   fragments of its own columns straight into registers, a chunk ahead -- no staging registers -> ds_write -> ds_read round trip
+//   (6 + 6 LDS instructions per thread and chunk in the split-operand variant), and an LDS stage shrinks to the A slab
 // S16 (with BF): the sources are bf16 NHWC.  A 16-byte corner fetch then carries 8 channels instead of 4, so an item is
 // (row, unit, 8-channel half): half the items, half the fetches and half the per-item offset arithmetic (the bilinear
 // weights, tanh / sigmoid and address math are computed once per item) for the same slab.
@@ -97,13 +101,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     constexpr int LDA16 = BK + 8;                     // bf16 elements per A row
     constexpr int A_ITEMS = BM * 2 * CQ;              // (row, unit-in-chunk, 16-byte channel part)
     constexpr int A_IT = (A_ITEMS + NG - 1) / NG;
-    constexpr int B_F4 = BF ? NP * BK * BN / 8 : BK * BN / 4;      // 16-byte items of a chunk's weight slab
-    constexpr int B_IT = (B_F4 + NG - 1) / NG;
-    constexpr int STAGE = BF ? NP * (BM * LDA16 + BK * BN) / 2 : BM * LDA + BK * BN;      // floats
+    constexpr int B_F4 = BK * BN / 4;                 // fp32 MFMA path: 16-byte items of a chunk's weight slab (staged through LDS)
+    constexpr int B_IT = BF ? 1 : (B_F4 + NG - 1) / NG;
+    constexpr int STAGE = BF ? NP * (BM * LDA16) / 2 : BM * LDA + BK * BN;      // floats (bf16 products: the A slab only)
     constexpr unsigned OOB = 0xFFFFFFFFu;
-    static_assert(KS * 2 * STAGE >= (KS - 1) * NG * TM * TN * 16, "reduction scratch must fit in LDS");
+    constexpr int RING = KS * 2 * STAGE, PARTS = (KS - 1) * NG * TM * TN * 16;  // the K groups' partial sums reuse the ring
+    constexpr int SMEM_F = RING > PARTS ? RING : PARTS;
 
-    __shared__ __attribute__((aligned(16))) float smem[KS * 2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
     __shared__ __attribute__((aligned(16))) int utab[MAX_UNITS * 8];
     // raw offset / mask (/ flow) words of a chunk: one 32-byte slot per (pixel row, unit) = {dy, dx, mask, -, fu, fv, -, -},
     // fetched by the first 2 BM threads of the group (3 loads) instead of by every item's four channel lanes
@@ -150,12 +155,24 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         b_off[ib] = ok ? (unsigned)((kq * p.Npad + n0 + n) * 16) : OOB;
     }
     const unsigned b_step = (unsigned)(BF ? NP * BK / 8 : BK / 4) * (unsigned)p.Npad * 16u;
+    // bf16 products: the lane's B fragments of chunk kt = 16 bytes at (plane pl, octet 2 kk + half, column n0 + (wn TN + tn) 32 + n).
+    // One lane-dependent offset (half, n) advanced by a chunk per trip; plane / k-step / column tile are wave-uniform and go into
+    // the load's scalar offset.  A column tile that lies entirely past Npad (Cout < BN) re-reads tile 0 -- its results are never
+    // stored, and the scalar offset (which the buffer's range check does not see) must not lead outside the packed weights.
+    const unsigned bf_lane = (unsigned)(((lane >> 5) * p.Npad + n0 + (lane & 31)) * 16);
+    unsigned bf_tn[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+        bf_tn[tn] = (n0 + (wn * TN + tn) * 32 < p.Npad) ? (unsigned)((wn * TN + tn) * 32 * 16) : 0u;
+    const unsigned bf_oct2 = 2u * (unsigned)p.Npad * 16u;       // two k-octets (one k-step of 16)
 
     // two register sets: the corner fetches / weights of chunk k+2 are issued while those of chunk k+1 (issued one
     // iteration earlier) are blended into LDS -- a whole MFMA block plus another group's turn covers the gather latency
     f32x4 c00[2][A_IT], c01[2][A_IT], c10[2][A_IT], c11[2][A_IT];
     float w00[2][A_IT], w01[2][A_IT], w10[2][A_IT], w11[2][A_IT];
-    f32x4 rb[2][B_IT];
+    f32x4 rb[2][B_IT];                                // fp32 MFMA path: staged weights
+    typedef __bf16 dcn_bf16x8 __attribute__((ext_vector_type(8)));
+    dcn_bf16x8 bfr[2][NP][2][TN];                     // bf16 products: B fragments [set][plane][k-step][column tile]
 
     // ---- unit decode through a table in LDS.  A K-chunk is two units (uu = 0 / 1 by lane); unit u = ((g * KK) + tap) * cgq + cq.
     // Everything a lane needs from (g, tap, cq) -- offset / mask / flow word offsets, the tap's (ky, kx) * dilation, the
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             const int* e = utab + (uok ? u : 0) * 8;
             const int dyk = e[3], dxk = e[4];
             // both units of a chunk read the same source (host guarantees an even unit count in source 0)
-            const bool second_src = (kt * 2) >= p.units0;
+            const bool second_src = (__builtin_amdgcn_readfirstlane(kt) * 2) >= p.units0;
             const unsigned cbase4 = second_src ? (unsigned)p.c[0] * (unsigned)SB : 0u;
             unsigned ld4 = (unsigned)(second_src ? p.ld[1] : p.ld[0]) * (unsigned)SB;
             unsigned ch = (unsigned)(S16 ? e[5] >> 1 : e[5]) - cbase4;
@@ -283,8 +300,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     };
     // the items' half: a slot's addresses + this item's 16-byte part -> corner fetches of chunk kt
     auto issue_corners = [&](int kt, int S, int rbuf) {
-        const bool second_src = (kt * 2) >= p.units0;
-        const __amdgpu_buffer_rsrc_t rs = second_src ? r_src1 : r_src0;
+        // (kt is wave-uniform; said so explicitly: hipcc otherwise selected the resource with v_cndmask in one of the two unrolled
+        //  halves of the K loop and wrapped each of the four corner loads in a waterfall loop -- ~45 instructions per chunk)
+        const bool second_src = (__builtin_amdgcn_readfirstlane(kt) * 2) >= p.units0;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(second_src ? p.src[1] : p.src[0], second_src ? p.src_bytes[1] : p.src_bytes[0]);
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             const float* slot = graw + (rbuf * SLOTS + it_row[ia] * 2 + it_uu[ia]) * 8;
@@ -299,14 +318,27 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         }
     };
     auto load_w = [&](int kt, int S) {
-        const bool tile_ok = kt < KT;
+        if constexpr (BF) {
+            // straight into the MFMA's B operand registers (chunks past the end: out of range = zeros)
+            const unsigned vo = kt < KT ? bf_lane + (unsigned)kt * b_step : OOB;
 #pragma unroll
-        for (int ib = 0; ib < B_IT; ++ib)
-            rb[S][ib] = buf_load4(r_w, (b_off[ib] == OOB || !tile_ok) ? OOB : b_off[ib] + (unsigned)kt * b_step);
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        bfr[S][pl][kk][tn] = __builtin_bit_cast(dcn_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                            r_w, (int)vo, (int)((unsigned)(pl * 2) * bf_oct2 + (unsigned)kk * bf_oct2 + bf_tn[tn]), 0));
+        } else {
+            const bool tile_ok = kt < KT;
+#pragma unroll
+            for (int ib = 0; ib < B_IT; ++ib)
+                rb[S][ib] = buf_load4(r_w, (b_off[ib] == OOB || !tile_ok) ? OOB : b_off[ib] + (unsigned)kt * b_step);
+        }
     };
     auto store_tile = [&](int buf, int S) {
         float* sA = sbase + buf * STAGE;
-        float* sB = BF ? sA + NP * BM * LDA16 / 2 : sA + BM * LDA;
+        float* sB = sA + BM * LDA;                     // (fp32 MFMA path only)
 #pragma unroll
         for (int ia = 0; ia < A_IT; ++ia) {
             if (A_ITEMS % NG == 0 || (tid + ia * NG) < A_ITEMS) {
@@ -354,10 +386,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                 }
             }
         }
+        if constexpr (!BF) {
 #pragma unroll
-        for (int ib = 0; ib < B_IT; ++ib) {
-            const int f = tid + ib * NG;
-            if (B_F4 % NG == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[S][ib];
+            for (int ib = 0; ib < B_IT; ++ib) {
+                const int f = tid + ib * NG;
+                if (B_F4 % NG == 0 || f < B_F4) *reinterpret_cast<f32x4*>(sB + f * 4) = rb[S][ib];
+            }
         }
     };
 
@@ -398,11 +432,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
         for (int par = 0; par < 2; ++par) {
             const int kt = kg + (it + par) * KS;
             issue_corners(kt + 2 * KS, par, par);            // raw words of chunk i+2 from sraw buffer i&1
-            load_w(kt + 2 * KS, par);
+            if constexpr (!BF) load_w(kt + 2 * KS, par);     // (bf16 products: behind the MFMAs, into the fragment set they have just read)
             if constexpr (X3) {
                 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                 const __bf16* sA16 = reinterpret_cast<const __bf16*>(sbase + cur * STAGE);
-                const __bf16* sB16 = sA16 + 3 * BM * LDA16;
                 const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -413,8 +446,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                         for (int tm = 0; tm < TM; ++tm)
                             a[pl][tm] = *reinterpret_cast<const bf16x8*>(sA16 + pl * (BM * LDA16) + ((wm * TM + tm) * 32 + li) * LDA16 + (2 * kk + lh) * 8);
 #pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-                            b[pl][tn] = *reinterpret_cast<const bf16x8*>(sB16 + pl * (BK * BN) + ((2 * kk + lh) * BN + (wn * TN + tn) * 32 + li) * 8);
+                        for (int tn = 0; tn < TN; ++tn) b[pl][tn] = bfr[par][pl][kk][tn];
                     }
                     // smallest terms first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
                     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -429,7 +461,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
             } else if (BF) {
                 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                 const __bf16* sA16 = reinterpret_cast<const __bf16*>(sbase + cur * STAGE);
-                const __bf16* sB16 = sA16 + BM * LDA16;
                 const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -438,8 +469,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                     for (int tm = 0; tm < TM; ++tm)
                         a[tm] = *reinterpret_cast<const bf16x8*>(sA16 + ((wm * TM + tm) * 32 + li) * LDA16 + (2 * kk + lh) * 8);
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        b[tn] = *reinterpret_cast<const bf16x8*>(sB16 + ((2 * kk + lh) * BN + (wn * TN + tn) * 32 + li) * 8);
+                    for (int tn = 0; tn < TN; ++tn) b[tn] = bfr[par][0][kk][tn];
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -450,6 +480,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
                 mma_ktile<TM, TN, BK, LDA, BN>(sbase + cur * STAGE, sbase + cur * STAGE + BM * LDA, acc, wm * TM * 32,
                                                wn * TN * 32, lane);
             }
+            if constexpr (BF) load_w(kt + 2 * KS, par);      // chunk i+2's B fragments: a whole trip to land
             store_tile(cur ^ 1, par ^ 1);                    // chunk i+1
             store_offsets(par ^ 1, kt + 3 * KS);             // chunk i+3 (that buffer's readers passed the last barrier)
             load_offsets(kt + 4 * KS);
@@ -602,7 +633,7 @@ int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16, bool x3 = false)
     p.tilesN = cdiv(p.Cout, BN);
     if (x3) {
         // three bf16 planes per operand: two ring stages per K group must fit the LDS beside the offset slots
-        if constexpr (KS * 2 * 3 * (BM * (32 + 8) + 32 * BN) * 2 + KS * 2 * 2 * BM * 32 + MAX_UNITS * 32 + 1024 <= 160 * 1024)
+        if constexpr (KS * 2 * 3 * (BM * (32 + 8)) * 2 + KS * 2 * 2 * BM * 32 + MAX_UNITS * 32 + 1024 <= 160 * 1024)
             hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
         else {
             e2fgvi_set_error("mdcn: this tile does not fit the LDS with split operands");
@@ -612,8 +643,15 @@ int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16, bool x3 = false)
         hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
     else if (bf)
         hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
-    else
-        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, false, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+    else {
+        // fp32 MFMA: the weights are staged through LDS
+        if constexpr (KS * 2 * (BM * (32 + 4) + 32 * BN) * 4 + KS * 2 * 2 * BM * 32 + MAX_UNITS * 32 + 1024 <= 160 * 1024)
+            hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, false, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+        else {
+            e2fgvi_set_error("mdcn: this tile does not fit the LDS with fp32 operands");
+            return E2FGVI_EUNSUP;
+        }
+    }
     E2_LAUNCH_CHECK("mdcn");
     return 0;
 }
@@ -761,6 +799,8 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
     if (tile == 4) return launch_dcn<32, 128, 1, 4, 2>(p, (hipStream_t)stream, bf, s16, x3);
     if (tile == 5) return launch_dcn<32, 128, 1, 4, 3>(p, (hipStream_t)stream, bf, s16, x3);
     if (tile == 6) return launch_dcn<64, 128, 2, 2, 2>(p, (hipStream_t)stream, bf, s16, x3);
+    // four K groups (round 5: with the weights out of the LDS a stage is the A slab alone): bf16 products only
+    if (tile == 7 && (bf || x3)) return launch_dcn<32, 128, 1, 4, 4>(p, (hipStream_t)stream, bf, s16, x3);
     e2fgvi_set_error("mdcn: unknown tile %d", tile);
     return E2FGVI_EINVAL;
 }

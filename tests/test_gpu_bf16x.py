@@ -314,7 +314,7 @@ def test_bf16_path_against_reference_golden(dev, fixture):
     assert_bound(np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max(), 5e-2 * max(1.0, fmax / 4), "bf16 golden %s flow bwd" % fixture)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 5, 6, 101, 106])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 101, 106])
 def test_mdcn_bf16_mfma(dev, tile):
     """deformable conv with the sampled columns and the weights rounded to bf16 for the MFMA (fp32 gather, blend and
     accumulation): against the fp32 oracle of mmcv's op.  Each of the K = 2304 products carries two 2^-9 roundings with
@@ -350,7 +350,7 @@ def test_mdcn_bf16_mfma(dev, tile):
         ops.PackedDcn(w.to(dev), b.to(dev), dg, pad=1)(xs16, nhwc(off).to(dev), mask=nhwc(msk).to(dev))   # bf16 sources need mfma="bf16"
 
 
-@pytest.mark.parametrize("tile", [1, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 4, 5, 6, 7])
 def test_mdcn_reruns_are_bit_identical(dev, tile):
     """200 launches of the same deformable conv must agree bit for bit (a 3 % per-launch event is missed with p < 1 %).  Guards the packed-fp32 hazard of DESIGN.md "Stream
     overlap" INSIDE one workgroup: mdcn.hip's sampler waves do arithmetic on freshly loaded offset / mask / flow words beside
