@@ -49,6 +49,8 @@ struct ConvXParams {
     int dst_ld, dst_coff, dst_bf16, dst_nchw;
     __bf16* dst2;
     int dst2_ld, dst2_coff;
+    int split_from;                    // ABI 8: channels >= split_from go to dst2 as three exact bf16 planes (split_plane elements apart)
+    long long split_plane;
     int act;
     float slope;
     int tp_cq;                            // tap-packed K-steps (narrow single-source layers): 16-byte chunks per tap (1..7), 0 = off
@@ -535,6 +537,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                 v0[c] = v0[c] > 0.f ? v0[c] : v0[c] * neg;
                 v1[c] = v1[c] > 0.f ? v1[c] : v1[c] * neg;
             }
+            if (p.split_plane && co >= p.split_from) {
+                // the K / V columns of a qkv Linear: the operand planes of the split-operand attention, not the fp32 rows
+                bf16x8 sh, sm, sl;
+                e2_split8(v0, v1, sh, sm, sl);
+                __bf16* o = p.dst2 + m * p.dst2_ld + p.dst2_coff + (co - p.split_from);
+                *reinterpret_cast<bf16x8*>(o) = sh;
+                *reinterpret_cast<bf16x8*>(o + p.split_plane) = sm;
+                *reinterpret_cast<bf16x8*>(o + 2 * p.split_plane) = sl;
+                continue;
+            }
             bf16x8 hv = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
             const long long dof = m * p.dst_ld + p.dst_coff + co;
             if (p.dst_bf16) {
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                 *reinterpret_cast<f32x4*>(o) = v0;
                 *reinterpret_cast<f32x4*>(o + 4) = v1;
             }
-            if (p.dst2) *reinterpret_cast<bf16x8*>(p.dst2 + m * p.dst2_ld + p.dst2_coff + co) = hv;
+            if (p.dst2 && !p.split_plane) *reinterpret_cast<bf16x8*>(p.dst2 + m * p.dst2_ld + p.dst2_coff + co) = hv;
         }
         continue;
     }
@@ -607,6 +619,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = apply_act(v[c], p.act, p.slope);
             }
+            if (p.split_plane && co >= p.split_from) {       // (the launcher guarantees Cout % 8 == 0 and 16-byte addressable planes)
+                const f32x4 s0 = {v[0], v[1], v[2], v[3]}, s1 = {v[4], v[5], v[6], v[7]};
+                bf16x8 sh, sm, sl;
+                e2_split8(s0, s1, sh, sm, sl);
+                __bf16* o = p.dst2 + (long long)m * p.dst2_ld + p.dst2_coff + (co - p.split_from);
+                *reinterpret_cast<bf16x8*>(o) = sh;
+                *reinterpret_cast<bf16x8*>(o + p.split_plane) = sm;
+                *reinterpret_cast<bf16x8*>(o + 2 * p.split_plane) = sl;
+                continue;
+            }
             bf16x8 hv;
 #pragma unroll
             for (int c = 0; c < 8; ++c) hv[c] = (__bf16)v[c];
@@ -635,7 +657,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
                     for (int c = 0; c < 8; ++c) if (full || n + c < p.Cout_g) o[c] = v[c];
                 }
             }
-            if (p.dst2) {
+            if (p.dst2 && !p.split_plane) {
                 __bf16* o = p.dst2 + (long long)m * p.dst2_ld + p.dst2_coff + co;
                 if (vec_2) *reinterpret_cast<bf16x8*>(o) = hv;
                 else {
@@ -958,7 +980,18 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         E2_REQUIRE(d->dst_coff >= 0 && d->dst_coff + d->Cout <= d->dst_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst slice exceeds dst_ld");
     E2_REQUIRE(((uintptr_t)d->dst & 15) == 0 && (!d->dst2 || ((uintptr_t)d->dst2 & 15) == 0) &&
                (!d->residual || ((uintptr_t)d->residual & 15) == 0), E2FGVI_EINVAL, "conv2d_bf16x: dst / dst2 / residual not 16-byte aligned");
-    if (d->dst2) E2_REQUIRE(d->dst2_coff >= 0 && d->dst2_coff + d->Cout <= d->dst2_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst2 slice exceeds dst2_ld");
+    if (d->dst2_plane_stride) {
+        // ABI 8: channels from dst2_split_from on as three exact bf16 planes (16-byte stores of 8 channels)
+        E2_REQUIRE(d->dst2 && d->dst2_plane_stride > 0 && d->dst_dtype == E2FGVI_F32 && !d->dst_nchw && d->groups == 1 &&
+                       !(d->out_grid && d->out_sy), E2FGVI_EINVAL,
+                   "conv2d_bf16x: split planes need dst2, an fp32 NHWC dst, groups = 1 and no output scatter");
+        E2_REQUIRE(d->Cout % 8 == 0 && d->dst2_split_from >= 0 && d->dst2_split_from <= d->Cout && d->dst2_split_from % 8 == 0 &&
+                       d->dst2_ld % 8 == 0 && d->dst2_coff % 8 == 0 && d->dst2_plane_stride % 8 == 0 && d->dst2_coff >= 0 &&
+                       d->dst2_coff + d->Cout - d->dst2_split_from <= d->dst2_ld, E2FGVI_EINVAL,
+                   "conv2d_bf16x: split planes: Cout, dst2_split_from, dst2_ld, dst2_coff and dst2_plane_stride in multiples of 8, "
+                   "the split channels inside dst2_ld");
+    } else if (d->dst2)
+        E2_REQUIRE(d->dst2_coff >= 0 && d->dst2_coff + d->Cout <= d->dst2_ld, E2FGVI_EINVAL, "conv2d_bf16x: dst2 slice exceeds dst2_ld");
     if (d->act == E2FGVI_ACT_DCNPOST)
         E2_REQUIRE(d->residual && d->res_dtype == E2FGVI_F32 && d->Cout % 3 == 0 && d->groups == 1, E2FGVI_EINVAL,
                    "conv2d_bf16x: ACT_DCNPOST needs the fp32 [pixel][4] flows as residual, Cout %% 3 == 0, groups == 1");
@@ -989,6 +1022,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
     p.dst = d->dst; p.dst_ld = d->dst_ld; p.dst_coff = d->dst_coff; p.dst_bf16 = d->dst_dtype == E2FGVI_BF16;
     p.dst_nchw = d->dst_nchw;
     p.dst2 = (__bf16*)d->dst2; p.dst2_ld = d->dst2_ld; p.dst2_coff = d->dst2_coff;
+    p.split_from = d->dst2_split_from; p.split_plane = d->dst2_plane_stride;
     p.act = d->act; p.slope = d->slope;
     hipStream_t st = (hipStream_t)stream;
     int tile = d->tile;

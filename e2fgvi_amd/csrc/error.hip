@@ -11,4 +11,4 @@ void e2fgvi_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* e2fgvi_last_error(void) { return g_err; }
-extern "C" int e2fgvi_abi_version(void) { return 7; }
+extern "C" int e2fgvi_abi_version(void) { return 8; }

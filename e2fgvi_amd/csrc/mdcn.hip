@@ -163,7 +163,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     unsigned bf_tn[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
-        bf_tn[tn] = (n0 + (wn * TN + tn) * 32 < p.Npad) ? (unsigned)((wn * TN + tn) * 32 * 16) : 0u;
+        bf_tn[tn] = (unsigned)__builtin_amdgcn_readfirstlane((n0 + (wn * TN + tn) * 32 < p.Npad) ? (wn * TN + tn) * 32 * 16 : 0);
+    // (readfirstlane: wn is wave-uniform but derived from threadIdx; as a vector value the scalar offset made hipcc wrap every
+    //  fragment load in a waterfall loop)
     const unsigned bf_oct2 = 2u * (unsigned)p.Npad * 16u;       // two k-octets (one k-step of 16)
 
     // two register sets: the corner fetches / weights of chunk k+2 are issued while those of chunk k+1 (issued one
@@ -792,7 +794,8 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         }
     }
     const bool bf = d->mfma_dtype == E2FGVI_BF16;
-    if (x3 && !d->tile) tile = tile == 5 ? 4 : tile;     // three planes per operand: the three-K-group tile does not fit the LDS
+    // (round 5: with the weights out of the LDS the three-K-group tile fits with split operands too: 53.0 vs 56.0 us at 60x108,
+    //  profiles/r05_dcn_tiles.txt)
     if (tile == 1) return launch_dcn<64, 128, 2, 2, 1>(p, (hipStream_t)stream, bf, s16, x3);
     if (tile == 2) return launch_dcn<32, 128, 1, 4, 1>(p, (hipStream_t)stream, bf, s16, x3);
     if (tile == 3) return launch_dcn<32, 64, 1, 2, 1>(p, (hipStream_t)stream, bf, s16, x3);

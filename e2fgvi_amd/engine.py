@@ -371,10 +371,11 @@ class Engine(BF16Path):
         return x                                            # [b*t, h, w, 128]
 
     # ------------------------------------------------------------------ propagation
-    def propagate(self, loc, flows_a, flows_b):
+    def propagate(self, loc, flows_a, flows_b, inplace=False):
         """loc: [l_t, b, h, w, 128] frame-major local features.  flows_a / flows_b: NHWC [b,l_t-1,h,w,2]; they are
         bound positionally like the reference (e2fgvi.py:249-250): flows_a drives 'backward_', flows_b 'forward_'.
-        Returns the propagated features [l_t, b, h, w, 128]."""
+        Returns the propagated features [l_t, b, h, w, 128]; inplace: written over `loc` (the fusion layer's residual is `loc`
+        itself: its epilogue reads a residual element and writes the same element in the same thread)."""
         l_t, b, h, w, ch = loc.shape
         dev = loc.device
         feats = {}
@@ -409,7 +410,7 @@ class Engine(BF16Path):
                 hist.append(feat_prop)
             feats[name] = store
         out = self.fusion([feats["backward_"].view(l_t * b, h, w, ch), feats["forward_"].view(l_t * b, h, w, ch)],
-                          residual=loc.view(l_t * b, h, w, ch))
+                          residual=loc.view(l_t * b, h, w, ch), out=loc.view(l_t * b, h, w, ch) if inplace else None)
         return out.view(l_t, b, h, w, ch)
 
     # ------------------------------------------------------------------ transformer
@@ -428,13 +429,16 @@ class Engine(BF16Path):
         nbuf = torch.empty((rows + prow, 512), dtype=torch.float32, device=x.device)
         n1 = ops.layernorm(x, blk["n1w"], blk["n1b"], out=nbuf[:rows])
         ops.window_pool(n1, blk["pool_w"], blk["pool_b"], b * t, fh, fw, out=nbuf[rows:])
-        both = blk["qkv"](nbuf)
-        qkv, kvp = both[:rows], both[rows:]
         if ops.attention_x3_applies(b, t, fh, fw):
-            # both products on the bf16 matrix pipe (exactly split operands): one pass splits the k / v columns of all rows
-            att = ops.focal_attention_x3(qkv, ops.split3_kv(both), tab, nk, b, t, fh, fw)
+            # both products on the bf16 matrix pipe (exactly split operands).  The k / v columns of all rows as three bf16 planes:
+            # written by the qkv GEMM's epilogue when the split-operand GEMM runs it (round 5: no separate pass over the rows, and
+            # the fp32 K / V columns are never stored), by e2fgvi_split3_kv otherwise (ops.PackedConv.__call__, kv_planes)
+            planes = torch.empty((3, rows + prow, 1024), dtype=torch.bfloat16, device=x.device)
+            both = blk["qkv"](nbuf, kv_planes=planes)
+            att = ops.focal_attention_x3(both[:rows], planes, tab, nk, b, t, fh, fw)
         else:
-            att = ops.focal_attention(qkv, kvp, tab, nk, b, t, fh, fw)
+            both = blk["qkv"](nbuf)
+            att = ops.focal_attention(both[:rows], both[rows:], tab, nk, b, t, fh, fw)
         x1 = blk["proj"](att, residual=x)
         n2 = ops.layernorm(x1, blk["n2w"], blk["n2b"])
         hid = blk["fc1"](n2)
@@ -509,8 +513,12 @@ class Engine(BF16Path):
         enc5 = enc.view(b, t, h, w, ch)
         if b == 1:
             loc = enc5[0, :l_t].unsqueeze(1)                 # view: [l_t, 1, h, w, C]
-            prop = self.propagate(loc, fwd, bwd)
-            enc5[0, :l_t].copy_(prop[:, 0])
+            # one clip: the local frames are a view of the encoder output and the propagated features replace them in place (no
+            # 33 MB copy; under E2FGVI_AUTOTUNE=1 the fusion layer writes a fresh tensor so that its candidates can be timed)
+            inplace = not ops.AUTOTUNE
+            prop = self.propagate(loc, fwd, bwd, inplace=inplace)
+            if not inplace:
+                enc5[0, :l_t].copy_(prop[:, 0])
         else:
             loc = enc5[:, :l_t].permute(1, 0, 2, 3, 4).contiguous()
             prop = self.propagate(loc, fwd, bwd)

@@ -45,6 +45,8 @@ class ConvXDesc(C.Structure):
         ("out_grid", C.c_int32), ("pad_left", C.c_int32),
         ("out_sy", C.c_int32), ("out_sx", C.c_int32), ("out_py", C.c_int32), ("out_px", C.c_int32),
         ("out_H", C.c_int32), ("out_W", C.c_int32), ("res_bcast", C.c_int32),
+        # ABI version 8: output channels from dst2_split_from on as three exact bf16 planes in dst2 (the qkv Linear -> attention_x3)
+        ("dst2_split_from", C.c_int32), ("dst2_plane_stride", C.c_int64),
     ]
 
 

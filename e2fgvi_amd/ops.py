@@ -423,8 +423,11 @@ class PackedConv:
             N, H, W, cin_g * self.groups, self.Cout, self.KH, self.stride, self.groups), macs=macs, issued=issued)
 
     def __call__(self, sources, out=None, out_coff=0, residual=None, res_coff=0, act=ACT_NONE, slope=0.0,
-                 out_nchw=False, tile=0):
-        """sources: list of NHWC tensors or (tensor, channel_offset) pairs, one per cpg entry."""
+                 out_nchw=False, tile=0, kv_planes=None):
+        """sources: list of NHWC tensors or (tensor, channel_offset) pairs, one per cpg entry.
+        kv_planes (a qkv Linear, Cout = 1536): [3, rows, 1024] bf16 -- the K / V columns as the three exact planes the split-operand
+        attention reads.  When the decision table hands the call to the split-operand GEMM its epilogue writes them (and skips the
+        fp32 K / V columns); any other kernel writes the fp32 rows and e2fgvi_split3_kv makes the planes from them."""
         lib = _L.load()
         d = _L.ConvDesc()
         srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
@@ -445,6 +448,8 @@ class PackedConv:
                 self([(t[n0:n1], c) for t, c in srcs], out=out[n0:n1], out_coff=out_coff,
                      residual=None if residual is None else residual[n0:n1], res_coff=res_coff, act=act, slope=slope,
                      out_nchw=out_nchw, tile=tile)
+            if kv_planes is not None:
+                split3_kv(out.view(-1, out.shape[-1]), out=kv_planes)
             return out
         for i, (t, coff) in enumerate(srcs):
             _chk(t, "source %d" % i)
@@ -587,10 +592,14 @@ class PackedConv:
                         w3_tile = W3_WIDE_FALLBACK
                 elif best and X3_BASE <= best < W3_BASE and self._alt3() is not None:
                     return self.alt3(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
-                                     tile=best - X3_BASE, out_nchw=out_nchw)
+                                     tile=best - X3_BASE, out_nchw=out_nchw, planes=kv_planes,
+                                     split_from=(self.Cout - kv_planes.shape[2]) if kv_planes is not None else 0)
                 elif best and self.tune and 2000 <= best < 2100 and self._alt() is not None:
-                    return self.alt(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
-                                    tile=best - 2000, out_nchw=out_nchw)
+                    r = self.alt(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
+                                 tile=best - 2000, out_nchw=out_nchw)
+                    if kv_planes is not None:
+                        split3_kv(out.view(-1, out.shape[-1]), out=kv_planes)
+                    return r
                 elif self.tune and best is not None and best < 2000:
                     d.tile = best
             except _L.HipError:
@@ -606,6 +615,8 @@ class PackedConv:
             w3_tile, d.tile = None, tile0          # a tabled block shape this call's geometry rejects: the static default
             rc, what = launch()
         _L.check(rc, what)
+        if kv_planes is not None:
+            split3_kv(out.view(-1, out.shape[-1]), out=kv_planes)
         return out
 
 
@@ -770,8 +781,19 @@ class PackedConvX:
         d.tap_packed = 1 if self.taps else 0
         return d
 
+    @staticmethod
+    def _set_planes(d, planes, split_from, rows):
+        """ABI 8: output channels from `split_from` on go to `planes` ([3, rows, Cout - split_from] bf16: hi / mid / lo, their sum is
+        the fp32 result bit for bit) instead of to the fp32 rows"""
+        _chk(planes, "planes", torch.bfloat16)
+        if planes.dim() != 3 or planes.shape[0] != 3 or planes.shape[1] != rows or planes.shape[2] != d.Cout - split_from:
+            raise ValueError("planes must be [3, %d, %d] bf16, got %s" % (rows, d.Cout - split_from, tuple(planes.shape)))
+        d.dst2, d.dst2_ld, d.dst2_coff = planes.data_ptr(), planes.shape[2], 0
+        d.dst2_split_from, d.dst2_plane_stride = split_from, planes.shape[1] * planes.shape[2]
+
     def __call__(self, sources, out=None, out_dtype=None, out_coff=0, residual=None, res_coff=0, act=ACT_NONE,
-                 slope=0.0, out2=None, tile=0, out_nchw=False):
+                 slope=0.0, out2=None, tile=0, out_nchw=False, planes=None, split_from=0):
+        """planes / split_from (fp32 results): see _set_planes -- the qkv Linear writes the attention's K / V operand planes"""
         if out_dtype is None:
             out_dtype = self.dtype
         srcs = [(s, 0) if isinstance(s, torch.Tensor) else s for s in sources]
@@ -785,6 +807,8 @@ class PackedConvX:
                    torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=dev))
         per_img = max(H * W * t.shape[3] * (4 if self.f32 else 2) for t, _ in srcs)
         if N > 1 and N * per_img >= (1 << 32) - 1:                 # 32-bit buffer resources: image chunks
+            if planes is not None:
+                raise ValueError("split planes: the batch spans >= 4 GiB (call in chunks)")
             step = max(1, ((1 << 32) - 2) // per_img)
             for n0 in range(0, N, step):
                 n1 = min(N, n0 + step)
@@ -793,6 +817,8 @@ class PackedConvX:
                      out2=None if out2 is None else out2[n0:n1], tile=tile, out_nchw=out_nchw)
             return out
         d = self._desc(srcs, out, out_coff, residual, res_coff, act, slope, out2, out_nchw)
+        if planes is not None:
+            self._set_planes(d, planes, split_from, N * Ho * Wo)
         d.tile = tile
         x3 = self.try_x3 and X3_ENABLED and self.f32 and not self.x3
         if tile == 0 and self.tune and N * Ho * Wo >= 2048:
@@ -811,7 +837,7 @@ class PackedConvX:
             if best and best >= X3_BASE and self._alt3() is not None:
                 try:
                     return self.alt3(srcs, out=out, out_dtype=out_dtype, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act,
-                                     slope=slope, out2=out2, tile=best - X3_BASE, out_nchw=out_nchw)
+                                     slope=slope, out2=out2, tile=best - X3_BASE, out_nchw=out_nchw, planes=planes, split_from=split_from)
                 except _L.HipError:                       # a neighbouring size class's tile that this shape rejects
                     best = 0
             d.tile = tile = (best or 0) if (best or 0) < X3_BASE else 0
@@ -967,7 +993,7 @@ class PackedLinear(PackedConv):
     def __init__(self, weight, bias, bk=None, precision="fp32"):
         super().__init__(weight, bias, [weight.shape[1]], bk=bk, precision=precision)
 
-    def __call__(self, x, out=None, residual=None, act=ACT_NONE, slope=0.0, tile=0):
+    def __call__(self, x, out=None, residual=None, act=ACT_NONE, slope=0.0, tile=0, kv_planes=None):
         _chk(x, "x")
         rows = x.numel() // x.shape[-1]
         x4 = x.view(rows, 1, 1, x.shape[-1])
@@ -975,7 +1001,7 @@ class PackedLinear(PackedConv):
             out = torch.empty((rows, self.Cout), dtype=torch.float32, device=x.device)
         o4 = out.view(rows, 1, 1, out.shape[-1])
         r4 = None if residual is None else residual.view(rows, 1, 1, residual.shape[-1])
-        super().__call__([x4], out=o4, residual=r4, act=act, slope=slope, tile=tile)
+        super().__call__([x4], out=o4, residual=r4, act=act, slope=slope, tile=tile, kv_planes=kv_planes)
         return out
 
 

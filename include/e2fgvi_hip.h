@@ -338,6 +338,15 @@ typedef struct {
     int32_t out_grid, pad_left;
     int32_t out_sy, out_sx, out_py, out_px, out_H, out_W;
     int32_t res_bcast;
+    /* ABI version 8 (zero = the behaviour of version 7).  dst2_plane_stride > 0 (fp32 dst, groups = 1, no NCHW / scatter):
+     * output channels co >= dst2_split_from are NOT stored to dst; their EXACT three-way bf16 split (hi + mid + lo == the fp32
+     * result, csrc/common.h e2_split2) goes to dst2 instead -- plane pl (0 = hi, 1 = mid, 2 = lo) of row m, channel co at
+     * dst2[pl * dst2_plane_stride + m * dst2_ld + dst2_coff + co - dst2_split_from] (elements) -- and channels below
+     * dst2_split_from go to dst only.  The qkv Linear of a transformer block writes the K / V operand planes of the
+     * split-operand attention (e2fgvi_focal_attention_x3) this way: no separate e2fgvi_split3_kv pass over the rows
+     * (tfocal_transformer.py:221-223: q = columns 0-511, k = 512-1023, v = 1024-1535). */
+    int32_t dst2_split_from;
+    int64_t dst2_plane_stride;
 } e2fgvi_convx_desc;
 
 int e2fgvi_conv2d_bf16x(const e2fgvi_convx_desc* d, void* stream);

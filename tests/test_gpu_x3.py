@@ -377,3 +377,44 @@ def test_mdcn_x3(dev):
     first = out.clone()
     bad = sum(int(not torch.equal(layer(srcs, nhwc(final).to(dev)), first)) for _ in range(100))
     assert bad == 0, "%d of 100 launches differ" % bad
+
+
+@pytest.mark.parametrize("rows", [7360, 256, 1000])
+def test_qkv_epilogue_writes_the_attention_planes(dev, rows):
+    """ABI 8 (round 5): the split-operand GEMM's epilogue writes the K / V columns of a qkv Linear as the three exact bf16 planes
+    the split-operand attention reads -- bit for bit what e2fgvi_split3_kv makes of the fp32 rows of the same kernel -- and leaves
+    the Q columns in the fp32 rows; every tile shape, row counts with and without a ragged last tile; then through
+    PackedLinear's kv_planes (the engine's call), whichever kernel the table hands it."""
+    from e2fgvi_amd import lib as L, ops
+    g = _gen(4100 + rows)
+    w = (torch.randn(1536, 512, generator=g) * 0.05).to(dev)
+    b = torch.randn(1536, generator=g).to(dev)
+    x = torch.randn(rows, 512, generator=g).to(dev)
+    layer = ops.PackedConvX(w, b, [512], dtype=torch.float32, x3=True)
+    x4 = x.view(rows, 1, 1, 512)
+    ran = 0
+    for tile in (1, 2, 4, 5, 6, 7):
+        full = torch.empty(rows, 1, 1, 1536, device=dev)
+        try:
+            layer([x4], out=full, tile=tile)
+        except L.HipError:
+            continue
+        want = ops.split3_kv(full.view(rows, 1536))
+        out = torch.full((rows, 1, 1, 1536), float("nan"), device=dev)
+        planes = torch.zeros(3, rows, 1024, dtype=torch.bfloat16, device=dev)
+        layer([x4], out=out, tile=tile, planes=planes, split_from=512)
+        assert torch.equal(planes, want), "tile %d: planes differ from split3_kv of the fp32 rows" % tile
+        assert torch.equal(out[..., :512], full[..., :512]), "tile %d: Q columns" % tile
+        assert torch.isnan(out[..., 512:]).all(), "tile %d: the fp32 K / V columns must not be stored" % tile
+        # the planes sum to the fp32 value
+        assert torch.equal(planes.double().sum(0), full.view(rows, 1536)[:, 512:].double())
+        ran += 1
+    assert ran >= 4
+    lin = ops.PackedLinear(w, b)
+    lin.tune = lin.try_x3 = True
+    planes = torch.zeros(3, rows, 1024, dtype=torch.bfloat16, device=dev)
+    y = lin(x, kv_planes=planes)
+    ref = lin(x)
+    assert torch.equal(y[:, :512], ref[:, :512]) and torch.equal(planes, ops.split3_kv(ref))
+    with pytest.raises(Exception):
+        layer([x4], out=out, planes=planes[:, :, :1000].contiguous(), split_from=512)

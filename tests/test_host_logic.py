@@ -100,7 +100,7 @@ def test_abi_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().e2fgvi_abi_version() == 7
+    assert lib.load().e2fgvi_abi_version() == 8
 
 
 def test_packing_size_functions_and_argument_checks_run_without_a_gpu():
