@@ -434,7 +434,11 @@ class Engine(BF16Path):
             # written by the qkv GEMM's epilogue when the split-operand GEMM runs it (round 5: no separate pass over the rows, and
             # the fp32 K / V columns are never stored), by e2fgvi_split3_kv otherwise (ops.PackedConv.__call__, kv_planes)
             planes = torch.empty((3, rows + prow, 1024), dtype=torch.bfloat16, device=x.device)
-            both = blk["qkv"](nbuf, kv_planes=planes)
+            if ops.KV_EPILOGUE:
+                both = blk["qkv"](nbuf, kv_planes=planes)
+            else:
+                both = blk["qkv"](nbuf)
+                ops.split3_kv(both, out=planes)
             att = ops.focal_attention_x3(both[:rows], planes, tab, nk, b, t, fh, fw)
         else:
             both = blk["qkv"](nbuf)

@@ -75,6 +75,10 @@ W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.
 # by tests/test_gpu_hazards.py (every selectable kernel beside device copies, bit-equal to the unaccompanied launch).
 # E2FGVI_W3_WIDE=0 switches the kernel off (A/B runs).
 WIDE_X3_OK = os.environ.get("E2FGVI_W3_WIDE", "1") != "0"
+# A/B switches (measurements): E2FGVI_KV_EPILOGUE=0 -- the attention's K / V planes by a separate e2fgvi_split3_kv pass instead of
+# the qkv GEMM's epilogue; E2FGVI_DCN_TILE=<code> -- the deformable conv's tile (0 = the library's rule)
+KV_EPILOGUE = os.environ.get("E2FGVI_KV_EPILOGUE", "1") != "0"
+DCN_TILE = int(os.environ.get("E2FGVI_DCN_TILE", "0") or 0)
 W3_WIDE = 6064
 W3_WIDE_FALLBACK = 164
 _TUNED = {}      # (layer geometry, input size class) -> tile code; shared by all layers of the same geometry (the 8 blocks)
@@ -561,7 +565,10 @@ class PackedConv:
                     if mine is None:
                         d.tile = best
                         mine = time_mine()
-                    res = self.alt3._time_tiles(self.alt3._desc(srcs, out, out_coff, residual, res_coff, act, slope, None, out_nchw))
+                    d3 = self.alt3._desc(srcs, out, out_coff, residual, res_coff, act, slope, None, out_nchw)
+                    if kv_planes is not None:            # timed as it will run: with the K / V planes written by the epilogue
+                        self.alt3._set_planes(d3, kv_planes, self.Cout - kv_planes.shape[2], N * Ho * Wo)
+                    res = self.alt3._time_tiles(d3)
                     if res and min(res.values()) < X3_MARGIN * mine:
                         best, mine = X3_BASE + min(res, key=res.get), min(res.values())
                 if x3 and use_wino and self._wino_x3() is not None:
@@ -1133,7 +1140,7 @@ class PackedDcn:
         if out is None:
             out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=sources[0].device)
         _chk_any(out, "out")
-        d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile, _dt(out)
+        d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile or DCN_TILE, _dt(out)
         d.mfma_dtype = 2 if self.mfma_x3 else (_L.DT_BF16 if self.mfma_bf16 else _L.DT_F32)
         if _L.TRACE is not None:
             m = N * Ho * Wo * self.Cout * self.C * K
