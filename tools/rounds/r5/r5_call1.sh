@@ -2,7 +2,7 @@
 # Round 5, first GPU call: (1) probe of the cheaper exact split, (2) the C4 aggressor tests, (3) the kernel table re-timed without
 # round 4's per-layer gate, (4) the whole GPU suite with it, (5) the default bench line, (6) rocprof summaries + PMC traffic of the
 # fp32 headline and of configs[4] (e2fgvi_hq 1080x1944 T=20 bf16), (7) per-layer tables.  Every step has its own timeout.
-#   gpurun --timeout 1800 -- 'bash tools/r5_call1.sh'      -> gpurun_out/r5a/
+#   gpurun --timeout 1800 -- 'bash tools/rounds/r5/r5_call1.sh'      -> gpurun_out/r5a/
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd $REPO; OUT=gpurun_out/r5a; mkdir -p $OUT
 T0=$(date +%s); lap() { echo "== $1: $(( $(date +%s) - T0 )) s"; }
 (timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe/split_probe.hip -o /tmp/split_probe 2>/dev/null && timeout 60 /tmp/split_probe) > $OUT/split_probe.txt 2>&1; tail -3 $OUT/split_probe.txt; lap probe

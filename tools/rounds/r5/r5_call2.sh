@@ -2,7 +2,7 @@
 # Round 5, second GPU call: the round-to-nearest split (csrc/common.h e2_split2: v_cvt_pk_bf16_f32 + v_dot2c_f32_bf16) against the
 # truncating one of rounds 3-4 -- exactness probe on the chip, the split-operand kernel tests, same-box A/B of the headline and of
 # single layers.  CPU, before the call:  python -c 'from e2fgvi_amd import build; build.build_variant("trunc", "-DE2_SPLIT_RNE=0")'
-#   gpurun --timeout 900 -- 'bash tools/r5_call2.sh'      -> gpurun_out/r5b/
+#   gpurun --timeout 900 -- 'bash tools/rounds/r5/r5_call2.sh'      -> gpurun_out/r5b/
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd $REPO; OUT=gpurun_out/r5b; mkdir -p $OUT
 T0=$(date +%s); lap() { echo "== $1: $(( $(date +%s) - T0 )) s"; }
 for O in 1 0; do
