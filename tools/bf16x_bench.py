@@ -19,7 +19,7 @@ LAYERS = [("encoder.10", 10, 180, 324, [128, 192], 2, 512, 3, 1, 1), ("encoder.8
           ("sc", 64800, 1, 1, [512], 1, 6272, 1, 1, 0),
           ("spynet.5.1", 18, 192, 352, [32], 1, 64, 7, 1, 3), ("spynet.5.2", 18, 192, 352, [64], 1, 32, 7, 1, 3),
           ("spynet.5.3", 18, 192, 352, [32], 1, 16, 7, 1, 3), ("decoder.0", 10, 360, 648, [128], 1, 128, 3, 1, 1)]
-only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None
+only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 and sys.argv[1] else None
 tiles = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 6, 21, 26]
 for name, N, H, W, cpg, groups, Cout, k, s, p in LAYERS:
     if only and name not in only:
