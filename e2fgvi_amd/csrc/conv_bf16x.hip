@@ -24,8 +24,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int V> struct XIC { static constexpr int value = V; };
-
 struct ConvXParams {
     const void* src[E2FGVI_MAX_SRC];
     int ld[E2FGVI_MAX_SRC];
@@ -100,17 +98,9 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8&
 // MODE 1's (fp32 rows, same DMA, same swizzle): a lane reads its 8 consecutive channels as two 16-byte chunks and splits
 // them in registers (44 VALU per fragment, shared by the 6 x TN MFMAs it feeds); the weights are split once, at packing
 // time, into three bf16 planes: a B stage is [3 planes][4 k-octets][BN][8 bf16].
-// PIPE (round 5, bf16 operands, plain tiles): the weights do not pass through LDS -- the packed layout [K-step][8 k-octets][Npad][8]
-// is the MFMA's B operand per lane, so every wave fetches the fragments of its own column tiles straight into registers, TWO
-// K-steps ahead (two register sets) -- and an LDS stage is the A tile alone, which makes room for THREE stages with the A tile
-// fetched two K-steps ahead as well while two workgroups still fit a CU.  Why: a K-step of a 128 x 128 tile is ~500 MFMA cycles
-// per wave, less than the L2 latency of the stage that was issued at its top -- with two stages every step ends in a wait for
-// its own prefetch (the second resident workgroup covers half of it); round 2's three-stage variant had to give up that second
-// workgroup for the LDS space (48 KB per stage with the weights in it).
-template <int BM, int BN, int WGM, int WGN, bool S3, int MODE, bool PIPE = false>
+template <int BM, int BN, int WGM, int WGN, bool S3, int MODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
-    static_assert(!PIPE || (MODE == 0 && !S3), "the pipelined variant: bf16 operands, plain tiles");
     constexpr bool F32 = MODE == 1, X3 = MODE == 2;
     constexpr int NT = 64 * WGM * WGN;
     constexpr int ESZ = MODE ? 4 : 2;                           // activation element size
@@ -129,9 +119,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr int TNH = TN / ES, CNH = CN / ES, LDE = CNH + 4;  // a wave's epilogue region: R rows of LDE floats
     constexpr int EPI = WGM * WGN * R * LDE * 4;
     static_assert(TN % ES == 0 && EPI <= 160 * 1024, "epilogue region");
-    constexpr int RING = PIPE ? 3 * A_BYTES : 2 * (A_BYTES + B_BYTES);      // A stages first, then B stages (PIPE: three A stages, no B)
-    constexpr int SMEM = RING > EPI ? RING : EPI;
-    static_assert(!PIPE || !A_PART, "the pipelined variant counts its DMA instructions: whole iterations only");
+    constexpr int SMEM = 2 * (A_BYTES + B_BYTES) > EPI ? 2 * (A_BYTES + B_BYTES) : EPI;   // A stages first, then B stages
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * B_CH) % 64 == 0 && SMEM <= 160 * 1024, "tile");
 
@@ -183,36 +171,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     }
     const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes, p.wgroup_bytes);
     const unsigned b_step = (unsigned)B_CH * (unsigned)p.Npad * 16u;   // packed-weight bytes per K-step
-    // PIPE: the lane's B fragment of (k-step kk, column tile tn) = 16 bytes at octet 2 kk + half, column n0 + (wn TN + tn) 32 + (lane & 31);
-    // one lane-dependent offset, the rest in the load's scalar offset (a column tile entirely past Npad re-reads tile 0: never stored)
-    constexpr int NB = 4 * TN;                                         // B loads per wave and K-step
-    f32x4 bfr[PIPE ? 2 : 1][PIPE ? 4 : 1][PIPE ? TN : 1];   // (asm-issued loads: hipcc counts neither them nor any wait for them)
-    const unsigned bp_lane = (unsigned)(((lane >> 5) * p.Npad + n0 + (lane & 31)) * 16);
-    unsigned bp_tn[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-        bp_tn[tn] = (unsigned)__builtin_amdgcn_readfirstlane((n0 + (wn * TN + tn) * 32 < p.Npad) ? (wn * TN + tn) * 32 * 16 : 0);
-    const unsigned bp_oct2 = 2u * (unsigned)p.Npad * 16u;
-    typedef int bp_i32x4 __attribute__((ext_vector_type(4)));
-    bp_i32x4 bp_rsrc;
-    {
-        const unsigned long long wb_ = (unsigned long long)(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes);
-        bp_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)wb_);
-        bp_rsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(wb_ >> 32) & 0xFFFFu));
-        bp_rsrc[2] = __builtin_amdgcn_readfirstlane((int)p.wgroup_bytes);
-        bp_rsrc[3] = 0x00020000;
-    }
-    // (macros, not lambdas: a generic lambda that captures the walk's mutable state by reference made hipcc keep the closure -- and
-    //  with it the source parameters -- in scratch memory, and wrap every load in a waterfall loop)
-#define E2_LOAD_BP(STEP_, SET_)                                                                                                   \
-    {                                                                                                                             \
-        const unsigned vo_ = bp_lane + (unsigned)(STEP_) * b_step;                                                                \
-        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                                       \
-            _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_)                                                                  \
-                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"                                               \
-                             : "=v"(bfr[PIPE ? (SET_) : 0][PIPE ? kk_ : 0][PIPE ? tn_ : 0])                                       \
-                             : "v"(vo_), "s"(bp_rsrc), "s"((unsigned)kk_ * bp_oct2 + bp_tn[tn_]) : "memory");                     \
-    }
 
     // walk of the K-steps: tap (ky, kx) -> source s -> 64-channel block c0.  The per-source parameters are read from the
     // kernel arguments ONCE (indexing the argument arrays per step costs dependent scalar loads and a wait in the loop).
@@ -396,87 +354,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         }
         }
     };
-    if constexpr (PIPE) {
-        // one K-step (64 channels) of the pipelined variant: A from the LDS stage at ST_, B from register set SET_
-        int ap_rd[TM], ap_key[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            ap_rd[tm] = a_row[tm] * 128;
-            ap_key[tm] = (a_row[tm] >> 1) & 7;
-        }
-#define E2_COMPUTE_P(ST_, SET_)                                                                                                   \
-    _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                                         \
-        bf16x8 a_[TM];                                                                                                            \
-        _Pragma("unroll") for (int tm_ = 0; tm_ < TM; ++tm_)                                                                      \
-            a_[tm_] = *reinterpret_cast<const bf16x8*>((ST_) + ap_rd[tm_] + (((2 * kk_ + h) ^ ap_key[tm_]) << 4));                \
-        _Pragma("unroll") for (int tm_ = 0; tm_ < TM; ++tm_)                                                                      \
-            _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_)                                                                  \
-                acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[tm_], __builtin_bit_cast(bf16x8, bfr[SET_][kk_][tn_]), \
-                                                                        acc[tm_][tn_], 0, 0, 0);                                  \
-    }
-        // step s: issue A(s + 2) -> stage (s + 2) % 3 (its readers passed the last barrier); claim B(s) (explicit wait: the B loads are
-        // asm-issued, the compiler counts neither them nor a wait for them -- with compiler-visible loads its conservative waits at
-        // the loop's back edge drained the whole queue, prefetches included, before the first MFMA); MFMAs of step s; B(s + 2) into
-        // the set just read (an MFMA in flight has read its B operand long before a load can return); then A(s + 1) must have
-        // landed: the loads issued after it are B(s + 1), A(s + 2), B(s + 2) = 2 NB + A_IT instructions of this wave (loads return
-        // in order) -- the last two steps simply wait for everything.
-#define E2_STEP_P(STEP_, SET_)                                                                                                    \
-    {                                                                                                                             \
-        const bool more2_ = (STEP_) + 2 < p.nsteps;                                                                               \
-        if (more2_) {                                                                                                             \
-            if (advance()) retarget();                                                                                            \
-            issue_a(ast == 0 ? 2 : ast - 1);                                                                                      \
-        }                                                                                                                         \
-        /* B(s) was issued two steps ago; since then: A(s + 1), B(s + 1) and -- just above -- A(s + 2) */                          \
-        if (more2_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A_IT + NB) : "memory");                                          \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                     \
-        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                                       \
-            _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_) asm volatile("" : "+v"(bfr[SET_][kk_][tn_]));                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                        \
-        E2_COMPUTE_P(smem + ast * A_BYTES, SET_)                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                        \
-        if (more2_) {                                                                                                             \
-            E2_LOAD_BP((STEP_) + 2, SET_)                                                                                         \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + A_IT) : "memory");                                                  \
-        } else {                                                                                                                  \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
-        }                                                                                                                         \
-        /* a raw barrier: __syncthreads() carries a fence for which hipcc -- it tracks the LDS-DMA pieces as pending LDS writes -- \
-           drains the whole vector-memory queue, prefetches included.  What the barrier has to order is covered explicitly: this    \
-           wave's pieces of stage s + 1 by the counted wait above, its own LDS reads of stage s by the MFMAs that consumed them */    \
-        __builtin_amdgcn_s_barrier();                                                                                             \
-        ast = ast == 2 ? 0 : ast + 1;                                                                                             \
-    }
-        // prologue: A of steps 0 and 1 into stages 0 and 1, B of steps 0 and 1 into the two register sets; everything waited for
-        issue_a(0);
-        E2_LOAD_BP(0, 0)
-        if (p.nsteps > 1) {
-            if (advance()) retarget();
-            issue_a(1);
-            E2_LOAD_BP(1, 1)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int ast = 0;                                               // LDS stage of the current step (step % 3)
-        for (int step = 0; step < p.nsteps; step += 2) {
-            E2_STEP_P(step, 0)
-            if (step + 1 < p.nsteps) E2_STEP_P(step + 1, 1)
-        }
-#undef E2_STEP_P
-#undef E2_COMPUTE_P
-    }
-#undef E2_LOAD_BP
     const bool tap_packed = !S3 && p.tp_cq != 0;          // its first A stage is issued by the packed branch below
-    if constexpr (!PIPE) {
     if (!tap_packed) issue_a(0);
     issue_b(0, 0);
     if (!tap_packed) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    }
-    if constexpr (PIPE) {
-    } else if constexpr (!S3) {
+    if constexpr (!S3) {
         if (p.tp_cq) {
             // Tap-packed K-steps: a source of fewer than 64 channels (bf16; fp32: 32 channels per step, 4 per chunk -- the same
             // bytes) fills only cq = cpg / 8 of the 8 chunks of a K-step, so the
@@ -880,20 +765,6 @@ __global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned
     o[2 * plane] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
 }
 
-// the pipelined variant (weights in registers, three A stages): bf16 operands, plain tiles, no tap-packed K-steps
-template <int BM, int BN, int WGM, int WGN>
-int launch_xp(ConvXParams& p, int groups, hipStream_t st, int mode) {
-    if (mode != 0 || p.tp_cq != 0) {
-        e2fgvi_set_error("conv2d_bf16x: the pipelined tiles (51..56) take bf16 operands and no tap-packed weights");
-        return E2FGVI_EUNSUP;
-    }
-    p.tilesM = cdiv(p.M, BM);
-    p.tilesN = cdiv(p.Cout_g, BN);
-    hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, 0, true>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
-    E2_LAUNCH_CHECK("conv2d_x (pipelined)");
-    return 0;
-}
-
 template <int BM, int BN, int WGM, int WGN, bool S3>
 int launch_x(ConvXParams& p, int groups, hipStream_t st, int mode = 0) {
     p.tilesM = cdiv(p.M, BM);
@@ -1183,12 +1054,6 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, mode);
         case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, mode);
         case 18: return launch_x<256, 64, 4, 2, true>(p, d->groups, st, mode);       // all of their traffic, a third of it here
-        // 50 + tile: the same block shapes pipelined (round 5: weights straight into registers, three A stages, everything two K-steps ahead)
-        case 51: return launch_xp<128, 128, 2, 2>(p, d->groups, st, mode);
-        case 52: return launch_xp<128, 64, 2, 2>(p, d->groups, st, mode);
-        case 54: return launch_xp<64, 128, 2, 2>(p, d->groups, st, mode);
-        case 55: return launch_xp<64, 64, 2, 2>(p, d->groups, st, mode);
-        case 56: return launch_xp<256, 128, 4, 2>(p, d->groups, st, mode);
         default: break;
     }
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);
