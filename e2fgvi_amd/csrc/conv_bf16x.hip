@@ -1100,6 +1100,9 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 5: return launch_x<64, 64, 2, 2, false>(p, d->groups, st, mode);
         case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, mode);
         case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
+        // the same block on FOUR waves of 128 x 128 (round 5): 4 x 4 accumulators per wave (256 registers: the compiler puts them in
+        // the accumulation registers), 8 operand reads per 16 MFMAs instead of 6 per 8 -- two thirds of tile 7's LDS read traffic
+        case 8: return launch_x<256, 256, 2, 2, false>(p, d->groups, st, mode);
         // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
         case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, mode);
         case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, mode);
@@ -1107,6 +1110,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 14: return launch_x<64, 128, 2, 2, true>(p, d->groups, st, mode);
         case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, mode);
         case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, mode);
+        case 19: return launch_x<256, 256, 2, 2, true>(p, d->groups, st, mode);
         case 18: return launch_x<256, 64, 4, 2, true>(p, d->groups, st, mode);       // all of their traffic, a third of it here
         // 90 + tile: the same block shapes with three LDS stages (two in flight), where that costs no resident workgroup
         case 92: return launch_x3s<128, 64, 2, 2>(p, d->groups, st, mode);
