@@ -98,13 +98,9 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8&
 // MODE 1's (fp32 rows, same DMA, same swizzle): a lane reads its 8 consecutive channels as two 16-byte chunks and splits
 // them in registers (44 VALU per fragment, shared by the 6 x TN MFMAs it feeds); the weights are split once, at packing
 // time, into three bf16 planes: a B stage is [3 planes][4 k-octets][BN][8 bf16].
-// NST = 3 (round 5; plain tiles whose three stages fit the LDS without giving up a resident workgroup: 256x128, 64x128, 128x64,
-// 64x64): the stage of step s + 2 is issued at the top of step s, so two stages are in flight while one is multiplied -- the
-// kernel's operand streams are bound by bytes in flight x latency (~64 KB per CU at ~1.5 us), not by the L2's bandwidth.
-template <int BM, int BN, int WGM, int WGN, bool S3, int MODE, int NST = 2>
+template <int BM, int BN, int WGM, int WGN, bool S3, int MODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
-    static_assert(NST == 2 || (NST == 3 && !S3), "two or three stages; the row-shift tiles have two");
     constexpr bool F32 = MODE == 1, X3 = MODE == 2;
     constexpr int NT = 64 * WGM * WGN;
     constexpr int ESZ = MODE ? 4 : 2;                           // activation element size
@@ -123,8 +119,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr int TNH = TN / ES, CNH = CN / ES, LDE = CNH + 4;  // a wave's epilogue region: R rows of LDE floats
     constexpr int EPI = WGM * WGN * R * LDE * 4;
     static_assert(TN % ES == 0 && EPI <= 160 * 1024, "epilogue region");
-    constexpr int SMEM = NST * (A_BYTES + B_BYTES) > EPI ? NST * (A_BYTES + B_BYTES) : EPI;   // A stages first, then B stages
-    static_assert(NST == 2 || (!A_PART && !B_PART), "three stages: the waits count whole DMA iterations");
+    constexpr int SMEM = 2 * (A_BYTES + B_BYTES) > EPI ? 2 * (A_BYTES + B_BYTES) : EPI;   // A stages first, then B stages
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(TM >= 1 && TN >= 1 && (BM * 8) % NT == 0 && (BN * B_CH) % 64 == 0 && SMEM <= 160 * 1024, "tile");
 
@@ -209,7 +204,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         }
     };
     retarget();
-    unsigned char* const smem_b = smem + NST * A_BYTES;
+    unsigned char* const smem_b = smem + 2 * A_BYTES;
     // The whole next stage is issued BEFORE the MFMAs of the current one.  Spreading the pieces between the four MFMA groups
     // of the step (a quarter after each group's operand reads) was measured 5-10 % slower on every layer: the loads are
     // latency-exposed, the earliest possible issue wins (profiles/r02_bf16x_conv_microbench.txt).
@@ -360,48 +355,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         }
     };
     const bool tap_packed = !S3 && p.tp_cq != 0;          // its first A stage is issued by the packed branch below
-    if constexpr (NST == 3) {
-        // three stages (the launcher sends tap-packed layers to the two-stage tiles): stages 0 and 1 up front, then per step: issue
-        // stage s + 2 (its slot's readers passed the last barrier), multiply stage s, wait until stage s + 1 has landed -- all but the
-        // A_IT + B_IT pieces just issued (loads return in order) -- and a RAW barrier: __syncthreads() carries a fence for which hipcc,
-        // which tracks the LDS-DMA pieces as pending LDS writes, drains the whole queue, prefetch included.  What the barrier has to
-        // order is covered explicitly: this wave's pieces by the counted wait, its LDS reads of stage s by the MFMAs that used them.
-        issue_a(0);
-        issue_b(0, 0);
-        if (p.nsteps > 1) {
-            if (advance()) retarget();
-            issue_a(1);
-            issue_b(1, 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_IT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;
-        for (int step = 0; step < p.nsteps; ++step) {
-            const bool more2 = step + 2 < p.nsteps;
-            const int nxt2 = cur == 0 ? 2 : cur - 1;
-            if (more2) {
-                if (advance()) retarget();
-                issue_a(nxt2);
-                issue_b(nxt2, step + 2);
-            }
-            compute(smem + cur * A_BYTES, smem_b + cur * B_BYTES, 0);
-            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_IT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur = cur == 2 ? 0 : cur + 1;
-        }
-    } else {
     if (!tap_packed) issue_a(0);
     issue_b(0, 0);
     if (!tap_packed) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    }
-    if constexpr (NST == 3) {
-    } else if constexpr (!S3) {
+    if constexpr (!S3) {
         if (p.tp_cq) {
             // Tap-packed K-steps: a source of fewer than 64 channels (bf16; fp32: 32 channels per step, 4 per chunk -- the same
             // bytes) fills only cq = cpg / 8 of the 8 chunks of a K-step, so the
@@ -805,20 +765,6 @@ __global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned
     o[2 * plane] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
 }
 
-// the three-stage tiles (90 + tile): bf16 operands, no tap-packed K-steps
-template <int BM, int BN, int WGM, int WGN>
-int launch_x3s(ConvXParams& p, int groups, hipStream_t st, int mode) {
-    if (mode != 0 || p.tp_cq != 0) {
-        e2fgvi_set_error("conv2d_bf16x: the three-stage tiles (92..96) take bf16 operands and no tap-packed weights");
-        return E2FGVI_EUNSUP;
-    }
-    p.tilesM = cdiv(p.M, BM);
-    p.tilesN = cdiv(p.Cout_g, BN);
-    hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, 0, 3>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
-    E2_LAUNCH_CHECK("conv2d_x (three stages)");
-    return 0;
-}
-
 template <int BM, int BN, int WGM, int WGN, bool S3>
 int launch_x(ConvXParams& p, int groups, hipStream_t st, int mode = 0) {
     p.tilesM = cdiv(p.M, BM);
@@ -1100,9 +1046,6 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 5: return launch_x<64, 64, 2, 2, false>(p, d->groups, st, mode);
         case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, mode);
         case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
-        // the same block on FOUR waves of 128 x 128 (round 5): 4 x 4 accumulators per wave (256 registers: the compiler puts them in
-        // the accumulation registers), 8 operand reads per 16 MFMAs instead of 6 per 8 -- two thirds of tile 7's LDS read traffic
-        case 8: return launch_x<256, 256, 2, 2, false>(p, d->groups, st, mode);
         // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
         case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, mode);
         case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, mode);
@@ -1110,13 +1053,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 14: return launch_x<64, 128, 2, 2, true>(p, d->groups, st, mode);
         case 16: return launch_x<256, 128, 4, 2, true>(p, d->groups, st, mode);
         case 17: return launch_x<256, 256, 4, 2, true>(p, d->groups, st, mode);
-        case 19: return launch_x<256, 256, 2, 2, true>(p, d->groups, st, mode);
         case 18: return launch_x<256, 64, 4, 2, true>(p, d->groups, st, mode);       // all of their traffic, a third of it here
-        // 90 + tile: the same block shapes with three LDS stages (two in flight), where that costs no resident workgroup
-        case 92: return launch_x3s<128, 64, 2, 2>(p, d->groups, st, mode);
-        case 94: return launch_x3s<64, 128, 2, 2>(p, d->groups, st, mode);
-        case 95: return launch_x3s<64, 64, 2, 2>(p, d->groups, st, mode);
-        case 96: return launch_x3s<256, 128, 4, 2>(p, d->groups, st, mode);
         default: break;
     }
     e2fgvi_set_error("conv2d_bf16x: unknown tile %d", tile);

@@ -53,10 +53,8 @@ _W4_FORCE = int(os.environ.get("E2FGVI_WINO4", "0") or 0)
 _W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
 # bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles; tile codes +10
 # are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
-XTUNE_CANDIDATES = (1, 4, 6, 7, 8, 2, 5, 3)          # (8, 19: the 256x256 block on four waves of 128x128, round 5)
-XTUNE_ROWSHIFT = (11, 16, 17, 19, 12, 13, 18)
-# 90 + tile (round 5; bf16 operands, not tap-packed): the block shapes whose THREE LDS stages cost no resident workgroup
-XTUNE_3STAGE = (96, 94, 92, 95)
+XTUNE_CANDIDATES = (1, 4, 6, 7, 2, 5, 3)
+XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
 # fp32 layers on the bf16 matrix pipe by exact operand splitting (conv_bf16x.hip MODE 2, PackedConvX(x3=True)): a tuning
 # alternative of every fp32 layer that asks for it (PackedConv.try_x3 / PackedConvX.try_x3); taken when its best tile beats
 # the fp32 kernel of the call by more than X3_MARGIN.  Tile codes X3_BASE + tile in the decision table (clear of the Winograd
@@ -882,11 +880,10 @@ class PackedConvX:
             self._fn(C.byref(d), st)
         for _ in range(rounds * TUNE_REPS):
             rowshift = (self.KH, self.KW, self.stride, self.pad) == (3, 3, 1, 1) and not self.f32 and not self.taps
-            st3 = XTUNE_3STAGE if (not self.f32 and not self.taps and os.environ.get("E2FGVI_3STAGE", "1") != "0") else ()
-            for code in XTUNE_CANDIDATES + (XTUNE_ROWSHIFT if rowshift else ()) + st3:
+            for code in XTUNE_CANDIDATES + (XTUNE_ROWSHIFT if rowshift else ()):
                 if code % 10 == 3 and self.Cout // self.groups > 64:  # 32-wide tiles only make sense for narrow layers
                     continue
-                if code in (12, 18, 92, 95) and self.Cout // self.groups > 64:
+                if code in (12, 18) and self.Cout // self.groups > 64:
                     continue
                 d.tile = code
                 if self._fn(C.byref(d), st) != 0:
