@@ -31,6 +31,8 @@ TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on cs
 # (profiles/r03_fc2_conv_x3.txt) -- and is the default
 FC2_CONV = os.environ.get("E2FGVI_FC2_CONV_FP32", "1" if ops.X3_ENABLED else "0") != "0"
 WIN = (5, 9)
+# where the side stream (SPyNet) joins the main one: in front of encoder.layers.<JOIN_AT> (10: measured best, profiles/r05_join_position.txt)
+JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "10") or 10)
 
 
 def token_grid(h, w):
@@ -364,10 +366,12 @@ class Engine(BF16Path):
         x = e[2]([x], **lr)
         x0 = e[3]([x], **lr)
         x = e[4]([x0], **lr)
-        if join is not None:
+        if join is not None and JOIN_AT == 10:
             join()
         for k in (5, 6, 7, 8):
             x = e[k]([x0, x], **lr)
+            if join is not None and JOIN_AT == 2 * k + 2:       # (A/B: E2FGVI_JOIN_AT = 12 / 14 / 16 / 18: the join behind a later layer)
+                join()
         return x                                            # [b*t, h, w, 128]
 
     # ------------------------------------------------------------------ propagation
