@@ -31,8 +31,11 @@ TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on cs
 # (profiles/r03_fc2_conv_x3.txt) -- and is the default
 FC2_CONV = os.environ.get("E2FGVI_FC2_CONV_FP32", "1" if ops.X3_ENABLED else "0") != "0"
 WIN = (5, 9)
-# where the side stream (SPyNet) joins the main one: in front of encoder.layers.<JOIN_AT> (10: measured best, profiles/r05_join_position.txt)
-JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "10") or 10)
+# where the side stream (SPyNet) joins the main one: in front of encoder.layers.<JOIN_AT> (18 = behind the encoder).  Round 4 joined in
+# front of layer 10 (its wide-tile kernel was fenced to layers with the chip to themselves); with encoder.layers.2 / 6 / 8 on that
+# kernel the main stream reaches layer 10 before SPyNet has finished and waited there: 787.9 frames/s joined at 10, 801-808 joined
+# at 12 ... 18, best at 16 (same box, two runs each: profiles/r05_join_position.txt)
+JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "16") or 16)
 
 
 def token_grid(h, w):
@@ -355,8 +358,7 @@ class Engine(BF16Path):
 
     # ------------------------------------------------------------------ encoder
     def encode(self, frames, join=None):
-        """join: called in front of encoder.layers.10 (the fork's other branch, SPyNet, has ended by then on every benchmark
-        shape -- profiles/r04_timeline.txt -- so the wait is free and the widest layers, 10..16, have the chip to themselves)"""
+        """join: called in front of encoder.layers.<JOIN_AT> (default 16: the fork's other branch, SPyNet, overlaps layers 0 .. 14)"""
         b, t, c, H, W = frames.shape
         x = ops.nchw_to_nhwc(frames.reshape(b * t, c, H, W).contiguous(), ld=4)
         e = self.enc
