@@ -35,7 +35,9 @@ WIN = (5, 9)
 # front of layer 10 (its wide-tile kernel was fenced to layers with the chip to themselves); with encoder.layers.2 / 6 / 8 on that
 # kernel the main stream reaches layer 10 before SPyNet has finished and waited there: 787.9 frames/s joined at 10, 801-808 joined
 # at 12 ... 18, best at 16 (same box, two runs each: profiles/r05_join_position.txt)
-JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "16") or 16)
+# With several clips per forward the batched encoder layers fill the chip on their own and the early join is 0.5 % ahead (8 clips: 974.7
+# vs 969.5 frames/s), so: 16 at one clip, 10 otherwise; E2FGVI_JOIN_AT overrides both.
+JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "0") or 0)
 
 
 def token_grid(h, w):
@@ -358,7 +360,7 @@ class Engine(BF16Path):
 
     # ------------------------------------------------------------------ encoder
     def encode(self, frames, join=None):
-        """join: called in front of encoder.layers.<JOIN_AT> (default 16: the fork's other branch, SPyNet, overlaps layers 0 .. 14)"""
+        """join: called in front of encoder.layers.<join_at> (16 at one clip: the fork's other branch, SPyNet, overlaps layers 0 .. 14)"""
         b, t, c, H, W = frames.shape
         x = ops.nchw_to_nhwc(frames.reshape(b * t, c, H, W).contiguous(), ld=4)
         e = self.enc
@@ -368,11 +370,12 @@ class Engine(BF16Path):
         x = e[2]([x], **lr)
         x0 = e[3]([x], **lr)
         x = e[4]([x0], **lr)
-        if join is not None and JOIN_AT == 10:
+        join_at = JOIN_AT or (16 if b == 1 else 10)
+        if join is not None and join_at <= 10:
             join()
         for k in (5, 6, 7, 8):
             x = e[k]([x0, x], **lr)
-            if join is not None and JOIN_AT == 2 * k + 2:       # (A/B: E2FGVI_JOIN_AT = 12 / 14 / 16 / 18: the join behind a later layer)
+            if join is not None and (join_at == 2 * k + 2 or (k == 8 and join_at > 18)):
                 join()
         return x                                            # [b*t, h, w, 128]
 
