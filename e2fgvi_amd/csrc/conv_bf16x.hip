@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     constexpr bool B_PART = (BN * B_CH) % NT != 0;              // (X3, 32-column tile: whole waves drop out)
     constexpr int R = TM * 32, CN = TN * 32;                    // a wave's output block
     // the epilogue parks the accumulators in LDS, the whole block at once or (256x256 tile) in two column halves
-    constexpr int ES = (WGM * WGN * R * (CN + 4) * 4 > 150 * 1024) ? 2 : 1;
+    // (three passes of one column tile for the 64 x 96 wave blocks of the 256x192 tile)
+    constexpr int ES = (WGM * WGN * R * (CN + 4) * 4 <= 150 * 1024) ? 1 : (TN % 2 == 0 ? 2 : TN);
     constexpr int TNH = TN / ES, CNH = CN / ES, LDE = CNH + 4;  // a wave's epilogue region: R rows of LDE floats
     constexpr int EPI = WGM * WGN * R * LDE * 4;
     static_assert(TN % ES == 0 && EPI <= 160 * 1024, "epilogue region");
@@ -1046,6 +1047,7 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 5: return launch_x<64, 64, 2, 2, false>(p, d->groups, st, mode);
         case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, mode);
         case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
+        case 8: return launch_x<256, 192, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 96): N = 1536 in 8 column tiles (qkv: 232 instead of 174 workgroups)
         // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
         case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, mode);
         case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, mode);

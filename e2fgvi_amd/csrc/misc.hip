@@ -117,6 +117,23 @@ __global__ void nchw_small_to_nhwc8_kernel(const float* __restrict__ src, TO* __
     st4(dst + idx * 8 + 4, v[1]);
 }
 
+// ... and C <= 4 -> pixels of exactly 4 channels (the fp32 path's RGB + zero frames): one 16-byte (8-byte) store per pixel.  The
+// tiled transpose spent 65 us on ten 240x432 frames at the head of the main stream (profiles/r05_timeline.txt).
+template <typename TO>
+__global__ void nchw_small_to_nhwc4_kernel(const float* __restrict__ src, TO* __restrict__ dst, int C, int HW, float scale,
+                                           float shift, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    FlatIdx fi(idx, total);
+    const int p = fi.pop(HW);
+    const long long n = fi.rest();
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < C) v[c] = src[(n * C + c) * HW + p] * scale + shift;
+    st4(dst + idx * 4, v);
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int C, int HW) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z;
@@ -561,6 +578,17 @@ extern "C" int e2fgvi_nchw_to_nhwc_x(const float* src, void* dst, int32_t dst_dt
             hipLaunchKernelGGL(nchw_small_to_nhwc8_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src,
                                (float*)dst, C, H * W, scale, shift, total);
         E2_LAUNCH_CHECK("nchw_to_nhwc8");
+        return 0;
+    }
+    if (ld == 4 && C <= 4 && ((uintptr_t)dst & 15) == 0) {
+        const long long total = (long long)N * H * W;
+        if (dst_dtype == E2FGVI_BF16)
+            hipLaunchKernelGGL(nchw_small_to_nhwc4_kernel<__bf16>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src,
+                               (__bf16*)dst, C, H * W, scale, shift, total);
+        else
+            hipLaunchKernelGGL(nchw_small_to_nhwc4_kernel<float>, dim3(blocks_for(total)), dim3(NTH), 0, (hipStream_t)stream, src,
+                               (float*)dst, C, H * W, scale, shift, total);
+        E2_LAUNCH_CHECK("nchw_to_nhwc4");
         return 0;
     }
     dim3 grid(cdiv(H * W, 32), cdiv(ld, 32), N), block(32, 8);

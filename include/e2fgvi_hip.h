@@ -325,7 +325,9 @@ typedef struct {
     int32_t dst2_ld, dst2_coff;
     int32_t act;
     float slope;
-    int32_t tile;                      /* 0 = auto                                                          */
+    int32_t tile;                      /* 0 = auto; rows x columns per workgroup: 1 = 128x128, 2 = 128x64, 3 = 128x32,
+                                        * 4 = 64x128, 5 = 64x64, 6 = 256x128, 7 = 256x256, 8 = 256x192; + 10 (11-14, 16-18):
+                                        * 3x3 stride-1 layers with one A stage per kernel row (bf16 operands only)      */
     int32_t dst_nchw;                  /* 1: dst is plain fp32 NCHW [N,Cout,Ho,Wo] (dst_ld / dst_coff ignored)  */
     int32_t tap_packed;                /* 1: wpacked comes from e2fgvi_pack_conv_weight_bf16x_taps (ABI version 3)  */
     /* ABI version 6 (zero = the behaviour of version 5).  out_grid = 1: Ho x Wo are taken as given, `pad` rows lie above and

@@ -31,13 +31,13 @@ def _act(x, act, slope):
 
 # name, N, H, W, cpg (per source), groups, Cout, k, stride, pad, tiles
 CASES = [
-    ("3x3 128->128", 2, 20, 28, [128], 1, 128, 3, 1, 1, (0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 14, 16, 17, 18)),
+    ("3x3 128->128", 2, 20, 28, [128], 1, 128, 3, 1, 1, (0, 1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18)),
     ("3x3 concat 128+128+128+8 -> 128 (conv_offset.0)", 1, 12, 20, [128, 128, 128, 8], 1, 128, 3, 1, 1, (0, 1, 4, 11, 14, 16, 17)),
     ("1x1 64 -> 128, one K-step", 2, 9, 13, [64], 1, 128, 1, 1, 0, (1, 4, 6)),
-    ("1x1 128 -> 128, two K-steps", 2, 9, 13, [128], 1, 128, 1, 1, 0, (1, 6, 7)),
-    ("3x3 128 -> 432 (conv_offset.6)", 1, 10, 18, [128], 1, 432, 3, 1, 1, (0, 1, 5, 7, 11, 17)),
+    ("1x1 128 -> 128, two K-steps", 2, 9, 13, [128], 1, 128, 1, 1, 0, (1, 6, 7, 8)),
+    ("3x3 128 -> 432 (conv_offset.6)", 1, 10, 18, [128], 1, 432, 3, 1, 1, (0, 1, 5, 7, 8, 11, 17)),
     ("3x3 groups 8, 32+48 -> 256 (encoder.14)", 2, 10, 12, [32, 48], 8, 256, 3, 1, 1, (0, 3, 5, 12, 13, 18)),
-    ("3x3 groups 2, 128+192 -> 512 (encoder.10)", 1, 12, 12, [128, 192], 2, 512, 3, 1, 1, (0, 1, 7, 11, 17)),
+    ("3x3 groups 2, 128+192 -> 512 (encoder.10)", 1, 12, 12, [128, 192], 2, 512, 3, 1, 1, (0, 1, 7, 8, 11, 17)),
     ("3x3 stride 2, 8 -> 64 (encoder.0)", 2, 24, 40, [8], 1, 64, 3, 2, 1, (0, 2)),
     ("3x3 stride 2, 64 -> 128", 1, 22, 30, [64], 1, 128, 3, 2, 1, (0, 1)),
     ("7x7 stride 3 pad 3, 128 -> 512 (soft split)", 2, 30, 54, [128], 1, 512, 7, 3, 3, (0, 1)),

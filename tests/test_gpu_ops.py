@@ -366,6 +366,13 @@ def test_layout_roundtrip(dev):
     assert_close(y.cpu(), ref, 1e-7, "nchw_to_nhwc")
     z = ops.nhwc_to_nchw(y, channels=37)
     assert_close(z.cpu(), x * 0.5 + 0.25, 1e-7, "nhwc_to_nchw")
+    # frames: C <= 4 -> pixels of 4 channels (the fp32 path's input), C <= 8 -> pixels of 8 (the bf16 path's); one thread per pixel
+    for ld, dt in ((4, torch.float32), (4, torch.bfloat16), (8, torch.float32)):
+        for c in (3, 4, 1):
+            fr = torch.randn(3, c, 23, 31, generator=g)
+            y = ops.nchw_to_nhwc(fr.to(dev), ld=ld, scale=0.5, shift=0.5, out_dtype=dt)
+            ref = F.pad(nhwc(fr * 0.5 + 0.5), (0, ld - c)).to(dt)
+            assert torch.equal(y.cpu(), ref), "nchw_to_nhwc C=%d ld=%d %s" % (c, ld, dt)
 
 
 @pytest.mark.parametrize("align,size_in,size_out", [(True, (240, 432), (60, 108)), (False, (60, 108), (64, 128)),

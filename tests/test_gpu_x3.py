@@ -35,7 +35,7 @@ def test_conv_x3(dev, case):
     src_d = [(s.to(dev), 4) for s in srcs]
     res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
     ref = F.leaky_relu(ref0 + nchw(res), 0.1)
-    for tile in sorted(set(t for t in tiles if t < 10) | {1, 5, 7}):
+    for tile in sorted(set(t for t in tiles if t < 10) | {1, 5, 7, 8}):
         out = layer(src_d, residual=res.to(dev), act=ops.ACT_LRELU, slope=0.1, tile=tile)
         assert out.dtype == torch.float32
         assert_close(nchw(out.cpu()), ref, fp32_tol(sum(cpg) * k * k), "%s x3 tile %d" % (name, tile))
@@ -393,7 +393,7 @@ def test_qkv_epilogue_writes_the_attention_planes(dev, rows):
     layer = ops.PackedConvX(w, b, [512], dtype=torch.float32, x3=True)
     x4 = x.view(rows, 1, 1, 512)
     ran = 0
-    for tile in (1, 2, 4, 5, 6, 7):
+    for tile in (1, 2, 4, 5, 6, 7, 8):
         full = torch.empty(rows, 1, 1, 1536, device=dev)
         try:
             layer([x4], out=full, tile=tile)
