@@ -4,7 +4,7 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if re.search(r"nchw_(small_)?to_nhwc", r["Kernel_Name"])]
 # a forward = from the first resize before the mark (flows run on the side stream) to the next forward's start
 seg = rows[marks[-2] - 1:marks[-1] - 1]
 t0 = int(seg[0]["Start_Timestamp"])
