@@ -297,7 +297,7 @@ class Engine(BF16Path):
     def _side_stream(self):
         if self._side is None:
             # (default priority on purpose: with a priority on EITHER branch of the captured forward -- this stream or the capture
-            #  stream -- the replayed graph takes 21.9 ms instead of 12.0, profiles/r05_stream_priority.txt)
+            #  stream -- the replayed graph takes 21.9 ms instead of 12.0, profiles/r05_tile8_priority_ab.txt)
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 

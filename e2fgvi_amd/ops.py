@@ -90,7 +90,7 @@ _TUNED = {}      # (layer geometry, input size class) -> tile code; shared by al
 #   E2FGVI_AUTOTUNE=1   time the candidates on the first eager call of each (geometry, size class) instead (what generates the
 #                       table); those decisions are persisted per library build under e2fgvi_amd/.tile_cache/ (or
 #                       $E2FGVI_CACHE_DIR; E2FGVI_TUNE_FILE=<path> names the file, =0 disables) so that a profiled run replays them
-#   E2FGVI_TILE_TABLE=0 ignore the table (every layer on its static default kernel)
+#   E2FGVI_TILE_TABLE=0 ignore the table (every layer on its static default kernel); =<file.py>: that table instead of the checked-in one
 AUTOTUNE = os.environ.get("E2FGVI_AUTOTUNE", "0") == "1"
 TUNE_REPS = max(1, int(os.environ.get("E2FGVI_TUNE_REPS", "1") or 1))      # x the timed launches per candidate (table generation: 4)
 TABLE_FORMAT = 2          # bump when the meaning of a key field or of a tile code changes: older tables / cache files are ignored
@@ -127,7 +127,13 @@ if AUTOTUNE:
                 pass
 elif os.environ.get("E2FGVI_TILE_TABLE", "1") != "0":
     try:
-        from . import tile_table as _tt
+        if os.environ.get("E2FGVI_TILE_TABLE", "1").endswith(".py"):       # another table of the same format (A/B runs, integrators)
+            import importlib.util
+            _spec = importlib.util.spec_from_file_location("e2fgvi_tile_table_override", os.environ["E2FGVI_TILE_TABLE"])
+            _tt = importlib.util.module_from_spec(_spec)
+            _spec.loader.exec_module(_tt)
+        else:
+            from . import tile_table as _tt
         if getattr(_tt, "TABLE_FORMAT", None) == TABLE_FORMAT:
             _TUNED.update(_tt.TILES)
     except ImportError:
