@@ -248,9 +248,14 @@ class Engine(BF16Path):
             # split exactly into three bf16 pieces, six bf16 MFMA terms per product, fp32-level rounding): timed against the
             # layer's fp32 kernel on the first eager call of each size class, kept where it is faster (the GEMM-shaped layers:
             # token Linears, soft split / composite, the stride-2 and 1x1 convs; the Winograd layers mostly keep Winograd).
-            # SPyNet stays on its packed-math-free fp32 kernels: it shares the chip with these LDS-fed bf16 MFMA waves.
+            # SPyNet's 7x7 layers are candidates too since round 5 (the split-operand GEMM is built without packed-fp32 VALU like every
+            # kernel that can run on the side stream): the two wide layers of the upper levels take it, 221 -> 199 and 239 -> 223 us
+            # alone and -- what matters beside the encoder -- at a third of the matrix-pipe time (profiles/r05_spynet_x3.txt).
             for layer in self.enc + self.dec[:3] + [self.fusion, self.ss, self.sc] + ([self.sc_bias_conv] if self.hq else []):
                 layer.try_x3 = True
+            for convs in self.spy:
+                for layer in convs:
+                    layer.try_x3 = True
             for off, _dcn, bb in self.prop.values():
                 for layer in off + bb:
                     layer.try_x3 = True

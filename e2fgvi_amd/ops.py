@@ -532,7 +532,8 @@ class PackedConv:
                 return lib.e2fgvi_conv2d_nhwc_nopk(C.byref(d), _stream()), "conv2d_nhwc_nopk"
             return lib.e2fgvi_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc"
 
-        x3 = self.try_x3 and X3_ENABLED and not self.nopk
+        # (a layer of the side stream may take it too: conv_bf16x.o is one of the packed-math-free objects, build.NOPK_OBJECTS)
+        x3 = self.try_x3 and X3_ENABLED
         if auto_tile and (tile == 0 or not self.tune) and (self.tune or x3) and self.precision == "fp32" and N * Ho * Wo >= 2048:
             # one decision per (layer geometry, size class): row counts within a quarter octave share the tile, so the
             # slightly different window lengths of a video (t = 17 ... 21 frames) do not each pay for a tuning pass
