@@ -38,6 +38,7 @@ WIN = (5, 9)
 # With several clips per forward the batched encoder layers fill the chip on their own and the early join is 0.5 % ahead (8 clips: 974.7
 # vs 969.5 frames/s), so: 16 at one clip, 10 otherwise; E2FGVI_JOIN_AT overrides both.
 JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "0") or 0)
+PROP_SPLIT = os.environ.get("E2FGVI_PROP_SPLIT", "1") != "0"       # 0: conv_offset.0 / backbone.0 whole in every propagation step (A/B)
 
 
 def token_grid(h, w):
@@ -141,11 +142,15 @@ class Engine(BF16Path):
                      PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1))]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)
-        # (Measured and rejected in round 2: splitting conv_offset.0 / backbone.0 into a batched non-recurrent half for all
-        # frames + a per-step recurrent half.  The per-step Winograd launches are dominated by their fixed cost, not by
-        # the K loop: 42 -> 34 us and 37 -> 26 us per step, but the four extra batched launches cost 537 us -- a net loss
-        # of 170 us per forward at one clip, profiles/r02_c2_layer_fp32_base.md.)
+        # conv_offset.0 and backbone.0 are linear in their input channels, and a third / a half / two thirds of those do not
+        # depend on the recurrence (the current frame's features, the other direction's result): at one clip per forward that
+        # part is computed for all frames at once on the side stream, beside the chain of one-frame launches that leaves most
+        # of the chip idle, and enters the per-step layer -- now 260 / 128 input channels instead of 388 / 256 / 384 -- as its
+        # residual (PROP_SPLIT, propagate()).  Round 2 measured the same split as a net loss (42 -> 34 and 37 -> 26 us per step
+        # against 537 us of batched launches in the critical path, profiles/r02_c2_layer_fp32_base.md): the batched half was
+        # four fp32-MFMA launches on the main stream then, it is three split-operand launches beside the chain now.
         self.prop = {}
+        self.prop_split = {}
         for d, nparts in (("backward_", 2), ("forward_", 3)):
             p = "feat_prop_module.deform_align.%s." % d
             # conv_offset.0 input = cat(cond_n1, cur, cond_n2, flow_1, flow_2): sources (cond|0), cur, (cond|128), flows4
@@ -161,6 +166,16 @@ class Engine(BF16Path):
             bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **ww),
                   PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **ww)]
             self.prop[d] = (off, dcn, bb)
+            if PROP_SPLIT and precision == "fp32":
+                w0, wb = f(p + "conv_offset.0.weight"), f(b + "0.weight")
+                sp = dict(off_rec=PackedConv(torch.cat([w0[:, :128], w0[:, 256:388]], 1).contiguous(), f(p + "conv_offset.0.bias"),
+                                             [128, 128, 4], pad=1, **ww),
+                          off_cur=PackedConv(w0[:, 128:256].contiguous(), None, [128], pad=1, **ww),
+                          bb_rec=PackedConv(wb[:, -128:].contiguous(), f(b + "0.bias"), [128], pad=1, **ww),
+                          bb_pre=PackedConv(wb[:, :-128].contiguous(), None, [128] * (nparts - 1), pad=1, **ww))
+                sp["off_rec"].name, sp["off_cur"].name = "deform_align.%sconv_offset.0 (recurrent part)" % d, "deform_align.%sconv_offset.0 (current-frame part)" % d
+                sp["bb_rec"].name, sp["bb_pre"].name = "backbone.%s0 (recurrent part)" % d, "backbone.%s0 (non-recurrent part)" % d
+                self.prop_split[d] = sp
         self.fusion = PackedConv(f("feat_prop_module.fusion.weight"), f("feat_prop_module.fusion.bias"), [128, 128], **pw)
 
         # ---- soft split / composite (tfocal_transformer.py:19-72)
@@ -258,6 +273,9 @@ class Engine(BF16Path):
                     layer.try_x3 = True
             for off, _dcn, bb in self.prop.values():
                 for layer in off + bb:
+                    layer.try_x3 = True
+            for sp in self.prop_split.values():
+                for layer in sp.values():
                     layer.try_x3 = True
             for blk in self.blocks:
                 for k in ("qkv", "proj", "fc1", "fc2"):
@@ -397,8 +415,44 @@ class Engine(BF16Path):
         feats = {}
         zero = self._zero((b, h, w, ch))
         lk = dict(act=ACT_LRELU, slope=0.1)
+        # the non-recurrent parts of conv_offset.0 / backbone.0 for the frames of steps 1 .. l_t - 1, all at once (see __init__);
+        # step 0 of a direction (backbone only, needed at once) keeps the whole layer
+        split = bool(self.prop_split) and b == 1 and l_t >= 3
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if (split and self.overlap_flows) else None
+        pre, ready = {}, {}
+        if split:
+            n1 = (l_t - 1) * b
+            for k in ("off backward_", "bb backward_", "off forward_", "bb forward_"):
+                pre[k] = torch.empty((l_t - 1, b, h, w, ch), dtype=torch.float32, device=dev)
+            flat = lambda t: t.reshape(n1, h, w, ch)
+            lb, lf = flat(loc[:l_t - 1]), flat(loc[1:])       # backward: steps 1.. are frames l_t-2 .. 0; forward: frames 1 .. l_t-1
+
+            def beside(jobs):
+                """jobs: (key, layer, sources) in the order the chain needs them; on the side stream when there is one"""
+                if side is not None:
+                    side.wait_stream(main)
+                for key, layer, srcs in jobs:
+                    if side is None:
+                        layer(srcs, out=flat(pre[key]))
+                        continue
+                    with torch.cuda.stream(side):
+                        layer(srcs, out=flat(pre[key]))
+                        ready[key] = torch.cuda.Event()
+                        ready[key].record(side)
+            sb, sf = self.prop_split["backward_"], self.prop_split["forward_"]
+            beside([("off backward_", sb["off_cur"], [lb]), ("bb backward_", sb["bb_pre"], [lb]), ("off forward_", sf["off_cur"], [lf])])
+
+        def partial(key, slot):
+            ev = ready.pop(key, None)
+            if ev is not None:
+                main.wait_event(ev)
+            return pre[key][slot]
         for name, flows in (("backward_", flows_a), ("forward_", flows_b)):
             off_convs, dcn, bb = self.prop[name]
+            sp = self.prop_split.get(name) if split else None
+            if sp is not None and name == "forward_":
+                beside([("bb forward_", sp["bb_pre"], [lf, flat(feats["backward_"][1:])])])
             store = torch.empty((l_t, b, h, w, ch), dtype=torch.float32, device=dev)
             order = list(range(l_t))
             if name == "backward_":
@@ -413,15 +467,22 @@ class Engine(BF16Path):
                     flow_b = flows[0, i - 2] if i > 1 else None
                     feat_n2 = hist[-2] if i > 1 else None
                     cond, fl = ops.prop_cond(feat_prop, feat_n2, flow_a, flow_b, img_stride)
-                    x = off_convs[0]([(cond, 0), cur, (cond, ch), fl], **lk)
+                    if sp is not None:
+                        slot = idx if name == "backward_" else idx - 1
+                        x = sp["off_rec"]([(cond, 0), (cond, ch), fl], residual=partial("off " + name, slot), **lk)
+                    else:
+                        x = off_convs[0]([(cond, 0), cur, (cond, ch), fl], **lk)
                     x = off_convs[1]([x], **lk)
                     x = off_convs[2]([x], **lk)
                     # 10*tanh + flow.flip / sigmoid (feat_prop.py:38-53) applied in the epilogue of the last conv_offset
                     # layer: the deformable conv then reads finished offsets and masks
                     offs = off_convs[3]([x], residual=fl, act=ACT_DCNPOST, slope=10.0)
                     feat_prop = dcn([feat_prop, feat_n2 if feat_n2 is not None else zero], offs)
-                srcs = [cur, feats["backward_"][idx], feat_prop] if name == "forward_" else [cur, feat_prop]
-                y = bb[0](srcs, **lk)
+                if sp is not None and i > 0:
+                    y = sp["bb_rec"]([feat_prop], residual=partial("bb " + name, idx if name == "backward_" else idx - 1), **lk)
+                else:
+                    srcs = [cur, feats["backward_"][idx], feat_prop] if name == "forward_" else [cur, feat_prop]
+                    y = bb[0](srcs, **lk)
                 feat_prop = bb[1]([y], residual=feat_prop, out=store[idx])
                 hist.append(feat_prop)
             feats[name] = store
