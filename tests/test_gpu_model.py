@@ -73,6 +73,43 @@ def test_stage_propagation(dev, model, kind, hw, t, lt):
     assert_close(prop.cpu(), ref, 2e-4, "propagation")
 
 
+@pytest.mark.parametrize("model,hw,lt", [("e2fgvi", (240, 432), 6), ("e2fgvi_hq", (120, 216), 4), ("e2fgvi", (240, 432), 3)])
+def test_propagation_split_matches_the_whole_layers(dev, model, hw, lt):
+    """engine.PROP_SPLIT (round 5): the non-recurrent input channels of conv_offset.0 / backbone.0 batched on the side stream and
+    added as the per-step layers' residual == the whole layers, up to the order of the fp32 sums; the two-stream run returns the
+    bits of the serial one; several clips per forward keep the whole layers (stress weights: real deformable offsets)"""
+    eng = _engine(model, "stress", dev)
+    assert eng.prop_split, "the split layers were not built"
+    h, w = hw[0] // 4, hw[1] // 4
+    g = torch.Generator().manual_seed(97 + lt)
+    loc = torch.randn(lt, 1, h, w, 128, generator=g).to(dev)
+    fa = (2.0 * torch.randn(1, lt - 1, h, w, 2, generator=g)).to(dev)
+    fb = (2.0 * torch.randn(1, lt - 1, h, w, 2, generator=g)).to(dev)
+    split = eng.propagate(loc, fa, fb).clone()
+    keep, flows_overlap = eng.prop_split, eng.overlap_flows
+    try:
+        eng.overlap_flows = False
+        serial = eng.propagate(loc, fa, fb).clone()
+        eng.prop_split = {}
+        whole = eng.propagate(loc, fa, fb).clone()
+    finally:
+        eng.prop_split, eng.overlap_flows = keep, flows_overlap
+    torch.cuda.synchronize()
+    assert torch.equal(split, serial), "side-stream and serial runs of the split layers differ"
+    assert_close(split.cpu(), whole.cpu(), 1e-4, "propagation, split against whole layers (l_t = %d)" % lt)
+    # two clips: the whole layers (identical to a run without the split layers)
+    loc2 = torch.cat([loc, loc.flip(0)], 1).contiguous()
+    fa2, fb2 = torch.cat([fa, fb], 0).contiguous(), torch.cat([fb, fa], 0).contiguous()
+    two = eng.propagate(loc2, fa2, fb2).clone()
+    try:
+        eng.prop_split = {}
+        two_whole = eng.propagate(loc2, fa2, fb2).clone()
+    finally:
+        eng.prop_split = keep
+    assert torch.equal(two, two_whole)
+    assert_close(two[:, 0].cpu(), whole[:, 0].cpu(), 1e-4, "clip 0 of two against the one-clip run")
+
+
 @pytest.mark.parametrize("model,kind,hw,t,lt", CFG)
 def test_stage_transformer(dev, model, kind, hw, t, lt):
     sd, x, tr, out, flows = _setup(model, kind, hw, t, lt)
