@@ -85,6 +85,16 @@ def build_key_table(fh, fw, valid_ind_rolled):
     return tab, nk
 
 
+def split_prop_weights(w_off0, w_bb0, ch=128):
+    """The propagation split as weight slices.  conv_offset.0 reads cat(cond_n1, current frame, cond_n2, flow_1,
+    flow_2) (feat_prop.py:27-35,117-123) and backbone.0 cat(current frame[, the other direction's feature], feat_prop)
+    (feat_prop.py:131-137): `*_rec` keep the input channels that depend on the recurrence -- sources (cond_n1, cond_n2, flows) and
+    (feat_prop) --, `off_cur` / `bb_pre` the rest; conv(whole) == conv(rec part) + conv(other part), bias counted once
+    (tests/test_identities.py)."""
+    return dict(off_rec=torch.cat([w_off0[:, :ch], w_off0[:, 2 * ch:]], 1).contiguous(), off_cur=w_off0[:, ch:2 * ch].contiguous(),
+                bb_rec=w_bb0[:, -ch:].contiguous(), bb_pre=w_bb0[:, :-ch].contiguous())
+
+
 class _NotBuilt:
     """stands in for an fp32 layer in the bf16 mode (names / flags may be set on it; calling it is a bug)"""
 
@@ -167,12 +177,11 @@ class Engine(BF16Path):
                   PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **ww)]
             self.prop[d] = (off, dcn, bb)
             if PROP_SPLIT and precision == "fp32":
-                w0, wb = f(p + "conv_offset.0.weight"), f(b + "0.weight")
-                sp = dict(off_rec=PackedConv(torch.cat([w0[:, :128], w0[:, 256:388]], 1).contiguous(), f(p + "conv_offset.0.bias"),
-                                             [128, 128, 4], pad=1, **ww),
-                          off_cur=PackedConv(w0[:, 128:256].contiguous(), None, [128], pad=1, **ww),
-                          bb_rec=PackedConv(wb[:, -128:].contiguous(), f(b + "0.bias"), [128], pad=1, **ww),
-                          bb_pre=PackedConv(wb[:, :-128].contiguous(), None, [128] * (nparts - 1), pad=1, **ww))
+                ws = split_prop_weights(f(p + "conv_offset.0.weight"), f(b + "0.weight"))
+                sp = dict(off_rec=PackedConv(ws["off_rec"], f(p + "conv_offset.0.bias"), [128, 128, 4], pad=1, **ww),
+                          off_cur=PackedConv(ws["off_cur"], None, [128], pad=1, **ww),
+                          bb_rec=PackedConv(ws["bb_rec"], f(b + "0.bias"), [128], pad=1, **ww),
+                          bb_pre=PackedConv(ws["bb_pre"], None, [128] * (nparts - 1), pad=1, **ww))
                 sp["off_rec"].name, sp["off_cur"].name = "deform_align.%sconv_offset.0 (recurrent part)" % d, "deform_align.%sconv_offset.0 (current-frame part)" % d
                 sp["bb_rec"].name, sp["bb_pre"].name = "backbone.%s0 (recurrent part)" % d, "backbone.%s0 (non-recurrent part)" % d
                 self.prop_split[d] = sp

@@ -168,3 +168,27 @@ def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_level(rne):
     # (one fp32 rounding per TERM here -- six per product, the worst case; the MFMA rounds once per 16-product instruction and
     #  measures at or below the plain fp32 kernel on the GPU, tests/test_gpu_x3.py)
     assert e_split < 8 * np.sqrt(K) * 2.0 ** -24 and e_split < 4 * e_plain + 1e-7, (e_plain, e_split)
+
+
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_propagation_split_is_the_whole_layer(nparts):
+    """engine.split_prop_weights: conv_offset.0 over cat(cond_n1, cur, cond_n2, flows) and backbone.0 over
+    cat(cur[, other direction], feat_prop) equal the recurrent-part convolution plus the non-recurrent one (bias once) -- the
+    identity the engine's side-stream precompute rests on, with the engine's own slices"""
+    from e2fgvi_amd.engine import split_prop_weights
+    g = torch.Generator().manual_seed(31 + nparts)
+    ch, h, w = 128, 10, 14
+    w_off0 = torch.randn(128, 3 * ch + 4, 3, 3, generator=g, dtype=torch.float64) * 0.05
+    w_bb0 = torch.randn(128, nparts * ch, 3, 3, generator=g, dtype=torch.float64) * 0.05
+    bias = torch.randn(128, generator=g, dtype=torch.float64)
+    ws = {k: v.double() for k, v in split_prop_weights(w_off0, w_bb0).items()}
+    c1, cur, c2 = (torch.randn(1, ch, h, w, generator=g, dtype=torch.float64) for _ in range(3))
+    fl = torch.randn(1, 4, h, w, generator=g, dtype=torch.float64)
+    whole = F.conv2d(torch.cat([c1, cur, c2, fl], 1), w_off0, bias, padding=1)
+    parts = F.conv2d(torch.cat([c1, c2, fl], 1), ws["off_rec"], bias, padding=1) + F.conv2d(cur, ws["off_cur"], None, padding=1)
+    assert (whole - parts).abs().max() < 1e-12
+    other = [torch.randn(1, ch, h, w, generator=g, dtype=torch.float64) for _ in range(nparts - 1)]   # cur[, the backward feature]
+    prop = torch.randn(1, ch, h, w, generator=g, dtype=torch.float64)
+    whole = F.conv2d(torch.cat(other + [prop], 1), w_bb0, bias, padding=1)
+    parts = F.conv2d(prop, ws["bb_rec"], bias, padding=1) + F.conv2d(torch.cat(other, 1), ws["bb_pre"], None, padding=1)
+    assert (whole - parts).abs().max() < 1e-12
