@@ -265,6 +265,19 @@ def test_kernel_table_invariants_and_nearest_size_class_lookup(monkeypatch):
     for k, v in tile_table.TILES.items():
         assert isinstance(k, tuple) and isinstance(k[ops._SIZE_FIELD], int) and isinstance(v, int)
         assert "alone" not in k, k
+        # every code names a kernel the library instantiates (csrc/conv_bf16x.hip conv2d_x; csrc/conv_wino.hip wino_run; conv.hip)
+        if k[0] == "x":
+            assert v in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18), (k, v)
+        elif v >= ops.W3_BASE:
+            assert v - ops.W3_BASE in ops.W3_CANDIDATES, (k, v)
+        elif v >= ops.X3_BASE:
+            assert v - ops.X3_BASE in ops.XTUNE_CANDIDATES, (k, v)
+        elif 2000 <= v < 2100:
+            assert v - 2000 in ops.XTUNE_CANDIDATES, (k, v)
+    # round 5: the qkv Linear on the 256x192 tile, SPyNet layers and the propagation split's layers among the decisions
+    assert any(v == ops.X3_BASE + 8 for v in tile_table.TILES.values())
+    assert any(k[0] != "x" and k[2] == 7 and v >= ops.X3_BASE for k, v in tile_table.TILES.items()), "no SPyNet layer on the split-operand GEMM"
+    assert any(k[0] != "x" and k[1] == (128, 128, 4) for k in tile_table.TILES), "the recurrent part of conv_offset.0 is not tabled"
     if ops.AUTOTUNE:
         return
     monkeypatch.setattr(ops, "_TUNED", dict(tile_table.TILES))
