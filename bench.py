@@ -55,6 +55,35 @@ def flops_per_clip(H, W, t, lt, hq):
 
 
 KERNELS = {}      # layer -> kernel of the last traced forward (bench line: config.kernels)
+USEFUL_GFLOP = 0.0   # of the last traced forward: issued work without tile / channel padding (roofline.frac_useful)
+# the roof the reference's direct-convolution FLOPs are priced against (`frac_effective`): an fp32 product costs the matrix pipe one
+# fp32 MFMA MAC (157.3 TF), or six bf16 MFMA MACs on exactly split operands (2500 / 6 = 416.7 TF), or one bf16 MAC on the bf16 path
+EFFECTIVE_PEAK = {"fp32": 157.3, "fp32+x3": 2500.0 / 6, "bf16": 2500.0}
+
+
+def launch_command(n, argv, script=None, port=None):
+    """argv of the one-process-per-GPU launch of this script on ONE node: the driver's own form
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:                       # a free port, so two jobs on one box do not collide
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv, script=None, env=None):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here and hand their exit code back.
+    Rank 0 prints the JSON line on the inherited stdout (the other ranks' stdout goes to /dev/null in main())."""
+    import subprocess
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL across processes)
+    e.setdefault("OMP_NUM_THREADS", "8")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    sys.stdout.flush()
+    return subprocess.call(launch_command(n, argv, script), env=e)
 
 
 def traced_work(net, x, lt):
@@ -79,6 +108,8 @@ def traced_work(net, x, lt):
     KERNELS.clear()
     KERNELS.update({k: " | ".join(sorted(v)) for k, v in sorted(names.items()) if not k.startswith("spynet.")})
     KERNELS["spynet.*"] = " | ".join(sorted({kk for k, v in names.items() if k.startswith("spynet.") for kk in v}))
+    global USEFUL_GFLOP
+    USEFUL_GFLOP = 2e-9 * sum(r.get("useful", min(r["macs"], r["issued"])) for r in rows)
     return 2e-9 * sum(r["macs"] for r in rows), 2e-9 * sum(r["issued"] for r in rows), len(rows)
 
 
@@ -196,6 +227,7 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
         net(x, lt)
         torch.cuda.synchronize()
         gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
+        gflop_useful = USEFUL_GFLOP
         kernels = dict(KERNELS)
         elapsed, dev_ms, graphed = time_local(net, x, lt, steps, warmup)
     finally:
@@ -211,10 +243,12 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
             "dtype": "f32" if precision == "fp32" else "bf16",
             "roofline": {"bound": "mfma", "achieved": round(gflop_issued / secs / 1e3, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(gflop_issued / secs / 1e3 / peak, 4),
+                         "frac_useful": round(gflop_useful / secs / 1e3 / peak, 4),
                          "achieved_algorithmic": round(gflop_alg / secs / 1e3, 2),
-                         "frac_algorithmic": round(gflop_alg / secs / 1e3 / peak, 4),
+                         "effective_peak": round(EFFECTIVE_PEAK[arith], 1),
+                         "frac_effective": round(gflop_alg / secs / 1e3 / EFFECTIVE_PEAK[arith], 4),
                          "gflop_per_forward": {"algorithmic": round(gflop_alg, 1), "issued": round(gflop_issued, 1),
-                                               "mfma_launches": nlaunch}},
+                                               "useful": round(gflop_useful, 1), "mfma_launches": nlaunch}},
             "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
     if precision == "fp32" and not x3:
         line["config"]["kernels"] = kernels
@@ -243,6 +277,8 @@ def main():
     ap.add_argument("--no-dominant-probe", action="store_true",
                     help="skip the 21 extra launches of encoder.layers.10 behind the timed region (PMC passes count whole processes: "
                          "tools/pmc.sh divides by the number of forwards)")
+    ap.add_argument("--launcher", action="store_true",
+                    help="start the ranks through torch.distributed.run even for one GPU (the N > 1 launch path, testable on one GPU)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the BASELINE configs[3] / [4] lines (e2fgvi_hq 720x1296 T=10 and 1080x1944 T=20, bf16) that the "
                          "default single-GPU invocation times after the headline and attaches as `secondary`")
@@ -251,10 +287,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    launched = "WORLD_SIZE" in os.environ
+    if launched and args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not launched and (args.gpus > 1 or args.launcher):
+        # plain `python bench.py --gpus N`: become the launcher of the N ranks (round 6; before, this form exited with a hint)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("--gpus %d but %d GPU(s) visible on this node" % (args.gpus, have))
+        argv = [a for a in sys.argv[1:] if a != "--launcher"]
+        if args.gpus == 1 and "--force-dist" not in argv:
+            argv.append("--force-dist")
+        raise SystemExit(self_launch(args.gpus, argv))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import importlib
@@ -282,6 +326,7 @@ def main():
     net(x, lt)
     torch.cuda.synchronize()
     gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)      # per forward of b clips
+    gflop_useful = USEFUL_GFLOP
     kernels = dict(KERNELS)
     same_work = None
     if world > 1 or args.force_dist:
@@ -343,6 +388,8 @@ def main():
     analytic = b * flops_per_clip(H, W, t, lt, hq)
     secs = dev_ms * 1e-3 / args.steps
     tf_alg, tf_iss = gflop_alg / secs / 1e3, gflop_issued / secs / 1e3          # this rank, device-timed
+    arith = "bf16" if args.precision == "bf16" else ("fp32+x3" if ops.X3_ENABLED else "fp32")
+    eff_peak = EFFECTIVE_PEAK[arith]
     config_no = 2 if (world == 1 and b == 1) else 3
     if hq:
         config_no = 4 if t <= 10 else 5
@@ -355,7 +402,7 @@ def main():
                                "random-init weights, torch.rand frames + box mask (SURVEY.md 8d)"
                                % (config_no - 1, args.model, W, H, t, lt, b, b * world),
                    "clips_per_gpu": b, "precision": args.precision,
-                   "arithmetic": ARITHMETIC["bf16" if args.precision == "bf16" else ("fp32+x3" if ops.X3_ENABLED else "fp32")],
+                   "arithmetic": ARITHMETIC[arith],
                    "kernels": kernels,
                    "kernel_selection": ("timed on this box (E2FGVI_AUTOTUNE=1)" if ops.AUTOTUNE else
                                         "e2fgvi_amd/tile_table.py (checked in, deterministic: ops.py)"),
@@ -363,23 +410,25 @@ def main():
                                   else "single GPU, no collective",
                    "hip_graph": bool(step.graphed)},
         "roofline": {"bound": "mfma", "achieved": round(tf_iss, 3), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(tf_iss / peak, 4),
-                     "achieved_algorithmic": round(tf_alg, 3), "frac_algorithmic": round(tf_alg / peak, 4),
+                     "frac": round(tf_iss / peak, 4), "frac_useful": round(gflop_useful / secs / 1e3 / peak, 4),
+                     "achieved_algorithmic": round(tf_alg, 3), "effective_peak": round(eff_peak, 1),
+                     "frac_effective": round(tf_alg / eff_peak, 4),
                      "gflop_per_forward": {"algorithmic": round(gflop_alg, 1), "issued": round(gflop_issued, 1),
+                                           "useful": round(gflop_useful, 1),
                                            "analytic_survey_8d": round(analytic, 1), "mfma_launches": nlaunch},
                      "traffic": None,
                      "note": "whole forward, device time of one forward (hip events on the launch stream). `achieved` / `frac` count "
                              "the FLOPs ISSUED to the matrix pipe (the Winograd F(2x2,3x3) layers issue 16/36 of their direct-"
-                             "convolution multiplies, plus block / channel padding: per-launch accounting of ops.PackedConv._work); "
-                             "`*_algorithmic` count the reference's direct-convolution FLOPs (SURVEY.md 8d) and can exceed the "
-                             "peak on Winograd layers.  fp32 layers that run on the bf16 matrix pipe with exactly split operands "
-                             "(six bf16 MFMA terms per fp32 product, fp32-level rounding: tests/test_gpu_x3.py) are counted in "
-                             "fp32-MFMA equivalents (bf16 MACs x 157.3 / 2500), so `frac` stays the share of the time the "
-                             "matrix pipe is busy at its peak rate (what rocprofv3's SQ_VALU_MFMA_BUSY_CYCLES measures).  Round 2's "
-                             "0.57 was that share on fp32 MFMA instructions only; with most layers issued as 6 bf16 MFMAs of 32 "
-                             "cycles per 16 k instead of 8 fp32 MFMAs of 64, the same work occupies the pipe for 0.375 of the time "
-                             "and the forward is bound by VALU / LDS-fill / launch latency instead (DESIGN.md section 6): `frac` "
-                             "falls while frames/s rise; `frac_algorithmic` is the reference's FLOPs against the fp32 MFMA peak"},
+                             "convolution multiplies, plus block / channel padding: per-launch accounting of ops.PackedConv._work), "
+                             "`frac_useful` the same without the tile / channel padding (lib.useful_macs).  fp32 layers that run on "
+                             "the bf16 matrix pipe with exactly split operands (six bf16 MFMA terms per fp32 product, fp32-level "
+                             "rounding: tests/test_gpu_x3.py) are counted in fp32-MFMA equivalents (bf16 MACs x 157.3 / 2500), so "
+                             "`frac` is the share of the time the matrix pipe is busy at its peak rate (what rocprofv3's "
+                             "SQ_VALU_MFMA_BUSY_CYCLES measures).  `achieved_algorithmic` counts the reference's direct-convolution "
+                             "FLOPs (SURVEY.md 8d); `frac_effective` prices them against `effective_peak`, the rate at which the "
+                             "matrix pipe can retire fp32 products in this arithmetic (157.3 TF as fp32 MFMA, 2500 / 6 = 416.7 TF as "
+                             "six bf16 terms, 2500 TF on the bf16 data path) -- Winograd's saved multiplies count in its favour, "
+                             "so it is an efficiency against the direct algorithm, not a pipe utilisation"},
     }
     # HBM-side traffic of one forward: rocprofv3 PMC passes (tools/pmc.sh) cannot run inside the timed process; the summary of the
     # last collection is committed under profiles/ TOGETHER WITH the key of the library it measured (lib.library_key()), and it is

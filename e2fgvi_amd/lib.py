@@ -153,10 +153,33 @@ TRACE = None
 NEXT_META = None
 
 
+X3_PIPE = 6 * 157.3 / 2500.0       # six bf16 MACs per split-operand product, in fp32-MFMA pipe time (bf16 MAC = 157.3 / 2500 of an fp32 MAC)
+
+
+def useful_macs(kernel, macs, issued):
+    """The MACs of `issued` that are not tile / channel padding: what the kernel's ALGORITHM must put on the matrix pipe for the
+    layer's direct-convolution `macs` (Winograd F(2x2,3x3): 16 of 36, F(2x4): 24 of 72 ... per output block; split operands:
+    six bf16 terms in fp32-pipe equivalents), never more than what was issued."""
+    import re
+    k = str(kernel)
+    f = 1.0
+    m = re.match(r"conv_wino4<F\((\d)x4\)", k)
+    if m:
+        fy = int(m.group(1))
+        f = (fy + 2) * 6 / (fy * 4 * 9.0)
+    elif k.startswith("conv_wino"):
+        f = 16 / 36.0
+    if "x3" in k:
+        f *= X3_PIPE
+    return min(int(issued), int(macs * f))
+
+
 def annotate(**meta):
     """metadata for the next traced launch (ignored when tracing is off)"""
     global NEXT_META
     if TRACE is not None:
+        if "macs" in meta and "issued" in meta and "useful" not in meta:
+            meta["useful"] = useful_macs(meta.get("kernel", ""), meta["macs"], meta["issued"])
         NEXT_META = meta
 
 

@@ -155,7 +155,8 @@ def dominant_kernel_probe(net, dev, iters=20):
     with exactly split operands on the bf16 matrix pipe where it is faster).  `achieved` / `frac` count the work ISSUED to the
     matrix pipe in fp32-MFMA equivalents (a bf16 MAC of a split-operand kernel occupies the pipe for 157.3 / 2500 of the time
     of an fp32 MAC, so `frac` is the fraction of the time the pipe is busy at its peak rate in either case);
-    `achieved_algorithmic` counts the direct-convolution FLOPs and can exceed the fp32 peak."""
+    `achieved_algorithmic` counts the direct-convolution FLOPs; `frac_effective` prices them against 2500 / 6 TF (split operands)
+    or 157.3 TF (fp32 MFMA)."""
     from . import lib, ops
     eng = net.engine()
     layer = eng.enc[5]
@@ -178,13 +179,18 @@ def dominant_kernel_probe(net, dev, iters=20):
     finally:
         lib.TRACE = saved
     gflop, gflop_iss = 2e-9 * wk["macs"], 2e-9 * wk["issued"]
+    gflop_use = 2e-9 * wk.get("useful", min(wk["macs"], wk["issued"]))
     tf, tf_iss = gflop / (us * 1e-6) / 1e3, gflop_iss / (us * 1e-6) / 1e3
+    eff_peak = 2500.0 / 6 if "x3" in wk["kernel"] else 157.3
     rec = {"kernel": "%s (encoder.layers.10: 3x3 640->512 g2 on 10x60x108)" % wk["kernel"], "avg_us": round(us, 2),
            "gflop_per_launch": round(gflop_iss, 3), "gflop_per_launch_algorithmic": round(gflop, 3),
            "achieved": round(tf_iss, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf_iss / 157.3, 4),
-           "achieved_algorithmic": round(tf, 2), "frac_algorithmic": round(tf / 157.3, 4),
-           "note": "achieved = work issued to the matrix pipe / time, in fp32-MFMA equivalents; *_algorithmic = direct-convolution "
-                   "FLOPs / time"}
+           "frac_useful": round(gflop_use / (us * 1e-6) / 1e3 / 157.3, 4),
+           "achieved_algorithmic": round(tf, 2), "effective_peak": round(eff_peak, 1), "frac_effective": round(tf / eff_peak, 4),
+           "note": "achieved = work issued to the matrix pipe / time, in fp32-MFMA equivalents (frac_useful: without the MFMAs of the "
+                   "tile padding -- 64x112-pixel blocks over 60x108 frames); achieved_algorithmic = direct-convolution FLOPs / time, "
+                   "frac_effective = that against the rate the pipe retires fp32 products in this kernel's arithmetic (2500 / 6 TF as "
+                   "six bf16 terms, 157.3 TF as fp32 MFMA)"}
     if "x3" in wk["kernel"]:
         rec["bf16_mfma"] = {"achieved": round(tf_iss * 2500.0 / 157.3, 1), "peak": 2500.0, "unit": "TFLOP/s",
                             "note": "the same launch counted as what it issues: six v_mfma_f32_32x32x16_bf16 terms per product of "

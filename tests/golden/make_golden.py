@@ -37,7 +37,21 @@ CASES = [
     # reference's own output, not only against the port
     ("g7_e2fgvi_stress_t10_lt10", "e2fgvi", "stress", (240, 432), 10, 10, 1, 17),
     ("g8_e2fgvi_stress_t10_lt5", "e2fgvi", "stress", (240, 432), 10, 5, 1, 18),
+    # round 6: the HQ model at the clip lengths its bench lines are timed at (BASELINE.json configs[3]: 720x1296, T = l_t = 10;
+    # configs[4]'s resolution with an 8-step recurrence -- T = 20 at 1080p needs > 60 GB for the reference's materialised
+    # attention scores), so the bf16 data path's error growth over the recurrent chain is measured against the REAL reference
+    ("g9_hq_stress_720x1296_t10_lt10", "e2fgvi_hq", "stress", (720, 1296), 10, 10, 1, 19),
+    ("g10_hq_stress_1080x1944_t8_lt8", "e2fgvi_hq", "stress", (1080, 1944), 8, 8, 1, 20),
+    # the "peaked" weights (synth.py: sharp attention, saturated DCN offsets / masks, non-uniform pooling): the stand-in
+    # for trained weights while the released checkpoints are unreachable
+    ("g11_e2fgvi_peaked_t10_lt10", "e2fgvi", "peaked", (240, 432), 10, 10, 1, 21),
+    ("g12_hq_peaked_240x432_t6_lt4", "e2fgvi_hq", "peaked", (240, 432), 6, 4, 1, 22),
+    ("g13_hq_peaked_720x1296_t4_lt3", "e2fgvi_hq", "peaked", (720, 1296), 4, 3, 1, 23),
+    # bench.py's own configs[3] clip (synth_clip seed 0, smooth=False, static box; default-init weights): the frames of the
+    # TIMED engine of that secondary line are compared with this fixture (its `parity` field)
+    ("g14_hq_default_720x1296_t10_lt10_benchclip", "e2fgvi_hq", "default", (720, 1296), 10, 10, 1, 0),
 ]
+BENCH_CLIPS = {"g14_hq_default_720x1296_t10_lt10_benchclip"}       # synth_clip(..., smooth=False, moving=False)
 OUT_STRIDE, FLOW_STRIDE = 8, 4
 
 
@@ -54,7 +68,7 @@ def main():
             continue
         sd = synth_state_dict(model, kind, 0)
         net = ref_import.build_reference_model(model, sd)
-        x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
+        x, _ = synth_clip(b, t, H, W, seed=seed, smooth=False) if name in BENCH_CLIPS else synth_clip(b, t, H, W, seed=seed, moving=True)
         with torch.no_grad():
             out, (ff, fb) = net(x, lt)
         np.savez_compressed(
@@ -64,7 +78,7 @@ def main():
             flow_fwd_sub=ff[..., ::FLOW_STRIDE, ::FLOW_STRIDE].numpy(), flow_bwd_sub=fb[..., ::FLOW_STRIDE, ::FLOW_STRIDE].numpy(),
             flow_fwd_stats=stats(ff), flow_bwd_stats=stats(fb),
             meta=np.array([H, W, t, lt, b, seed, OUT_STRIDE, FLOW_STRIDE]), model=model, kind=kind)
-        print(name, tuple(out.shape), "out stats", stats(out))
+        print(name, tuple(out.shape), "out stats", stats(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,27 @@ def _bench(*args, timeout=900):
     return json.loads(lines[-1])
 
 
+def _fracs(node, path=""):
+    """every `frac*` number anywhere in a bench line"""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k.startswith("frac") and isinstance(v, (int, float)):
+                yield path + "/" + k, v
+            else:
+                yield from _fracs(v, path + "/" + k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            yield from _fracs(v, "%s[%d]" % (path, i))
+
+
+def test_plain_gpus_flag_launches_the_ranks_itself(dev):
+    """`python bench.py --gpus N` with no launcher around it (the driver's 8-GPU form minus torch.distributed.run) must start its
+    own ranks: --launcher takes the same path with one GPU (torch.distributed.run -> one rank, RCCL group, gather, JSON line)"""
+    j = _bench("--gpus", "1", "--launcher", "--clips-per-gpu", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert j["n_gpus"] == 1 and j["config"]["clips_per_gpu"] == 2 and "all-gather" in j["config"]["parallelism"]
+    assert j["single_gpu_same_work"]["value"] > 0 and j["value"] > 30
+
+
 def test_multi_gpu_flow_with_one_rank(dev):
     """config 3's per-GPU flow: `bench.py --force-dist --clips-per-gpu 8`"""
     j = _bench("--force-dist", "--clips-per-gpu", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
@@ -46,6 +67,11 @@ def test_default_line_carries_the_hq_configs(dev):
     j = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert j["metric"].startswith("inpainted frames/sec at 432x240 T=10") and j["dtype"] == "f32" and j["value"] > 30
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    # round 6: no fraction above 1 anywhere on the line (round 5 printed direct-convolution FLOPs over the fp32 peak as a `frac_*`)
+    fr = dict(_fracs(j))
+    assert fr and all(0 < v < 1 for v in fr.values()), fr
+    assert 0 < j["roofline"]["frac_useful"] <= j["roofline"]["frac"] and j["roofline"]["effective_peak"] == 416.7
+    assert j["roofline"]["dominant_kernel"]["frac_useful"] <= j["roofline"]["dominant_kernel"]["frac"]
     assert "split operands" in j["config"]["arithmetic"] and j["config"]["kernel_selection"].startswith("e2fgvi_amd/tile_table.py")
     assert "encoder.layers.10" in j["config"]["kernels"] and j["peak_memory_gb"] > 0
     sec = j["secondary"]

@@ -10,7 +10,7 @@ timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=
 python - "$OUT" <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1] + "/bench.json").read().strip().splitlines()[-1])
-print("headline %s %s ms frac %s alg %s | cpu %s" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["frac_algorithmic"], j.get("cpu_baseline", {}).get("value")))
+print("headline %s %s ms frac %s alg %s | cpu %s" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"].get("frac_effective"), j.get("cpu_baseline", {}).get("value")))
 for s in j.get("secondary", []):
     print("  ", s.get("metric"), s.get("value"), s.get("ms_per_step"), s.get("roofline", {}).get("frac"), s.get("error"))
 PY

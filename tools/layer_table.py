@@ -76,7 +76,9 @@ summary = {"model": a.model, "hw": [H, W], "t": a.t, "clips": a.clips, "precisio
 peak = 157.3 if a.precision == "fp32" else 2500.0
 summary["tflops_issued_whole_forward"] = round(summary["gflop_issued"] / fwd_ms, 1)
 summary["frac_issued"] = round(summary["gflop_issued"] / fwd_ms / peak, 4)
-summary["frac_algorithmic"] = round(summary["gflop_algorithmic"] / fwd_ms / peak, 4)
+eff_peak = peak if (a.precision != "fp32" or os.environ.get("E2FGVI_X3", "1") == "0") else 2500.0 / 6
+summary["effective_peak"] = round(eff_peak, 1)       # the rate the pipe retires fp32 products in this arithmetic (bench.py EFFECTIVE_PEAK)
+summary["frac_effective"] = round(summary["gflop_algorithmic"] / fwd_ms / eff_peak, 4)
 os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
 json.dump({"summary": summary, "rows": rows}, open(a.out + ".json", "w"), indent=0)
 # grouped view: same (layer-name-without-index, kernel, shape) collapsed

@@ -12,7 +12,7 @@ python - "$OUT" <<'PY'
 import json, sys
 try:
     j = json.loads(open(sys.argv[1] + "/bench.json").read().strip().splitlines()[-1])
-    print("headline %s %s ms frac %s alg %s | cpu %s | parity %s | traffic %s" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["frac_algorithmic"], j.get("cpu_baseline", {}).get("value"), {k: (v if not isinstance(v, dict) else v["max_abs"]) for k, v in j.get("parity", {}).items() if k not in ("vs",)}, j["roofline"].get("traffic")))
+    print("headline %s %s ms frac %s alg %s | cpu %s | parity %s | traffic %s" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"].get("frac_effective"), j.get("cpu_baseline", {}).get("value"), {k: (v if not isinstance(v, dict) else v["max_abs"]) for k, v in j.get("parity", {}).items() if k not in ("vs",)}, j["roofline"].get("traffic")))
     d = j["roofline"].get("dominant_kernel", {}); print("dominant", d.get("avg_us"), d.get("kernel"), d.get("frac"), d.get("bf16_mfma", {}).get("achieved"), d.get("traffic"))
     for s in j.get("secondary", []):
         print("  ", s.get("metric"), s.get("value"), s.get("ms_per_step"), s.get("roofline", {}).get("frac"), s.get("error"))
