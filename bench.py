@@ -186,7 +186,63 @@ def time_local(net, x, lt, steps, warmup, use_graph=True):
     step.finish()
     ev1.record()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, ev0.elapsed_time(ev1), bool(step.graphed)
+    wall, dev_ms = time.perf_counter() - t0, ev0.elapsed_time(ev1)
+    LAST_FRAMES[0] = step.finish()          # the frames of the last timed step (bf16 lines: compared with the real reference's fixture)
+    return wall, dev_ms, bool(step.graphed)
+
+
+LAST_FRAMES = [None]
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+# fixtures of the REAL reference (tests/golden/make_golden.py) for the bf16 lines: (H, W, T) -> (the bench clip under the timed
+# default-init weights | None, a stress-weights clip of the same resolution)
+HQ_FIXTURES = {(720, 1296, 10): ("g14_hq_default_720x1296_t10_lt10_benchclip.npz", "g9_hq_stress_720x1296_t10_lt10.npz"),
+               (1080, 1944, 20): (None, "g10_hq_stress_1080x1944_t8_lt8.npz")}
+
+
+def _fixture_parity(frames, path, what):
+    """frames [b*t, 3, H, W] of the HIP path against the strided sub-sample a fixture holds of the real reference's output"""
+    import numpy as np
+    z = np.load(path)
+    so = int(z["meta"][6])
+    diff = frames[:, :, ::so, ::so].float().cpu().numpy().astype(np.float64) - z["out_sub"]
+    rms = float(z["out_stats"][2])
+    return {"max_abs": float("%.3e" % np.abs(diff).max()), "rms_of_difference_over_rms": float("%.3e" % (np.sqrt((diff ** 2).mean()) / rms)),
+            "rms_of_reference": float("%.3e" % rms), "fixture": "tests/golden/" + os.path.basename(path), "weights": what}
+
+
+def hq_parity(dev, model, H, W, t, precision, timed_frames):
+    """`parity` of a bf16 secondary line, against the REAL reference (fixtures made in the build container; the reference cannot
+    travel): `default` = the frames of the timed engine on the timed clip (720x1296 T=10: the fixture IS bench.py's clip),
+    `stress` = a second engine of the same class and kernel decisions on the stress-weights fixture clip of that resolution
+    (T = l_t = 10 at 720x1296, T = l_t = 8 at 1080x1944: the reference's materialised attention scores at T = 20 need > 60 GB)."""
+    import importlib
+    import numpy as np
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    fx = HQ_FIXTURES.get((H, W, t))
+    if fx is None or not all(f is None or os.path.exists(os.path.join(GOLDEN, f)) for f in fx):
+        return None
+    par = {}
+    if fx[0] is not None and timed_frames is not None:
+        par["default"] = _fixture_parity(timed_frames, os.path.join(GOLDEN, fx[0]), "reference's init_weights distribution (the timed weights, "
+                                         "the timed clip, the timed engine's last step)")
+    z = np.load(os.path.join(GOLDEN, fx[1]))
+    fh, fw, ft, flt, fb, seed = [int(v) for v in z["meta"][:6]]
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(synth_state_dict(model, "stress", 0))
+    net = net.to(dev).eval()
+    net.precision = precision
+    xs = synth_clip(fb, ft, fh, fw, seed=seed, moving=True)[0].to(dev)
+    out = net(xs, flt)[0]
+    torch.cuda.synchronize()
+    par["stress"] = _fixture_parity(out, os.path.join(GOLDEN, fx[1]), "stress weights, %dx%d T=%d l_t=%d (a second engine, same kernel table)"
+                                    % (fw, fh, ft, flt))
+    del net, xs, out
+    par.update({"max_abs": max(v["max_abs"] for v in par.values()),
+                "rms_of_difference_over_rms": max(v["rms_of_difference_over_rms"] for v in par.values()),
+                "bound_max_abs": 1e-2, "bound_rms_of_difference_over_rms": 2e-2,
+                "vs": "the REAL reference's CPU forward (sub-sampled fixtures, tests/golden/make_golden.py); bf16 data path: the bound is "
+                      "DESIGN.md section 4's (not the fp32 contract's 1e-3)"})
+    return par
 
 
 ARITHMETIC = {
@@ -230,6 +286,7 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
         gflop_useful = USEFUL_GFLOP
         kernels = dict(KERNELS)
         elapsed, dev_ms, graphed = time_local(net, x, lt, steps, warmup)
+        timed_frames, LAST_FRAMES[0] = LAST_FRAMES[0], None
     finally:
         ops.X3_ENABLED, engine.FC2_CONV = saved
     secs = dev_ms * 1e-3 / steps
@@ -255,6 +312,13 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
     del net, x
     gc.collect()
     torch.cuda.empty_cache()
+    if precision == "bf16":
+        par = hq_parity(dev, model, H, W, t, precision, timed_frames)
+        if par is not None:
+            line["parity"] = par
+        del timed_frames
+        gc.collect()
+        torch.cuda.empty_cache()
     return line
 
 

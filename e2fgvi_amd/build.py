@@ -22,12 +22,16 @@ NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # attention_bf16.hip / conv_tail.hip (round 3, advisor): their fp32 VALU works on MFMA results and LDS data today, but both
 # units hold bf16 MFMA streams, so they are kept free of packed fp32 as well (measured neutral) -- a later epilogue edit that
 # touches VMEM-fresh registers then cannot re-enter the hazard silently; 200-launch bit-identity reruns in the GPU tests.
+# conv_wino.o / conv_wino4.o (round 6, advisor): the fp32 Winograd kernels build their A operands with VALU adds on patch words and
+# run wherever the kernel table (or a table miss, or E2FGVI_TILE_TABLE=0) names them -- encoder.layers.14 in front of the join
+# beside SPyNet's split-operand GEMM, the propagation split's side-stream layers beside the main stream's split-operand deformable
+# conv: they held 48-992 v_pk_{mul,add,fma}_f32 per kernel.  Both objects are built packed-free now and checked like the others.
 UNITS = [("error.hip", "error.o", []), ("conv.hip", "conv.o", []), ("conv.hip", "conv_nopk.o", NOPK + ["-DE2_NOPK_VARIANT"]),
-         ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", []), ("conv_wino.hip", "conv_wino_x3.o", NOPK + ["-DE2_WINO_X3=1"]), ("conv_wino4.hip", "conv_wino4.o", []), ("conv_tail.hip", "conv_tail.o", NOPK),
+         ("conv_bf16x.hip", "conv_bf16x.o", NOPK), ("conv_wino.hip", "conv_wino.o", NOPK), ("conv_wino.hip", "conv_wino_x3.o", NOPK + ["-DE2_WINO_X3=1"]), ("conv_wino4.hip", "conv_wino4.o", NOPK), ("conv_tail.hip", "conv_tail.o", NOPK),
          ("mdcn.hip", "mdcn.o", NOPK), ("attention.hip", "attention.o", []),
          ("attention_bf16.hip", "attention_bf16.o", NOPK), ("attention_x3.hip", "attention_x3.o", NOPK), ("misc.hip", "misc.o", NOPK),
          ("video.hip", "video.o", NOPK), ("metrics.hip", "metrics.o", NOPK)]
-NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "conv_wino_x3.o", "conv_tail.o", "mdcn.o", "attention_bf16.o", "attention_x3.o", "misc.o", "video.o", "metrics.o")
+NOPK_OBJECTS = ("conv_nopk.o", "conv_bf16x.o", "conv_wino.o", "conv_wino4.o", "conv_wino_x3.o", "conv_tail.o", "mdcn.o", "attention_bf16.o", "attention_x3.o", "misc.o", "video.o", "metrics.o")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 

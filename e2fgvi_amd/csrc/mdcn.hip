@@ -87,6 +87,21 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // thread that blends it, once per workgroup, the weights are packed as three bf16 planes whose sum is the fp32 weight, and six
 // of the nine bf16 partial products are accumulated (conv_bf16x.hip MODE 2): fp32-level rounding at 6 x 32 instead of 8 x 64
 // MFMA cycles per 16 k.  LDS images: A [3 planes][BM rows][32 k (+8 pad)], B [3 planes][4 k-octets][BN][8].
+// Static LDS of one mdcn_kernel instantiation in bytes: the ring (or the K groups' partial sums that reuse it, whichever is larger),
+// the unit table and the raw offset / mask slots.  The kernel sizes its arrays and launch_dcn() decides "fits / EUNSUP" from this
+// ONE expression (round 6, advisor: the guards counted the ring only while the kernel took max(ring, partial sums)).
+template <int BM, int BN, int WGM, int WGN, int KS, bool BF, bool X3>
+constexpr int mdcn_smem_floats() {
+    constexpr int NG = 64 * WGM * WGN, TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+    constexpr int STAGE = BF ? (X3 ? 3 : 1) * (BM * (32 + 8)) / 2 : BM * (32 + 4) + 32 * BN;
+    constexpr int RING = KS * 2 * STAGE, PARTS = (KS - 1) * NG * TM * TN * 16;
+    return RING > PARTS ? RING : PARTS;
+}
+template <int BM, int BN, int WGM, int WGN, int KS, bool BF, bool X3>
+constexpr bool mdcn_fits_lds() {
+    return mdcn_smem_floats<BM, BN, WGM, WGN, KS, BF, X3>() * 4 + MAX_UNITS * 8 * 4 + KS * 2 * (2 * BM) * 8 * 4 + 1024 <= 160 * 1024;
+}
+
 template <int BM, int BN, int WGM, int WGN, int KS, bool BF, bool S16, bool X3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnParams p) {
     static_assert(BF || !S16, "bf16 sources only with the bf16 MFMA slab");
@@ -105,8 +120,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void mdcn_kernel(const DcnPara
     constexpr int B_IT = BF ? 1 : (B_F4 + NG - 1) / NG;
     constexpr int STAGE = BF ? NP * (BM * LDA16) / 2 : BM * LDA + BK * BN;      // floats (bf16 products: the A slab only)
     constexpr unsigned OOB = 0xFFFFFFFFu;
-    constexpr int RING = KS * 2 * STAGE, PARTS = (KS - 1) * NG * TM * TN * 16;  // the K groups' partial sums reuse the ring
-    constexpr int SMEM_F = RING > PARTS ? RING : PARTS;
+    constexpr int SMEM_F = mdcn_smem_floats<BM, BN, WGM, WGN, KS, BF, X3>();     // ring; the K groups' partial sums reuse it
+    static_assert(SMEM_F >= KS * 2 * STAGE, "mdcn_smem_floats() and the kernel's stage layout disagree");
 
     __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
     __shared__ __attribute__((aligned(16))) int utab[MAX_UNITS * 8];
@@ -635,19 +650,25 @@ int launch_dcn(DcnParams& p, hipStream_t st, bool bf, bool s16, bool x3 = false)
     p.tilesN = cdiv(p.Cout, BN);
     if (x3) {
         // three bf16 planes per operand: two ring stages per K group must fit the LDS beside the offset slots
-        if constexpr (KS * 2 * 3 * (BM * (32 + 8)) * 2 + KS * 2 * 2 * BM * 32 + MAX_UNITS * 32 + 1024 <= 160 * 1024)
+        if constexpr (mdcn_fits_lds<BM, BN, WGM, WGN, KS, true, true>())
             hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
         else {
             e2fgvi_set_error("mdcn: this tile does not fit the LDS with split operands");
             return E2FGVI_EUNSUP;
         }
-    } else if (s16)
-        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
-    else if (bf)
-        hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
-    else {
+    } else if (s16 || bf) {
+        if constexpr (mdcn_fits_lds<BM, BN, WGM, WGN, KS, true, false>()) {
+            if (s16)
+                hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, true>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+            else
+                hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, true, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
+        } else {
+            e2fgvi_set_error("mdcn: this tile does not fit the LDS with bf16 operands");
+            return E2FGVI_EUNSUP;
+        }
+    } else {
         // fp32 MFMA: the weights are staged through LDS
-        if constexpr (KS * 2 * (BM * (32 + 4) + 32 * BN) * 4 + KS * 2 * 2 * BM * 32 + MAX_UNITS * 32 + 1024 <= 160 * 1024)
+        if constexpr (mdcn_fits_lds<BM, BN, WGM, WGN, KS, false, false>())
             hipLaunchKernelGGL((mdcn_kernel<BM, BN, WGM, WGN, KS, false, false>), dim3(p.tilesM * p.tilesN), dim3(64 * WGM * WGN * KS), 0, st, p);
         else {
             e2fgvi_set_error("mdcn: this tile does not fit the LDS with fp32 operands");

@@ -38,6 +38,8 @@ WIN = (5, 9)
 # With several clips per forward the batched encoder layers fill the chip on their own and the early join is 0.5 % ahead (8 clips: 974.7
 # vs 969.5 frames/s), so: 16 at one clip, 10 otherwise; E2FGVI_JOIN_AT overrides both.
 JOIN_AT = int(os.environ.get("E2FGVI_JOIN_AT", "0") or 0)
+if JOIN_AT not in (0, 10, 12, 14, 16, 18):
+    raise ValueError("E2FGVI_JOIN_AT=%d: the join sits in front of encoder.layers.10 / 12 / 14 / 16 or behind the encoder (18)" % JOIN_AT)
 PROP_SPLIT = os.environ.get("E2FGVI_PROP_SPLIT", "1") != "0"       # 0: conv_offset.0 / backbone.0 whole in every propagation step (A/B)
 
 
@@ -405,12 +407,15 @@ class Engine(BF16Path):
         x0 = e[3]([x], **lr)
         x = e[4]([x0], **lr)
         join_at = JOIN_AT or (16 if b == 1 else 10)
-        if join is not None and join_at <= 10:
+        joined = join is None
+        if not joined and join_at <= 10:
             join()
+            joined = True
         for k in (5, 6, 7, 8):
             x = e[k]([x0, x], **lr)
-            if join is not None and (join_at == 2 * k + 2 or (k == 8 and join_at > 18)):
+            if not joined and (join_at <= 2 * k + 2 or k == 8):        # never leave the encoder with the fork open
                 join()
+                joined = True
         return x                                            # [b*t, h, w, 128]
 
     # ------------------------------------------------------------------ propagation

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E2FGVI_LIB") or os.path.join(_HERE, "csrc", "libe2fgvi_hip.so")    # E2FGVI_LIB: A/B builds
 
+ABI_VERSION = 8        # the struct layouts / symbols below; csrc/error.hip e2fgvi_abi_version() must agree (checked in load())
 MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_DCNPOST = 0, 1, 2, 3, 4
 DT_F32, DT_BF16 = 0, 1
@@ -220,6 +221,11 @@ def load():
         fn.argtypes = args
         if args and args[-1] is _fp and res is C.c_int:      # asynchronous launch on a stream
             setattr(lib, name, _traced(name, fn))
+    have = int(lib.e2fgvi_abi_version())
+    if have != ABI_VERSION:
+        # a stale build (or an E2FGVI_LIB A/B library of another round) would read the descriptors with another layout
+        raise HipLibraryMissing("%s implements ABI version %d, this binding is version %d: rebuild it (python -m e2fgvi_amd.build)"
+                                % (LIB_PATH, have, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -85,6 +85,12 @@ def test_default_line_carries_the_hq_configs(dev):
     assert "1080" in hq1080["metric"] and "T=20" in hq1080["metric"] and hq1080["dtype"] == "bf16" and hq1080["value"] > 10
     for s in (hq720, hq1080):
         assert s["roofline"]["peak"] == 2500.0 and 0 < s["roofline"]["frac"] < 1 and s["config"]["hip_graph"] is True
+        # round 6: the bf16 lines carry their parity against the REAL reference's fixtures (the timed engine's frames on the timed
+        # clip at 720x1296 T=10; a stress-weights clip at the line's resolution and T = 10 / 8)
+        p = s["parity"]
+        assert 0 < p["max_abs"] <= p["bound_max_abs"] == 1e-2 and 0 < p["rms_of_difference_over_rms"] <= 2e-2, p
+        assert p["stress"]["fixture"].startswith("tests/golden/g") and p["stress"]["rms_of_reference"] > 0.05
+    assert hq720["parity"]["default"]["fixture"].endswith("benchclip.npz")
 
 
 def test_bench_line_carries_its_own_parity(dev):

@@ -282,7 +282,12 @@ def test_bf16_path_end_to_end(dev, model, hw, t, lt):
     assert torch.equal(got, got2), "bf16 path is not deterministic (two streams)"
 
 
-@pytest.mark.parametrize("fixture", ["g5_hq_stress_720x1296_t3_lt2.npz", "g6_hq_stress_1080x1944_t2_lt2.npz", "g3_hq_stress_120x216_t4_lt3.npz"])
+@pytest.mark.parametrize("fixture", ["g5_hq_stress_720x1296_t3_lt2.npz", "g6_hq_stress_1080x1944_t2_lt2.npz", "g3_hq_stress_120x216_t4_lt3.npz",
+                                     # round 6: the clip lengths the bf16 bench lines are timed at (configs[3]: 720x1296 T = l_t = 10; configs[4]'s
+                                     # resolution with an 8-step recurrence), the bench clip itself, and the peaked weights
+                                     "g9_hq_stress_720x1296_t10_lt10.npz", "g10_hq_stress_1080x1944_t8_lt8.npz",
+                                     "g14_hq_default_720x1296_t10_lt10_benchclip.npz", "g12_hq_peaked_240x432_t6_lt4.npz",
+                                     "g13_hq_peaked_720x1296_t4_lt3.npz"])
 def test_bf16_path_against_reference_golden(dev, fixture):
     """The bf16 data path at the BASELINE HQ resolutions (720x1296: 12x12 window grid, 1080x1944: 18x18) against the
     sub-sampled outputs of the REAL reference (tests/golden/make_golden.py) -- the same bound as at the small sizes
@@ -291,15 +296,13 @@ def test_bf16_path_against_reference_golden(dev, fixture):
     import importlib
     import os
     import numpy as np
-    from e2fgvi_amd.synth import synth_clip, synth_state_dict
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
-    H, W, t, lt, b, seed, so, sf = [int(v) for v in z["meta"]]
-    model, kind = str(z["model"]), str(z["kind"])
+    from e2fgvi_amd.synth import synth_state_dict
+    from tests.util import golden_case
+    z, model, kind, x, lt, so, sf = golden_case(os.path.join(os.path.dirname(__file__), "golden", fixture))
     net = importlib.import_module("model." + model).InpaintGenerator()
     net.load_state_dict(synth_state_dict(model, kind, 0))
     net = net.to(dev).eval()
     net.precision = "bf16"
-    x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
     out, (ff, fb) = net(x.to(dev), lt)
     out, ff, fb = out.cpu(), ff.cpu(), fb.cpu()
     diff = out[:, :, ::so, ::so].numpy() - z["out_sub"]

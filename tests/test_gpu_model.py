@@ -146,7 +146,10 @@ E2E = [("e2fgvi", "stress", (240, 432), 3, 3, 1), ("e2fgvi", "default", (240, 43
        # propagation; and two clips of it
        ("e2fgvi", "stress", (240, 432), 10, 5, 1), ("e2fgvi", "default", (240, 432), 10, 5, 1), ("e2fgvi", "stress", (240, 432), 10, 5, 2),
        # a single local frame (test.py on a 1-frame video): empty flow tensors, propagation without neighbours
-       ("e2fgvi_hq", "stress", (60, 108), 3, 1, 1), ("e2fgvi", "stress", (240, 432), 1, 1, 1)]
+       ("e2fgvi_hq", "stress", (60, 108), 3, 1, 1), ("e2fgvi", "stress", (240, 432), 1, 1, 1),
+       # round 6: the "peaked" weights (synth.py): sharp attention (mean largest probability 0.5-0.7), residual DCN offsets at the
+       # +-10 px tanh limit, saturated masks, non-uniform pool_layers -- the stand-in for trained weights
+       ("e2fgvi", "peaked", (240, 432), 5, 3, 1), ("e2fgvi_hq", "peaked", (120, 216), 4, 3, 1), ("e2fgvi", "peaked", (240, 432), 10, 5, 1)]
 
 
 @pytest.mark.parametrize("model,kind,hw,t,lt,b", E2E)
@@ -183,21 +186,20 @@ import os
 
 import numpy as np
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g[0-9]_*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "g[0-9]*_*.npz")),
+              key=lambda q: int(os.path.basename(q).split("_")[0][1:]))
 
 
 @pytest.mark.parametrize("path", GOLD, ids=os.path.basename)
 def test_hip_matches_reference_golden(dev, path):
     """HIP forward vs sub-sampled outputs of the REAL reference (tests/golden/make_golden.py), <= 1e-3."""
     import importlib
-    from e2fgvi_amd.synth import synth_clip, synth_state_dict
-    z = np.load(path)
-    H, W, t, lt, b, seed, so, sf = [int(v) for v in z["meta"]]
-    model, kind = str(z["model"]), str(z["kind"])
+    from e2fgvi_amd.synth import synth_state_dict
+    from tests.util import golden_case
+    z, model, kind, x, lt, so, sf = golden_case(path)
     net = importlib.import_module("model." + model).InpaintGenerator()
     net.load_state_dict(synth_state_dict(model, kind, 0))
     net = net.to(dev).eval()
-    x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
     out, (ff, fb) = net(x.to(dev), lt)
     out, ff, fb = out.cpu(), ff.cpu(), fb.cpu()
     d = np.abs(out[:, :, ::so, ::so].numpy() - z["out_sub"]).max()

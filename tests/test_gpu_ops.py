@@ -645,3 +645,41 @@ def test_conv3x3_winograd_argument_errors(dev):
         layer([torch.randn(1, 15, 16, 16, device=dev)])                                               # odd H
     with pytest.raises(HipError):
         layer([torch.randn(1, 16, 16, 16, device=dev)], tile=48)                                      # unknown tile code
+
+
+def test_fusion_layer_in_place_over_its_residual(dev):
+    """engine.propagate runs the 1x1 fusion layer with out == residual (feat_prop.py:139-146: stack(fusion(cat(bwd, fwd))) + x, the
+    sum written over x).  That is only sound if every kernel the layer can be handed to reads a residual element in the thread that
+    writes it, before it writes it (advisor, round 5): every candidate -- the implicit GEMM's tiles, the LDS-DMA fp32 kernel's,
+    the split-operand GEMM's -- is run aliased and compared bit for bit with its own out-of-place result."""
+    from e2fgvi_amd import ops
+    g = _gen(4242)
+    w = torch.randn(128, 256, 1, 1, generator=g) / 16
+    b = torch.randn(128, generator=g) * 0.1
+    s0 = torch.randn(10, 60, 108, 128, generator=g).to(dev)
+    s1 = torch.randn(10, 60, 108, 128, generator=g).to(dev)
+    res = torch.randn(10, 60, 108, 128, generator=g).to(dev)
+    layers = [("igemm", ops.PackedConv(w.to(dev), b.to(dev), [128, 128]), ops.TUNE_CANDIDATES),
+              ("f32x", ops.PackedConvX(w.to(dev), b.to(dev), [128, 128], dtype=torch.float32), ops.XTUNE_CANDIDATES),
+              ("f32x3", ops.PackedConvX(w.to(dev), b.to(dev), [128, 128], dtype=torch.float32, x3=True), ops.XTUNE_CANDIDATES)]
+    ran = 0
+    for name, layer, tiles in layers:
+        for tile in tiles:
+            try:
+                ref = layer([s0, s1], residual=res, tile=tile)
+            except Exception:                      # a tile this shape does not admit
+                continue
+            io = res.clone()
+            layer([s0, s1], residual=io, out=io, tile=tile)
+            torch.cuda.synchronize()
+            assert torch.equal(io, ref), (name, tile, float((io - ref).abs().max()))
+            ran += 1
+    assert ran >= 12, ran
+    # ... and what the layer of the engine itself picks (table decision) at one clip
+    auto = ops.PackedConv(w.to(dev), b.to(dev), [128, 128])
+    auto.try_x3 = True
+    auto.tune = True
+    ref = auto([s0, s1], residual=res)
+    io = res.clone()
+    auto([s0, s1], residual=io, out=io)
+    assert torch.equal(io, ref)

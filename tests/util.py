@@ -108,3 +108,19 @@ def timed_tuning():
         ops._TUNED.update(tuned)
         ops._NEAREST.clear()
         ops._NEAREST.update(nearest)
+
+
+def golden_case(path):
+    """(npz, model, weights kind, clip, l_t, out stride, flow stride) of a fixture of tests/golden/make_golden.py: the clip is rebuilt
+    from the seed in `meta` exactly as the generator built it (fixtures named *benchclip* hold bench.py's own clip: static box,
+    unsmoothed noise)."""
+    import os
+    import numpy as np
+    from e2fgvi_amd.synth import synth_clip
+    z = np.load(path)
+    H, W, t, lt, b, seed, so, sf = [int(v) for v in z["meta"]]
+    if "benchclip" in os.path.basename(path):
+        x, _ = synth_clip(b, t, H, W, seed=seed, smooth=False)
+    else:
+        x, _ = synth_clip(b, t, H, W, seed=seed, moving=True)
+    return z, str(z["model"]), str(z["kind"]), x, lt, so, sf
