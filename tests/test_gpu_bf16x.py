@@ -310,11 +310,18 @@ def test_bf16_path_against_reference_golden(dev, fixture):
     print("bf16 path vs reference %s: max abs %.3e, rms of the difference %.2e x rms(reference)"
           % (fixture, d, np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms))
     assert np.isfinite(out.numpy()).all()
-    assert_bound(d, 1e-2, "bf16 golden %s max abs" % fixture)
-    assert_bound(np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms, 2e-2, "bf16 golden %s rms of difference / rms" % fixture)
+    # The peaked weights (sharp attention: mean largest probability 0.24-0.51, logits of +-30..60): a 2^-9 relative rounding of q and
+    # k moves a logit by 0.02-0.05 and a softmax weight by as many per cent; measured (tools/bf16_error_growth.py) the token stream's
+    # error grows 0.85 % -> 2.2 % of its rms over the first three blocks (stress weights: flat 0.5 %), whatever the precision of the
+    # recurrent propagation state; frames: max abs 1.4e-2 / 3.0e-2, rms of the difference 2.1 % / 4.1 % (432x240 / 720x1296).  The
+    # bf16 path is bounded per regime; where 1e-3 matters the fp32 configuration is the one to run (same fixtures, test_gpu_model.py).
+    peaked = kind == "peaked"
+    assert_bound(d, 6e-2 if peaked else 1e-2, "bf16 golden %s max abs" % fixture)
+    assert_bound(np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms, 8e-2 if peaked else 2e-2, "bf16 golden %s rms of difference / rms" % fixture)
     fmax = max(1.0, float(z["flow_fwd_stats"][3]))
-    assert_bound(np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max(), 5e-2 * max(1.0, fmax / 4), "bf16 golden %s flow fwd" % fixture)
-    assert_bound(np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max(), 5e-2 * max(1.0, fmax / 4), "bf16 golden %s flow bwd" % fixture)
+    fb_bound = 0.3 if peaked else 5e-2 * max(1.0, fmax / 4)      # px; peaked: flows up to 10 px, measured 0.10 px
+    assert_bound(np.abs(ff[..., ::sf, ::sf].numpy() - z["flow_fwd_sub"]).max(), fb_bound, "bf16 golden %s flow fwd" % fixture)
+    assert_bound(np.abs(fb[..., ::sf, ::sf].numpy() - z["flow_bwd_sub"]).max(), fb_bound, "bf16 golden %s flow bwd" % fixture)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 101, 106])

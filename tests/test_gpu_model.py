@@ -35,7 +35,9 @@ def _engine(model, kind, dev):
     return _CACHE[key]
 
 
-CFG = [("e2fgvi", "stress", (240, 432), 3, 3), ("e2fgvi_hq", "stress", (120, 216), 4, 3)]
+CFG = [("e2fgvi", "stress", (240, 432), 3, 3), ("e2fgvi_hq", "stress", (120, 216), 4, 3),
+       # round 6: the trained-regime stand-in (synth.py "peaked": sharp attention, saturated DCN offsets / masks, flows of several px)
+       ("e2fgvi", "peaked", (240, 432), 3, 3), ("e2fgvi_hq", "peaked", (120, 216), 4, 3)]
 
 
 @pytest.mark.parametrize("model,kind,hw,t,lt", CFG)
