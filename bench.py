@@ -127,9 +127,10 @@ def cpu_baseline(sd, model, H, W, t, lt, hip_out=None, stress=None):
     clip on a CPU, there the sample is one un-warmed forward of a 2-frame clip of the same resolution.
     hip_out: the frames the TIMED configuration (same clip, same weights, the timed kernels) produced -- the oracle's output of
     the first forward is compared with them and returned as the second value: the bench line carries its own parity.
-    stress: (state_dict, hip frames) of the same clip under the stress weights of SURVEY.md 8(c) T3 (O(1) activations, non-zero
-    conv_offset[-1]: real DCN offsets and masks) -- one more oracle forward, compared the same way (round 5: at default init
-    conv_offset[-1] == 0 makes offsets = flow and mask = 0.5, a regime in which a 1e-3 absolute bound is weak)."""
+    stress: {kind: (state_dict, hip frames)} of the same clip under the stress weights of SURVEY.md 8(c) T3 (O(1) activations, non-zero
+    conv_offset[-1]: real DCN offsets and masks) and, round 6, the peaked weights (synth.py: sharp attention, saturated offsets) --
+    one more oracle forward each, compared the same way (round 5: at default init conv_offset[-1] == 0 makes offsets = flow and
+    mask = 0.5, a regime in which a 1e-3 absolute bound is weak)."""
     from e2fgvi_amd.synth import synth_clip
     from oracle import e2fgvi_oracle as O
     host = os.cpu_count() or 1
@@ -148,17 +149,21 @@ def cpu_baseline(sd, model, H, W, t, lt, hip_out=None, stress=None):
         times.append(time.perf_counter() - t0)
         if k == 0 and hip_out is not None and tuple(hip_out.shape) == tuple(ref.shape):
             parity = {"default": _parity(hip_out, ref, "reference's init_weights distribution (the timed weights)")}
-    if parity is not None and stress is not None:
-        ref, _ = O.forward(stress[0], x, ls, model)
-        if tuple(stress[1].shape) == tuple(ref.shape):
-            parity["stress"] = _parity(stress[1], ref, "stress weights (synth_state_dict 'stress': O(1) activations, non-zero "
-                                                       "conv_offset[-1], random sc.bias; SURVEY.md 8c T3)")
+    what = {"stress": "stress weights (synth_state_dict 'stress': O(1) activations, non-zero conv_offset[-1], random sc.bias; "
+                      "SURVEY.md 8c T3)",
+            "peaked": "peaked weights (synth_state_dict 'peaked', the stand-in for trained weights: mean largest attention "
+                      "probability 0.24-0.51, 46 % of the residual DCN offsets beyond +-9 px, saturated masks, non-uniform pool_layers, "
+                      "flows up to 10 px)"}
+    for kind, (sd_k, frames_k) in (stress or {}).items() if parity is not None else ():
+        ref, _ = O.forward(sd_k, x, ls, model)
+        if tuple(frames_k.shape) == tuple(ref.shape):
+            parity[kind] = _parity(frames_k, ref, what[kind])
     if parity is not None:
         parity.update({"max_abs": max(v["max_abs"] for v in parity.values()),
                        "max_abs_over_rms": max(v["max_abs_over_rms"] for v in parity.values()), "bound_max_abs": 1e-3,
                        "vs": "oracle port (oracle/e2fgvi_oracle.py, torch CPU fp32) on the timed clip; the HIP frames are those of the "
                              "timed configuration (same engine class, same kernel decisions as config.kernels; `default` = the very "
-                             "engine / HIP graph that was timed, `stress` = a second engine on the same clip)"})
+                             "engine / HIP graph that was timed, `stress` / `peaked` = further engines on the same clip)"})
     timed = times[1:] if small else times
     dt = statistics.median(timed)
     return {"value": round(ts / dt, 4), "unit": "frames/s", "cores": cores, "host_cores": host, "kind": "port",
@@ -559,14 +564,16 @@ def main():
             hip_frames = (hip_frames if hip_frames is not None else net(x, lt)[0])[:t].float().cpu() if not step.pack_u8 else None
             stress = None
             if hip_frames is not None and (H, W) == (240, 432):
-                # the same clip under the stress weights: a second engine, the same (table-driven) kernel decisions
-                sd_s = synth_state_dict(args.model, "stress", 0)
-                net_s = importlib.import_module("model." + args.model).InpaintGenerator()
-                net_s.load_state_dict(sd_s)
-                net_s = net_s.to(dev).eval()
-                net_s.precision = args.precision
-                stress = (sd_s, net_s(x[:1], lt)[0][:t].float().cpu())
-                del net_s
+                # the same clip under the stress and the peaked weights: a second / third engine, the same (table-driven) kernel decisions
+                stress = {}
+                for kind in ("stress", "peaked"):
+                    sd_s = synth_state_dict(args.model, kind, 0)
+                    net_s = importlib.import_module("model." + args.model).InpaintGenerator()
+                    net_s.load_state_dict(sd_s)
+                    net_s = net_s.to(dev).eval()
+                    net_s.precision = args.precision
+                    stress[kind] = (sd_s, net_s(x[:1], lt)[0][:t].float().cpu())
+                    del net_s
             out["cpu_baseline"], parity = cpu_baseline(sd, args.model, H, W, t, lt, hip_out=hip_frames, stress=stress)
             if parity is not None:
                 out["parity"] = parity

@@ -98,10 +98,10 @@ def test_bench_line_carries_its_own_parity(dev):
     (`parity`), and bench.py exits non-zero above the north-star bound"""
     j = _bench("--steps", "3", "--warmup", "1", "--no-secondary")
     p = j["parity"]
-    assert p["bound_max_abs"] == 1e-3 and 0 <= p["max_abs"] <= 1e-3 and p["max_abs_over_rms"] <= 2e-4, p
+    assert p["bound_max_abs"] == 1e-3 and 0 <= p["max_abs"] <= 1e-3 and p["max_abs_over_rms"] <= 2e-3, p
     # round 5: the default-init weights (conv_offset[-1] == 0: offsets = flow, mask = 0.5) AND the stress weights
-    for k in ("default", "stress"):
-        assert 0 <= p[k]["max_abs"] <= 1e-3 and p[k]["max_abs_over_rms"] <= 2e-4, (k, p[k])
+    for k in ("default", "stress", "peaked"):       # round 6: three weight regimes on the line
+        assert 0 <= p[k]["max_abs"] <= 1e-3 and p[k]["max_abs_over_rms"] <= (2e-3 if k == "peaked" else 2e-4), (k, p[k])
     assert p["stress"]["rms_of_reference"] > 10 * p["default"]["rms_of_reference"]
     # the traffic figure is this library's or absent (never another build's)
     assert j["library_sha16"] and (j["roofline"]["traffic"] is None or j["library_sha16"] in j["roofline"]["traffic_note"])
