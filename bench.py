@@ -175,11 +175,11 @@ def cpu_baseline(sd, model, H, W, t, lt, hip_out=None, stress=None):
                          "one un-warmed forward (%.1f s)" % dt, ts)}, parity
 
 
-def time_local(net, x, lt, steps, warmup, use_graph=True):
+def time_local(net, x, lt, steps, warmup, use_graph=True, in_flight=1):
     """`steps` forwards of this GPU's clips replayed from a HIP graph, no collective: (wall seconds, device ms, graphed)"""
     from e2fgvi_amd import runner
-    step = runner.ShardedStep(net, x, lt, group_world=1, use_graph=use_graph)
-    for _ in range(max(warmup, 2)):                   # the second call captures the graph
+    step = runner.ShardedStep(net, x, lt, group_world=1, use_graph=use_graph, in_flight=in_flight)
+    for _ in range(max(warmup, 2 if in_flight == 1 else 2 + in_flight)):       # the second call captures the graph(s)
         step.run()
     step.finish()
     torch.cuda.synchronize()
@@ -260,16 +260,18 @@ ARITHMETIC = {
             "token residual stream and the output frames stay fp32 (DESIGN.md 1b)",
 }
 
-SECONDARY = [   # (label, model, H, W, clips, t, l_t, precision, x3, steps, warmup)
+SECONDARY = [   # (label, model, H, W, clips, t, l_t, precision, x3, steps, warmup[, forwards in flight])
     ("BASELINE.json configs[1] with E2FGVI_X3=0: every fp32 layer on fp32 MFMA (no split-operand kernels)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", False, 10, 2),
     ("SURVEY.md 8(d) C2 second split: T=10 with 5 local + 5 reference frames (configs/train_e2fgvi.json:9-10)", "e2fgvi", 240, 432, 1, 10, 5, "fp32", True, 10, 2),
     ("BASELINE.json configs[2] per-GPU work on ONE GPU: 8 clips per forward, no collective (the N = 1 point of the 8-GPU job)", "e2fgvi", 240, 432, 8, 10, 10, "fp32", True, 5, 2),
+    ("BASELINE.json configs[1] with THREE forwards in flight (three HIP graphs of the one-clip forward replayed round-robin on three "
+     "streams: runner.ShardedStep(in_flight=3); the headline replays one graph back to back)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", True, 30, 5, 3),
     ("BASELINE.json configs[3]", "e2fgvi_hq", 720, 1296, 1, 10, 10, "bf16", True, 20, 3),
     ("BASELINE.json configs[4] (one GPU's clip)", "e2fgvi_hq", 1080, 1944, 1, 20, 20, "bf16", True, 5, 2),
 ]
 
 
-def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warmup):
+def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warmup, in_flight=1):
     """One more configuration timed in the same process after the headline (inputs resident, HIP-graph replay)."""
     import gc
     import importlib
@@ -290,7 +292,7 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
         gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
         gflop_useful = USEFUL_GFLOP
         kernels = dict(KERNELS)
-        elapsed, dev_ms, graphed = time_local(net, x, lt, steps, warmup)
+        elapsed, dev_ms, graphed = time_local(net, x, lt, steps, warmup, in_flight=in_flight)
         timed_frames, LAST_FRAMES[0] = LAST_FRAMES[0], None
     finally:
         ops.X3_ENABLED, engine.FC2_CONV = saved
@@ -299,7 +301,7 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
     arith = "bf16" if precision == "bf16" else ("fp32+x3" if x3 and saved[0] else "fp32")
     line = {"config": {"workload": "%s: %s %dx%d T=%d l_t=%d, %d clip(s) per forward on one GPU, random-init weights, torch.rand "
                                    "frames + box mask (SURVEY.md 8d)" % (label, model, W, H, t, lt, b),
-                       "precision": precision, "arithmetic": ARITHMETIC[arith], "hip_graph": graphed},
+                       "precision": precision, "arithmetic": ARITHMETIC[arith], "hip_graph": graphed, "forwards_in_flight": in_flight},
             "metric": "inpainted frames/sec at %dx%d T=%d" % (W, H, t), "value": round(b * t * steps / elapsed, 3), "unit": "frames/s",
             "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
             "dtype": "f32" if precision == "fp32" else "bf16",
@@ -342,6 +344,9 @@ def main():
     ap.add_argument("--gather", default="u8", choices=("u8", "f32"), help="dtype of the frames in the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="forwards in flight on one GPU (runner.ShardedStep(in_flight=K): K HIP graphs replayed round-robin on K "
+                         "streams); default 1 = one graph replayed back to back (the headline); ignored with a gather")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (self-test)")
     ap.add_argument("--no-dominant-probe", action="store_true",
                     help="skip the 21 extra launches of encoder.layers.10 behind the timed region (PMC passes count whole processes: "
@@ -424,8 +429,8 @@ def main():
 
     # the forward replays from a HIP graph in every mode; the collective stays outside the graph (runner.ShardedStep)
     step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=not args.no_graph, force_gather=args.force_dist,
-                              pack_u8=(dist is not None and args.gather == "u8"))
-    for _ in range(max(args.warmup, 2)):        # at least two untimed steps: the second one captures the HIP graph
+                              pack_u8=(dist is not None and args.gather == "u8"), in_flight=args.in_flight if dist is None else 1)
+    for _ in range(max(args.warmup, 2 if step.in_flight == 1 else 2 + step.in_flight)):   # the second untimed step captures the HIP graph(s)
         step.run()
     step.finish()
     torch.cuda.synchronize()
@@ -477,7 +482,7 @@ def main():
                                         "e2fgvi_amd/tile_table.py (checked in, deterministic: ops.py)"),
                    "parallelism": "clip-shard x%d + all-gather of the %s frames" % (world, args.gather) if dist is not None
                                   else "single GPU, no collective",
-                   "hip_graph": bool(step.graphed)},
+                   "hip_graph": bool(step.graphed), "forwards_in_flight": step.in_flight},
         "roofline": {"bound": "mfma", "achieved": round(tf_iss, 3), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(tf_iss / peak, 4), "frac_useful": round(gflop_useful / secs / 1e3 / peak, 4),
                      "achieved_algorithmic": round(tf_alg, 3), "effective_peak": round(eff_peak, 1),

@@ -48,10 +48,19 @@ class ShardedStep:
     two staging buffers, the all-gather of that buffer is issued asynchronously (RCCL's own stream) and runs under step
     k+1's forward; ``run()`` returns the gathered frames of the PREVIOUS step (None on the first call) and ``finish()``
     those of the last one; a returned buffer is valid until the next ``run()`` (two gather buffers alternate).
-    Without a gather ``run()`` / ``finish()`` return this step's frames directly."""
+    Without a gather ``run()`` / ``finish()`` return this step's frames directly.
 
-    def __init__(self, net, x, lt, group_world=1, use_graph=True, force_gather=False, pack_u8=False, group=None):
+    in_flight = K > 1 (without a gather; round 6): K HIP graphs of the same forward, each with its own static buffers and its own
+    stream, replayed round-robin -- step n + 1 starts while step n is still in its latency-bound propagation chain (the engine's
+    state is read-only under replay: weights, key tables, zero buffers).  ``run()`` then returns the frames of the step issued
+    K - 1 calls earlier (None for the first K - 1 calls), valid until the next ``run()``; ``finish()`` drains the pipelines and
+    returns the last step's frames.  Ordering: a pipeline's replay waits for everything the caller has enqueued on the current
+    stream so far (the consumer of the buffer it is about to overwrite), the current stream waits for the step it hands out."""
+
+    def __init__(self, net, x, lt, group_world=1, use_graph=True, force_gather=False, pack_u8=False, group=None, in_flight=1):
         self.net, self.x, self.lt, self.world = net, x, lt, group_world
+        self.in_flight = max(1, int(in_flight))
+        self._pipes = None         # in_flight > 1: [(graph, static output, stream, event)]
         self.gather = group_world > 1 or force_gather
         self.pack_u8, self.group = pack_u8, group
         self.graph = None
@@ -104,7 +113,38 @@ class ShardedStep:
         if ops.sync_tile_decisions(self.group) and ops._TUNED != mine:
             self.out = self._forward()
 
+    def _run_pipelined(self):
+        if self._pipes is None:
+            keep = (self.graph, self.out)
+            pipes = []
+            for _ in range(self.in_flight):
+                self.graph = None
+                self._capture()
+                if self.graph is None:                 # capture unsupported: sequential eager steps
+                    self.in_flight, self.graph, self.out = 1, None, keep[1]
+                    return self.run()
+                pipes.append([self.graph, self.out, torch.cuda.Stream(), torch.cuda.Event(), False])
+            self._pipes, self._issued = pipes, 0
+        K, n = self.in_flight, self._issued
+        cur = torch.cuda.current_stream()
+        g, out, st, ev, _ = self._pipes[n % K]
+        st.wait_stream(cur)                            # the consumer of the buffer this replay overwrites
+        with torch.cuda.stream(st):
+            g.replay()
+            ev.record(st)
+        self._pipes[n % K][4] = True
+        self._issued = n + 1
+        self._calls += 1
+        oldest = self._pipes[(n + 1) % K]
+        if not oldest[4]:
+            return None
+        cur.wait_event(oldest[3])
+        self._last = self.out = oldest[1]
+        return oldest[1]
+
     def run(self):
+        if self.in_flight > 1 and not self.gather and self.use_graph and self._calls >= 1:
+            return self._run_pipelined()
         if self.use_graph and self.graph is None and self._calls >= 1:
             self._capture()
         self._calls += 1
@@ -139,7 +179,14 @@ class ShardedStep:
         return prev[1]
 
     def finish(self):
-        """Frames of the last step (all ranks' frames when gathering); waits for the gather in flight."""
+        """Frames of the last step (all ranks' frames when gathering); waits for the gather / the pipelines in flight."""
+        if self._pipes is not None and self._issued:
+            cur = torch.cuda.current_stream()
+            for p in self._pipes:
+                if p[4]:
+                    cur.wait_event(p[3])
+            self._last = self.out = self._pipes[(self._issued - 1) % self.in_flight][1]
+            return self._last
         if self._pending is not None:
             work, buf = self._pending
             work.wait()

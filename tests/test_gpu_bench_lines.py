@@ -75,8 +75,10 @@ def test_default_line_carries_the_hq_configs(dev):
     assert "split operands" in j["config"]["arithmetic"] and j["config"]["kernel_selection"].startswith("e2fgvi_amd/tile_table.py")
     assert "encoder.layers.10" in j["config"]["kernels"] and j["peak_memory_gb"] > 0
     sec = j["secondary"]
-    assert len(sec) == 5 and all("error" not in s for s in sec), sec
-    x30, lt5, c8, hq720, hq1080 = sec
+    assert len(sec) == 6 and all("error" not in s for s in sec), sec
+    x30, lt5, c8, fl3, hq720, hq1080 = sec
+    # round 6: three forwards in flight (three graphs on three streams) -- same clip, same kernels, more of the chip busy
+    assert fl3["config"]["forwards_in_flight"] == 3 and j["config"]["forwards_in_flight"] == 1 and fl3["value"] > 0.97 * j["value"]
     assert "E2FGVI_X3=0" in x30["config"]["workload"] and x30["dtype"] == "f32" and "fp32 MFMA" in x30["config"]["arithmetic"]
     assert not any("x3" in k for k in x30["config"]["kernels"].values()), x30["config"]["kernels"]
     assert "l_t=5" in lt5["config"]["workload"] and lt5["value"] > 30

@@ -133,3 +133,30 @@ def test_forced_gather_soak_of_the_eight_clip_step_is_bit_identical(dev):
         assert step.graphed and bad == 0, "%d of 51 pipelined steps differ from the plain forward" % bad
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,hw,t,lt,k,precision", [("e2fgvi", (240, 432), 10, 10, 3, "fp32"), ("e2fgvi", (240, 432), 6, 3, 2, "fp32"),
+                                                        ("e2fgvi_hq", (120, 216), 4, 3, 3, "bf16")])
+def test_forwards_in_flight_return_the_bits_of_the_serial_forward(dev, model, hw, t, lt, k, precision):
+    """runner.ShardedStep(in_flight=K), round 6: K HIP graphs of the same forward on K streams, any kernel of one beside any kernel
+    of another -- every step must return the bits of the single-stream forward (60 steps), in the order the steps were issued"""
+    import importlib
+    from e2fgvi_amd import runner
+    from e2fgvi_amd.synth import synth_clip, synth_state_dict
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(synth_state_dict(model, "stress", 0))
+    net = net.to(dev).eval()
+    net.precision = precision
+    x = synth_clip(1, t, hw[0], hw[1], seed=31, moving=True)[0].to(dev)
+    ref = net(x, lt)[0].clone()
+    step = runner.ShardedStep(net, x, lt, in_flight=k)
+    got, none = 0, 0
+    for n in range(60):
+        out = step.run()
+        if out is None:
+            none += 1
+            continue
+        assert torch.equal(out, ref), "step %d of %d in flight differs from the serial forward" % (n, k)
+        got += 1
+    assert torch.equal(step.finish(), ref)
+    assert step.graphed and step.in_flight == k and none <= k and got >= 60 - k - 1
