@@ -279,7 +279,7 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
     from e2fgvi_amd.synth import synth_clip, synth_state_dict
     saved = (ops.X3_ENABLED, engine.FC2_CONV)
     if precision == "fp32" and not x3:
-        ops.X3_ENABLED, engine.FC2_CONV = False, os.environ.get("E2FGVI_FC2_CONV_FP32", "0") != "0"
+        ops.X3_ENABLED, engine.FC2_CONV = False, False
     try:
         net = importlib.import_module("model." + model).InpaintGenerator()
         net.load_state_dict(synth_state_dict(model, "default", 0))

@@ -162,10 +162,9 @@ def check_kernel_waits(obj, name, ins):
             if off < 0 and tgt in addr_to_idx:
                 spans.append((addr_to_idx[tgt], i))
     loops = 0
-    # kernels that opt in to other wait disciplines, by (mangled) name:
-    #   conv_wino_kernel<..., DMA = true, X3 = true> fetches TWO trips ahead (its wait carries two inter-wait intervals);
-    #   conv_wino_x3w_kernel reloads its single-buffered weight planes in place and claims them group by group (below)
-    two_ahead = re.search(r"conv_wino_kernelILi\d+ELi\d+ELi\d+ELb1ELb1E", name) is not None
+    # a kernel that opts in to another wait discipline, by (mangled) name: conv_wino_x3w_kernel reloads its single-buffered weight
+    # planes in place and claims them group by group (below).  (Round 3's two-trips-ahead LDS-DMA variant of conv_wino_kernel and
+    # its rule left with the kernel in round 6.)
     rolling = "conv_wino_x3w_kernel" in name
     for lo, hi in spans:
         inner = [m for m in marks if lo <= m <= hi]
@@ -197,16 +196,6 @@ def check_kernel_waits(obj, name, ins):
             else:                                       # over the back edge: tail of the loop + its head
                 rng = list(range(inner[-1] + 2, hi + 1)) + list(range(lo, m))
             cnt = sum(1 for k in rng if vmem.match(ins[k][1]))
-            if cnt != n and two_ahead:
-                # a kernel that fetches TWO trips ahead (conv_wino.hip, X3 + LDS-DMA): its wait carries the loads of the two
-                # preceding inter-wait intervals (cyclically)
-                jj = (j - 1) % len(inner)
-                if jj:
-                    rng2 = range(inner[jj - 1] + 2, inner[jj])
-                else:
-                    rng2 = list(range(inner[-1] + 2, hi + 1)) + list(range(lo, inner[0]))
-                if cnt + sum(1 for k in rng2 if vmem.match(ins[k][1])) == n:
-                    continue
             if cnt != n:
                 raise RuntimeError("%s: %s: explicit s_waitcnt vmcnt(%d) at 0x%x follows %d vector-memory instructions "
                                    "since the previous explicit wait" % (obj, name[:60], n, ins[m][0], cnt))

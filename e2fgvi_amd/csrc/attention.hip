@@ -585,11 +585,9 @@ extern "C" int e2fgvi_focal_attention(const float* qkv, const float* kv_pool, co
     if (ks == 0) ks = ((long long)grid.x * grid.y * grid.z < 384) ? 2 : 1;     // < 1.5 workgroups per CU: split the keys
     block = dim3(64 * waves * ks);
     {
-        static int env_v1 = -1;
-        if (env_v1 < 0) { const char* e = getenv("E2FGVI_ATT32_V1"); env_v1 = (e && atoi(e)) ? 1 : 0; }
         const size_t dyn = (size_t)cdiv(T * SLOTS, TK * ks) * ks * TK * 4;
         const bool fits = one && hi_end < 0xFFFFF000LL && dyn + (size_t)ks * A2_RING + 2048 + 1024 + 256 <= 160 * 1024;
-        if (v2 < 0) v2 = (fits && !env_v1) ? 1 : 0;
+        if (v2 < 0) v2 = fits ? 1 : 0;
         if (v2 == 1 && !fits && ks == 2) {                  // the two-group rings leave no room for the table: one group
             const size_t dyn1 = (size_t)cdiv(T * SLOTS, TK) * TK * 4;
             if (one && hi_end < 0xFFFFF000LL && dyn1 + A2_RING + 1024 + 256 <= 160 * 1024) { ks = 1; block = dim3(64 * waves); }

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 ? 3 : 2)) void focal_attn_bf16_v2
 
 }  // namespace
 
-static int g_att_variant = -1;       // -1: read E2FGVI_ATT_VARIANT on first use
+static int g_att_variant = 0;        // 0: automatic; set through the ABI (tools / tests), never from the environment (round 6)
 
 extern "C" int e2fgvi_focal_attention_bf16_variant(int variant) {
     const int prev = g_att_variant;
@@ -591,12 +591,9 @@ extern "C" int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool,
     const long long hi_end = (cq + qb > cp + pb ? cq + qb : cp + pb) - lo;
     E2_REQUIRE(hi_end < 0xFFFFF000LL, E2FGVI_EUNSUP,
                "focal_attention_bf16: qkv and kv_pool must lie within one 4 GiB window (allocate them back to back / split the batch)");
-    // Variant: E2FGVI_ATT_VARIANT = 10 * QB + NW selects the round-3 kernel with NW waves of QB x 32 queries per workgroup
-    // (12, 14, 18, 22, 24); 1 = round 2's kernel (E2FGVI_ATT_NW = its waves per workgroup); unset / 0 = automatic.
-    static int nw_env = -1, xcd_env = -1;
-    if (xcd_env < 0) { const char* e = getenv("E2FGVI_ATT_XCD"); xcd_env = (e && atoi(e)) ? 1 : 0; }
-    if (g_att_variant < 0) { const char* e = getenv("E2FGVI_ATT_VARIANT"); g_att_variant = e ? atoi(e) : 0; }
-    if (nw_env < 0) { const char* e = getenv("E2FGVI_ATT_NW"); nw_env = e ? atoi(e) : 0; }
+    // Variant (e2fgvi_focal_attention_bf16_variant): 10 * QB + NW selects the round-3 kernel with NW waves of QB x 32 queries per
+    // workgroup (12, 14, 18, 22, 24); 1 = round 2's kernel; 0 = automatic.
+    constexpr int xcd_env = 0;
     int variant = g_att_variant;
     const size_t dyn = (size_t)cdiv(T * SLOTS, TK) * TK * 4;              // the key-row table of the round-3 kernel
     const bool v2_fits = dyn + 2 * V2_KB + 2 * V2_VB + 1024 + 256 <= 160 * 1024;
@@ -637,8 +634,8 @@ extern "C" int e2fgvi_focal_attention_bf16(const void* qkv, const void* kv_pool,
         return 0;
     }
     // eight query waves per workgroup when a window has enough query tiles (720p T=10: 15): every staged K / V tile then
-    // serves 256 queries instead of 128, half the staging work per MFMA (-0.2 ms per 720p forward); E2FGVI_ATT_NW overrides
-    const int nw = nw_env ? nw_env : (qtiles >= 12 ? 8 : 4);
+    // serves 256 queries instead of 128, half the staging work per MFMA (-0.2 ms per 720p forward)
+    const int nw = qtiles >= 12 ? 8 : 4;
     dim3 grid(cdiv(qtiles, nw), nWin * NH, B), block(64 * nw);
     if (nw == 8)
         hipLaunchKernelGGL(focal_attn_bf16_kernel<8>, grid, block, 0, (hipStream_t)stream, (const __bf16*)qkv, key_tab, tab_ld, nkeys,

@@ -142,14 +142,9 @@ __device__ __forceinline__ void dma_piece(i32x4 rsrc, unsigned lds_dst, unsigned
 typedef __attribute__((address_space(3))) void wino_lds_void;
 
 // MT = MFMA row-tiles per workgroup: 2 -> 16x16-pixel block (the big layers), 1 -> 8x16 (small images: more workgroups)
-// DMA (round 3): the raw patch goes global -> LDS by LDS-DMA instead of through staging registers + a parking pass of
-// ds_writes.  Each lane fetches the 16-byte unit that belongs at its LDS position (planes [kq][column parity], rows of 12
-// units, 9 used: the rest and the plane padding fetch out of range = zeros), the chunk areas are 1 KiB aligned so that a
-// piece never straddles two chunks (two sources); wave w issues the pieces w, w + 8 of a chunk.  Three LDS stages (they fit
-// under the epilogue's footprint): the pieces of stage st + 2 are issued during stage st, chunk by chunk, right in front of
-// the next chunk's weight loads, so every explicit weight wait is `vmcnt(2 TN + pieces of this wave)` and -- loads return in
-// order -- also retires the wave's pieces of the stage after next; the stage barrier then orders them for the other waves.
-template <int MT, int BN, int SC, bool DMA, bool X3>
+// (Round 3's LDS-DMA staging of the patch with two stages of look-ahead -- tile codes + 1000 -- measured slower on every layer
+//  in both arithmetics, profiles/r03_wino_dma_staging.txt, and was removed in round 6; the wide-tile kernel below keeps its own.)
+template <int MT, int BN, int SC, bool X3>
 __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void conv_wino_kernel(const WinoParams p) {
     static_assert(SC == 2, "chunks per LDS stage (the explicit vmcnt counts of k_loop assume two)");
     constexpr int NT = 512;
@@ -161,14 +156,12 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
     // cycles, profiles/r02_wino4_pmc_enc10.txt)
     constexpr int PLANE_BYTES = PLANE_RAW + ((16 - PLANE_RAW % 128) + 128) % 128;
     constexpr int CHUNK_USED = 4 * PLANE_BYTES;               // planes of one 8-channel chunk: [kq][column parity]
-    constexpr int CHUNK_BYTES = DMA ? (CHUNK_USED + 1023) / 1024 * 1024 : CHUNK_USED;      // DMA: whole 1-KiB pieces
+    constexpr int CHUNK_BYTES = CHUNK_USED;
     constexpr int STAGE_BYTES = SC * CHUNK_BYTES;             // an LDS stage holds SC chunks (one barrier per 8 SC channels)
-    constexpr int NSTAGE = DMA ? 3 : 2;
+    constexpr int NSTAGE = 2;
     constexpr int TILES = 32 * MT;
     constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
     constexpr int SMEM = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
-    constexpr int PIECES = CHUNK_BYTES / 1024;                // DMA pieces per chunk; wave w issues w, w + 8, ...
-    constexpr int NPMAX = (PIECES + 7) / 8;
     constexpr int RAW_ITEMS = RAW_H * RAW_W * 2;          // (pixel, kq) of one chunk
     constexpr int RAW_IT = (RAW_ITEMS + NT - 1) / NT;
 
@@ -203,23 +196,6 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
         raw_dst[it] = have ? (kq * 2 + (pxx & 1)) * PLANE_BYTES + (py * PLANE_ROW + (pxx >> 1)) * 16 : -1;
     }
     const unsigned raw_kq16 = (unsigned)(tid & 1) * 16u;            // NT is even: the kq of an item is the thread's parity
-    // ---- DMA variant: the 16-byte LDS unit this lane fills in piece j of its wave (unit U of the chunk area = plane,
-    // patch row, column pair), as the source pixel to fetch it from (OOB: padding / outside the image) and its channel quad
-    unsigned dma_pix[NPMAX], dma_kq16[NPMAX];
-    if constexpr (DMA) {
-        constexpr int UP = PLANE_BYTES / 16;
-#pragma unroll
-        for (int j = 0; j < NPMAX; ++j) {
-            const int U = ((tid >> 6) + 8 * j) * 64 + lane;
-            const int plane = U / UP, r2 = U - plane * UP;
-            const int py = r2 / PLANE_ROW, c = r2 - py * PLANE_ROW;
-            const int pxx = 2 * c + (plane & 1);
-            const int gy = y0 + py, gx = x0 + pxx;
-            const bool in = plane < 4 && py < RAW_H && c < RAW_W / 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            dma_pix[j] = in ? (unsigned)((img * p.H + gy) * p.W + gx) : OOB;
-            dma_kq16[j] = (unsigned)(plane >> 1) * 16u;
-        }
-    }
 
     // Chunks past the end (odd chunk count, prefetch overrun) need no guards: their weight loads fall outside the
     // group's buffer range and return zeros, so whatever patch data is re-read contributes nothing.
@@ -276,49 +252,6 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
     const unsigned dsc0 = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u, dsc1 = (unsigned)(p.coff[1] + g * p.cpg[1]) * 4u,
                    dsc2 = (unsigned)(p.coff[2] + g * p.cpg[2]) * 4u, dsc3 = (unsigned)(p.coff[3] + g * p.cpg[3]) * 4u;
     const int dsg0 = p.cpg[0], dsg1 = p.cpg[1], dsg2 = p.cpg[2], dsg3 = p.cpg[3];
-    // DMA variant: the pieces of this wave (W_ = its index, NPW_ = how many) of the NEXT chunk of the source walk into the
-    // chunk area at LDS byte address lds_chunk.  Exactly NPW vector-memory instructions on every path (the explicit waits).
-    // The chunk -> (source, channel) map is STATELESS here (chunk index -> source by comparing with the per-source chunk
-    // prefixes, everything captured by value): with the running (source, channel) state of load_raw, mutated inside this
-    // lambda from 48 inlined call sites, hipcc left the closure -- and with it the whole parameter block -- in scratch
-    // memory (hundreds of scratch loads + its own vmcnt waits in the K loop).  Chunks past the end take the last chunk's
-    // parameters and fetch out of range.
-    const int dpre1 = (dsg0 + 7) / 8, dpre2 = dpre1 + (p.nsrc > 1 ? (dsg1 + 7) / 8 : 0), dpre3 = dpre2 + (p.nsrc > 2 ? (dsg2 + 7) / 8 : 0);
-    const int dnsrc = p.nsrc, dlast = p.nchunks - 1;
-    auto dma_chunk = [=, &dma_pix, &dma_kq16](auto W_, auto NPW_, int chunk, unsigned lds_chunk) __attribute__((always_inline)) {
-        constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
-        const int k = chunk < dlast ? chunk : dlast;
-        const int sidx = (dnsrc > 1 && k >= dpre1 ? 1 : 0) + (dnsrc > 2 && k >= dpre2 ? 1 : 0) + (dnsrc > 3 && k >= dpre3 ? 1 : 0);
-        // a select of four values as arithmetic: hipcc turns `sidx == 0 ? a : sidx == 1 ? b : ...` over adjacent closure fields
-        // into an indexed load from the closure, which then has to live in scratch memory
-        // (one source: nothing to select -- the common case, kept free of the 64-bit select arithmetic)
-        const unsigned long long m1 = dnsrc > 1 && sidx == 1, m2 = dnsrc > 2 && sidx == 2, m3 = dnsrc > 3 && sidx == 3;
-        auto sel = [=](unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long d) {
-            return a + m1 * (b - a) + m2 * (c - a) + m3 * (d - a);
-        };
-        const float* csrc = dsp0;
-        unsigned cbytes = dsb0, cld4 = dsl0, cchan = dsc0;
-        int ccpg = dsg0, cc0 = k * 8;
-        if (dnsrc > 1) {                           // wave-uniform
-            csrc = reinterpret_cast<const float*>(sel((unsigned long long)dsp0, (unsigned long long)dsp1, (unsigned long long)dsp2,
-                                                      (unsigned long long)dsp3));
-            cbytes = (unsigned)sel(dsb0, dsb1, dsb2, dsb3);
-            cld4 = (unsigned)sel(dsl0, dsl1, dsl2, dsl3);
-            cchan = (unsigned)sel(dsc0, dsc1, dsc2, dsc3);
-            ccpg = (int)sel((unsigned)dsg0, (unsigned)dsg1, (unsigned)dsg2, (unsigned)dsg3);
-            cc0 = (k - (int)sel(0u, (unsigned)dpre1, (unsigned)dpre2, (unsigned)dpre3)) * 8;
-        }
-        const i32x4 rs = rsrc_words(csrc, cbytes);
-        const unsigned chan = cchan + (unsigned)cc0 * 4u;
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) {
-            // a source may end in the middle of a chunk; chunks past the end fetch out of range (zeros, no memory access)
-            const bool cvalid = chunk <= dlast && cc0 + (int)(dma_kq16[j] >> 2) < ccpg;
-            unsigned off = (cvalid && dma_pix[j] != OOB) ? dma_pix[j] * cld4 + chan + dma_kq16[j] : OOB;
-            asm volatile("" : "+v"(off));
-            dma_piece(rs, __builtin_amdgcn_readfirstlane(lds_chunk + (unsigned)((WV + 8 * j) * 1024)), off);
-        }
-    };
 
     // ---- this wave's transform positions: xi = wave >> 1, nu in {0,1} (pair A) or {2,3} (pair B)
     //   B^T rows:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3          (same combinations over columns)
@@ -366,7 +299,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             for (int n = 0; n < TN; ++n) buf_load4_pinned(q[a][n], wrsrc, u_off[a][n] + (unsigned)chunk * u_step);
     };
     // X3: the weights of a 16-channel stage, 3 planes per (position, column tile)
-    f32x4 bw[(X3 && DMA) ? 3 : 2][2][X3 ? TN : 1][3];
+    f32x4 bw[2][2][X3 ? TN : 1][3];
     auto load_b3 = [&](int st, f32x4 (&q)[2][X3 ? TN : 1][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -396,7 +329,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
                 for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
 
     const int nstages = (p.nchunks + SC - 1) / SC;
-    if constexpr (!DMA) {
+    {
 #pragma unroll
         for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
         if constexpr (X3) load_b3(0, bw[0]);
@@ -479,50 +412,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(wq[a][n][pl]));
             };
-            if constexpr (DMA) {
-                // Patch by LDS-DMA into three LDS stages and everything fetched TWO stages ahead: with the matrix work of a
-                // stage cut to a third, one stage of lookahead no longer covers the L2 / fabric latency of the weight and patch
-                // loads (the one-workgroup-per-CU propagation layers ran at ~1.1 us per stage against ~0.5 us of arithmetic).
-                // Trip st issues the pieces and the weights of stage st + 2 (slot / buffer (st + 2) % 3: its previous readers
-                // passed the last barrier), claims stage st's weights -- issued two trips ago, 2 x (SC NPW + 6 TN) loads back --
-                // and, before the stage barrier, waits for its own pieces of stage st + 1 (all but this trip's loads).
-                constexpr int WV = 2 * XI + (PB ? 1 : 0);
-                constexpr int NPW = (PIECES - WV + 7) / 8;
-                constexpr int PER = SC * NPW + 6 * TN;                     // vector-memory instructions per trip
-#pragma unroll
-                for (int c4 = 0; c4 < 2 * SC; ++c4)
-                    dma_chunk(IC<WV>{}, IC<NPW>{}, c4, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
-                load_b3(0, bw[0]);
-                load_b3(1, bw[1]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                auto trip = [&](auto CUR_, int st) __attribute__((always_inline)) {
-                    constexpr int CUR = decltype(CUR_)::value, NX2 = (CUR + 2) % 3;
-#pragma unroll
-                    for (int q = 0; q < SC; ++q)
-                        dma_chunk(IC<WV>{}, IC<NPW>{}, SC * (st + 2) + q, smem_lds + (unsigned)(NX2 * STAGE_BYTES + q * CHUNK_BYTES));
-                    load_b3(st + 2, bw[NX2]);
-                    wait_vmcnt<2 * PER>();
-                    claim3(bw[CUR]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    {
-                        bf16x8 A[MT][6];
-                        x3_prep(smem + CUR * STAGE_BYTES, A);
-                        x3_mma(A, bw[CUR]);
-                    }
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");     // this wave's pieces of stage st + 1 have landed
-                    __syncthreads();
-                };
-                for (int st = 0; st < nstages; st += 3) {
-                    trip(IC<0>{}, st);
-                    trip(IC<1>{}, st + 1);
-                    trip(IC<2>{}, st + 2);
-                }
-                // pieces issued for stages past the end are still in flight and target LDS the epilogue is about to reuse
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                return;
-            }
+            
             // Register-staged patch (the product variant).  Entry state (prologue above): buffer 0 = stage 0 (visible), staging
             // registers = stage 1, stage 0's weights issued between the two patch loads -- like the fp32 kernel's.
             // (two stages per trip with compile-time buffer indices: `bw[st & 1]` would put the weight registers in scratch; an odd
@@ -558,58 +448,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
             }
             return;
         }
-        if constexpr (DMA) {
-            constexpr int WV = 2 * XI + (PB ? 1 : 0);                  // this wave
-            constexpr int NPW = (PIECES - WV + 7) / 8;                 // its pieces per chunk
-            // prologue: stages 0 and 1 (chunks 0 .. 3) and the first chunk's weights, waited for in full
-#pragma unroll
-            for (int c4 = 0; c4 < 2 * SC; ++c4)
-                dma_chunk(IC<WV>{}, IC<NPW>{}, c4, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
-            load_b(0, bq[0]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int slot = 0;
-            for (int st = 0; st < nstages; ++st) {
-                const unsigned char* stage = smem + slot * STAGE_BYTES;
-                const unsigned ahead = smem_lds + (unsigned)((slot == 0 ? 2 : slot - 1) * STAGE_BYTES);   // stage st + 2's slot
-#pragma unroll
-                for (int q = 0; q < SC; ++q) {
-                    dma_chunk(IC<WV>{}, IC<NPW>{}, SC * (st + 2) + q, ahead + (unsigned)(q * CHUNK_BYTES));   // its readers passed the last barrier
-                    load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);            // next chunk's weights land during this chunk
-                    // issued since this chunk's weights: the NPW pieces above and the next chunk's 2 TN weight loads; loads
-                    // return in order, so the wait also retires this wave's pieces of stage st + 1 (issued a stage ago)
-                    claim_b(IC<2 * TN + NPW>{}, bq[q & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned char* raw = stage + q * CHUNK_BYTES;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const unsigned char* rm = raw + m * (8 * PLANE_ROW * 16);
-                        f32x4 e[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(rm + a_off[0][j]);
-                            const f32x4 d1 = *reinterpret_cast<const f32x4*>(rm + a_off[1][j]);
-                            e[j] = XI == 1 ? d0 + d1 : XI == 2 ? d1 - d0 : d0 - d1;
-                        }
-                        const f32x4 va = PB ? e[1] - e[0] : e[0] - e[2];
-                        const f32x4 vb = PB ? e[0] - e[2] : e[1] + e[2];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-#pragma unroll
-                            for (int n = 0; n < TN; ++n) {
-                                acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[k], bq[q & 1][0][n][k], acc[0][m][n], 0, 0, 0);
-                                acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[k], bq[q & 1][1][n][k], acc[1][m][n], 0, 0, 0);
-                            }
-                    }
-                }
-                __syncthreads();        // everybody's pieces of stage st + 1 have landed (each wave waited for its own above)
-                slot = slot == 2 ? 0 : slot + 1;
-            }
-            // pieces issued for stages past the end are still in flight and target LDS the epilogue is about to reuse
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            return;
-        }
+        
         for (int st = 0; st < nstages; ++st) {
             const unsigned char* stage = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
@@ -670,7 +509,7 @@ __global__ __launch_bounds__(512, ((MT == 1 && BN == 32 && !X3) ? 4 : 2)) void c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (X3) {
 #pragma unroll
-        for (int b_ = 0; b_ < ((X3 && DMA) ? 3 : 2); ++b_)
+        for (int b_ = 0; b_ < (2); ++b_)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1627,7 +1466,7 @@ extern "C" int e2fgvi_pack_winograd_weight(const float* w, float* wpacked, int32
 }
 #endif
 
-template <int MT, int BN, int SC, bool DMA, bool X3 = false>
+template <int MT, int BN, int SC, bool X3 = false>
 static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     p.blocksY = cdiv(p.H, 8 * MT);
     p.blocksX = cdiv(p.W, 16);
@@ -1635,7 +1474,7 @@ static int launch_wino(WinoParams& p, int groups, hipStream_t st) {
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd: grid too large");
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC, DMA, X3>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_wino_kernel<MT, BN, SC, X3>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd");
     return 0;
 }
@@ -1730,34 +1569,23 @@ static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
     if (tile == 64) tile = 164;
     switch (tile) {
         // (no 16x16-pixel x 64-cout shape: 128 accumulator + 96 weight registers per lane do not fit beside the split)
-        case 32: return launch_wino<2, 32, 2, false, true>(p, d->groups, st);
-        case 164: return launch_wino<1, 64, 2, false, true>(p, d->groups, st);
-        case 132: return launch_wino<1, 32, 2, false, true>(p, d->groups, st);
+        case 32: return launch_wino<2, 32, 2, true>(p, d->groups, st);
+        case 164: return launch_wino<1, 64, 2, true>(p, d->groups, st);
+        case 132: return launch_wino<1, 32, 2, true>(p, d->groups, st);
         // + 5000: four positions per wave, four-wave workgroups (two per CU)
         case 5132: return launch_wino_p4<32>(p, d->groups, st);
         // + 6000: 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place (round 4)
         case 6064: return launch_wino_w<64>(p, d->groups, st);
-        // + 1000: patch by LDS-DMA, patch and weights fetched two stages ahead (32-cout shapes: three weight buffers fit)
-        case 1032: return launch_wino<2, 32, 2, true, true>(p, d->groups, st);
-        case 1132: return launch_wino<1, 32, 2, true, true>(p, d->groups, st);
         default: break;
     }
     e2fgvi_set_error("conv3x3_winograd_x3: tile must be 0 (auto), 32 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");
     return E2FGVI_EINVAL;
 #else
-    // + 1000: the same block shape with the raw patch staged by LDS-DMA (round 3); E2FGVI_WINO_DMA=1 makes it the default
-    static int dma_env = -1;
-    if (dma_env < 0) { const char* e = getenv("E2FGVI_WINO_DMA"); dma_env = e ? atoi(e) : 0; }
-    if (tile < 1000 && dma_env) tile += 1000;
     switch (tile) {
-        case 64: return launch_wino<2, 64, 2, false>(p, d->groups, st);
-        case 32: return launch_wino<2, 32, 2, false>(p, d->groups, st);
-        case 164: return launch_wino<1, 64, 2, false>(p, d->groups, st);
-        case 132: return launch_wino<1, 32, 2, false>(p, d->groups, st);
-        case 1064: return launch_wino<2, 64, 2, true>(p, d->groups, st);
-        case 1032: return launch_wino<2, 32, 2, true>(p, d->groups, st);
-        case 1164: return launch_wino<1, 64, 2, true>(p, d->groups, st);
-        case 1132: return launch_wino<1, 32, 2, true>(p, d->groups, st);
+        case 64: return launch_wino<2, 64, 2>(p, d->groups, st);
+        case 32: return launch_wino<2, 32, 2>(p, d->groups, st);
+        case 164: return launch_wino<1, 64, 2>(p, d->groups, st);
+        case 132: return launch_wino<1, 32, 2>(p, d->groups, st);
         // (four chunks per LDS stage -- half the barriers -- measured 1-6 % slower on every layer, profiles/r02_wino_sc4.txt)
         default: break;
     }

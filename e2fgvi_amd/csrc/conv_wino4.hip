@@ -152,12 +152,11 @@ __device__ __forceinline__ void w4_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// PIPE: the K loop is software-pipelined by one chunk (see k_loop).  Measured on MI355X (profiles/r02_wino4_bench.txt):
-// it pays for F(4x4) (12 waves, 12 MFMAs per chunk and wave: 897 -> 837 us on encoder.layers.10) and costs 2-3 % for F(2x4)
-// (24 MFMAs per chunk and wave cover the transform well enough; the fences cost more than the overlap gains).
-template <int FY, int BN, int SC, bool PIPE>
-__global__ __launch_bounds__(128 * (FY + 2), (FY == 4 ? 3 : 2)) void conv_wino4_kernel(const W4Params p) {
-    static_assert(FY == 2 || FY == 4, "row tile");
+// (Round 6 pruned what never won a layer -- profiles/r02_wino4_bench.txt: F(4x4,3x3) with its software-pipelined K loop, 12-wave
+//  workgroups and 36 positions, and the 32-cout shape of F(2x4); the formulas below keep FY as a name, FY = 2 is what is built.)
+template <int FY, int BN, int SC>
+__global__ __launch_bounds__(128 * (FY + 2), 2) void conv_wino4_kernel(const W4Params p) {
+    static_assert(FY == 2, "row tile: F(2x4,3x3)");
     static_assert(SC == 2, "chunks per LDS stage (the weight double buffer alternates with the chunk parity)");
     constexpr int NW = 2 * (FY + 2);
     constexpr int NT = 64 * NW;
@@ -343,96 +342,34 @@ __global__ __launch_bounds__(128 * (FY + 2), (FY == 4 ? 3 : 2)) void conv_wino4_
             }
             return acc_v;
         };
-        // One chunk: multiply (vc, b) while building vn from the patch at `raw`.  The chunk is NM slots of one MFMA plus
-        // a piece of the next transform (reads of a column / its row combination / one column combination), fenced by
-        // sched_barrier so that the pieces issue in the shadow of the MFMAs instead of at their tail (the scheduler
-        // otherwise clusters all MFMAs first; sched_group_barrier pipelines were not honoured for the VALU groups).
-        auto step = [&](const f32x4 (&vc)[3], const f32x4 (&b)[3][TN], const unsigned char* raw, f32x4 (&vn)[3]) {
-            constexpr int NM = 12 * TN;
-            f32x4 d[5][FY + 2];
-            f32x4 e[5];
-            w4_static_for<NM>([&](auto S_) {
-                constexpr int sl = decltype(S_)::value;
-                constexpr int k = sl / (3 * TN), n = (sl / 3) % TN, a = sl % 3;
-                acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[a][k], b[a][n][k], acc[a][n], 0, 0, 0);
-                w4_static_for<5>([&](auto J_) {
-                    constexpr int j = decltype(J_)::value;
-                    constexpr int rs = (NM == 24) ? (j == 0 ? 0 : j - 1) : j;           // slot of the reads of column j
-                    constexpr int es = (NM == 24) ? 4 + 2 * j : j + 2;                   // slot of its row combination
-                    if constexpr (sl == rs) read_col(raw, d[j], J_);
-                    if constexpr (sl == es) e[j] = row_comb(d[j]);
-                });
-                w4_static_for<3>([&](auto A_) {
-                    constexpr int aa = decltype(A_)::value;
-                    constexpr int vs = (NM == 24) ? 14 + 3 * aa : 7 + aa;
-                    if constexpr (sl == vs) vn[aa] = col_comb(e, A_);
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // the IR-level sinking pass would otherwise move the whole transform down to its first use (after the
-            // barrier of the next chunk)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(vn[a]));
-        };
-        if constexpr (!PIPE) {
-            // plain form: per chunk transform, then multiply (two workgroups per CU cover each other's transform phases)
-            for (int st = 0; st < nstages; ++st) {
-                const unsigned char* stage = smem + (st & 1) * STAGE_BYTES + lane_base;
-#pragma unroll
-                for (int q = 0; q < SC; ++q) {
-                    load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);        // next chunk's weights land during this chunk
-                    if (q == 0) claim_b(IC4<3 * TN + SC * RAW_IT>{}, bq[q & 1]);
-                    else claim_b(IC4<3 * TN>{}, bq[q & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned char* raw = stage + q * CHUNK_BYTES;
-                    f32x4 d[5][FY + 2];
-                    f32x4 e[5];
-                    f32x4 v[3];
-                    w4_static_for<5>([&](auto J_) { read_col(raw, d[decltype(J_)::value], J_); });
-                    w4_static_for<5>([&](auto J_) { e[decltype(J_)::value] = row_comb(d[decltype(J_)::value]); });
-                    v[0] = col_comb(e, IC4<0>{}); v[1] = col_comb(e, IC4<1>{}); v[2] = col_comb(e, IC4<2>{});
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int n = 0; n < TN; ++n)
-#pragma unroll
-                            for (int a = 0; a < 3; ++a)
-                                acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a][k], bq[q & 1][a][n][k], acc[a][n], 0, 0, 0);
-                }
-                store_raw((st & 1) ^ 1);
-#pragma unroll
-                for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
-                __syncthreads();
-            }
-            return;
-        }
-        f32x4 v0[3], v1[3];
-        {   // A operands of chunk 0
-            const unsigned char* raw = smem + lane_base;
-            f32x4 d[5][FY + 2];
-            f32x4 e[5];
-            w4_static_for<5>([&](auto J_) { read_col(raw, d[decltype(J_)::value], J_); });
-            w4_static_for<5>([&](auto J_) { e[decltype(J_)::value] = row_comb(d[decltype(J_)::value]); });
-            v0[0] = col_comb(e, IC4<0>{}); v0[1] = col_comb(e, IC4<1>{}); v0[2] = col_comb(e, IC4<2>{});
-        }
+        // plain form: per chunk transform, then multiply (two workgroups per CU cover each other's transform phases)
         for (int st = 0; st < nstages; ++st) {
-            const unsigned char* cur = smem + (st & 1) * STAGE_BYTES + lane_base;
-            const unsigned char* nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES + lane_base;
-            // ---- first chunk of the stage (weights in bq[0], issued during the previous chunk)
-            load_b(SC * st + 1, bq[1]);
-            claim_b(IC4<3 * TN>{}, bq[0]);                       // loads issued since: the 3 TN just above
-            __builtin_amdgcn_sched_barrier(0);
-            step(v0, bq[0], cur + CHUNK_BYTES, v1);
-            // the registers hold stage st+1: park it in the other buffer (its last readers passed the previous barrier)
+            const unsigned char* stage = smem + (st & 1) * STAGE_BYTES + lane_base;
+#pragma unroll
+            for (int q = 0; q < SC; ++q) {
+                load_b(SC * st + q + 1, bq[(q & 1) ^ 1]);        // next chunk's weights land during this chunk
+                if (q == 0) claim_b(IC4<3 * TN + SC * RAW_IT>{}, bq[q & 1]);
+                else claim_b(IC4<3 * TN>{}, bq[q & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* raw = stage + q * CHUNK_BYTES;
+                f32x4 d[5][FY + 2];
+                f32x4 e[5];
+                f32x4 v[3];
+                w4_static_for<5>([&](auto J_) { read_col(raw, d[decltype(J_)::value], J_); });
+                w4_static_for<5>([&](auto J_) { e[decltype(J_)::value] = row_comb(d[decltype(J_)::value]); });
+                v[0] = col_comb(e, IC4<0>{}); v[1] = col_comb(e, IC4<1>{}); v[2] = col_comb(e, IC4<2>{});
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a][k], bq[q & 1][a][n][k], acc[a][n], 0, 0, 0);
+            }
             store_raw((st & 1) ^ 1);
 #pragma unroll
             for (int q = 0; q < SC; ++q) load_raw(rraw[q]);
             __syncthreads();
-            // ---- second chunk; its successor is the first chunk of the next stage
-            load_b(SC * st + 2, bq[0]);
-            claim_b(IC4<3 * TN + SC * RAW_IT>{}, bq[1]);         // since: the patch prefetch and the 3 TN just above
-            __builtin_amdgcn_sched_barrier(0);
-            step(v1, bq[1], nxt, v0);
         }
         __syncthreads();                                          // the epilogue reuses the LDS
     };
@@ -445,16 +382,7 @@ __global__ __launch_bounds__(128 * (FY + 2), (FY == 4 ? 3 : 2)) void conv_wino4_
         case 5: k_loop(IC4<2>{}, IC4<1>{}); break;
         case 6: k_loop(IC4<3>{}, IC4<0>{}); break;
         case 7: k_loop(IC4<3>{}, IC4<1>{}); break;
-        default:
-            if constexpr (FY == 4) {
-                switch (wave) {
-                    case 8: k_loop(IC4<4>{}, IC4<0>{}); break;
-                    case 9: k_loop(IC4<4>{}, IC4<1>{}); break;
-                    case 10: k_loop(IC4<5>{}, IC4<0>{}); break;
-                    default: k_loop(IC4<5>{}, IC4<1>{}); break;
-                }
-            }
-            break;
+        default: break;
     }
     // The weight loads issued for the chunk PAST the end (out of range: zeros) are still in flight, and for hipcc an asm load's
     // destination is written when the statement ends: wait, then name the registers, so that nothing of the epilogue is allocated
@@ -569,7 +497,7 @@ struct W4Pack {
 };
 
 bool w4_geometry(int Cout, int groups, int nsrc, const int32_t* cpg, int fy, W4Pack* q) {
-    if (Cout <= 0 || groups <= 0 || Cout % groups || nsrc < 1 || nsrc > E2FGVI_MAX_SRC || (fy != 2 && fy != 4)) return false;
+    if (Cout <= 0 || groups <= 0 || Cout % groups || nsrc < 1 || nsrc > E2FGVI_MAX_SRC || fy != 2) return false;
     q->Cout = Cout; q->groups = groups; q->nsrc = nsrc; q->fy = fy; q->npos = (fy + 2) * 6;
     q->Cout_g = Cout / groups;
     q->Npad = round_up(q->Cout_g, 32);
@@ -627,7 +555,7 @@ int launch_wino4(W4Params& p, int groups, hipStream_t st) {
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd4: grid too large");
     p.nblk = (int)nblk;
-    hipLaunchKernelGGL((conv_wino4_kernel<FY, BN, 2, (FY == 4)>), dim3(p.nblk, groups, 1), dim3(128 * (FY + 2)), 0, st, p);
+    hipLaunchKernelGGL((conv_wino4_kernel<FY, BN, 2>), dim3(p.nblk, groups, 1), dim3(128 * (FY + 2)), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd4");
     return 0;
 }
@@ -638,7 +566,7 @@ extern "C" int64_t e2fgvi_packed_winograd4_weight_size(int32_t Cout, int32_t gro
                                                        int32_t fy) {
     W4Pack q;
     if (!src_cpg || !w4_geometry(Cout, groups, nsrc, src_cpg, fy, &q)) {
-        e2fgvi_set_error("packed_winograd4_weight_size: bad geometry (channels per source multiples of 4, fy 2 or 4)");
+        e2fgvi_set_error("packed_winograd4_weight_size: bad geometry (channels per source multiples of 4, fy = 2)");
         return E2FGVI_EINVAL;
     }
     return q.total;
@@ -659,7 +587,7 @@ extern "C" int e2fgvi_conv3x3_winograd4(const e2fgvi_conv_desc* d, int32_t fy, v
     E2_REQUIRE(d, E2FGVI_EINVAL, "conv3x3_winograd4: null descriptor");
     W4Pack q;
     E2_REQUIRE(w4_geometry(d->Cout, d->groups, d->nsrc, d->src_cpg, fy, &q), E2FGVI_EINVAL,
-               "conv3x3_winograd4: bad geometry (channels per source must be multiples of 4, fy 2 or 4)");
+               "conv3x3_winograd4: bad geometry (channels per source must be multiples of 4, fy = 2)");
     E2_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1, E2FGVI_EUNSUP,
                "conv3x3_winograd4: only 3x3, stride 1, pad 1");
     E2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % fy == 0 && d->W % 4 == 0, E2FGVI_EUNSUP,
@@ -701,10 +629,8 @@ extern "C" int e2fgvi_conv3x3_winograd4(const e2fgvi_conv_desc* d, int32_t fy, v
     p.vec_store = vec ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     int tile = d->tile;
-    if (!tile) tile = (fy == 2 && q.Cout_g > 32) ? 64 : 32;
+    if (!tile) tile = 64;
     if (fy == 2 && tile == 64) return launch_wino4<2, 64>(p, d->groups, st);
-    if (fy == 2 && tile == 32) return launch_wino4<2, 32>(p, d->groups, st);
-    if (fy == 4 && tile == 32) return launch_wino4<4, 32>(p, d->groups, st);
-    e2fgvi_set_error("conv3x3_winograd4: tile must be 0 (auto), 32 or 64 couts per workgroup (fy = 4: 32 only)");
-    return E2FGVI_EINVAL;
+    e2fgvi_set_error("conv3x3_winograd4: fy must be 2 and tile 0 (auto) or 64 couts per workgroup (the other shapes were pruned in round 6)");
+    return E2FGVI_EUNSUP;
 }

@@ -805,13 +805,10 @@ extern "C" int e2fgvi_mdcn_nhwc(const e2fgvi_mdcn_desc* d, void* stream) {
         // Its 64 rows as an 8 x 8 pixel block (tile 106: the corner fetches of a tile fall into a (8 + 2r)^2 neighbourhood instead
         // of (64 + 2r) x (1 + 2r) pixels) is 9 % faster on i.i.d. random 3-pixel offsets (177.9 vs 196.2 us) and exactly neutral
         // inside the forward, where the offsets follow the smooth flow field (34.46 / 34.57 vs 34.42 / 34.58 ms, same box,
-        // profiles/r02_dcn_sampler.txt): off by default, E2FGVI_DCN_BLOCKS=1 or tile codes 101 ... 106 select it
+        // profiles/r02_dcn_sampler.txt): off by default, tile codes 101 ... 106 select it
         // (planar sources: the single K group wins, 143 vs 156 us on a smooth offset field, 170 vs 178 on random offsets)
         if (tile == 1 && d->mfma_dtype == E2FGVI_BF16 && !p.planar) {
             tile = 6;
-            static int blocks_env = -1;
-            if (blocks_env < 0) { const char* e = getenv("E2FGVI_DCN_BLOCKS"); blocks_env = e ? atoi(e) : 0; }
-            p.sw = blocks_env ? 1 : 0;
         }
     }
     const bool bf = d->mfma_dtype == E2FGVI_BF16;

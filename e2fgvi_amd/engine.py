@@ -24,12 +24,11 @@ from . import ops
 from .engine_x import BF16Path
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, PackedConv, PackedConvX, PackedDcn, PackedLinear
 
-TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
 # fp32 path: the FFN's second Linear as a conv of the folded tensor (as the bf16 path runs it).  Measured neutral on the fp32
 # MFMA kernels (15.785 vs 15.775 ms, profiles/r02_fc2_conv.txt: the 16-byte tap-packed fetches cost what the unfold kernel
 # saved); with the split-operand kernels (ops.X3_ENABLED) the conv form wins -- 743 -> 750 frames/s, same box, two runs each
 # (profiles/r03_fc2_conv_x3.txt) -- and is the default
-FC2_CONV = os.environ.get("E2FGVI_FC2_CONV_FP32", "1" if ops.X3_ENABLED else "0") != "0"
+FC2_CONV = ops.X3_ENABLED          # (bench.py's E2FGVI_X3=0 secondary line sets both to False for its engine)
 WIN = (5, 9)
 # where the side stream (SPyNet) joins the main one: in front of encoder.layers.<JOIN_AT> (18 = behind the encoder).  Round 4 joined in
 # front of layer 10 (its wide-tile kernel was fenced to layers with the chip to themselves); with encoder.layers.2 / 6 / 8 on that
@@ -150,8 +149,7 @@ class Engine(BF16Path):
         self.dec = [PackedConv(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1, **ww),
                     PackedConv(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1, **ww),
                     PackedConv(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1, **ww),
-                    (PackedTail(f("decoder.6.weight"), f("decoder.6.bias")) if TAIL_KERNEL else
-                     PackedConv(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1))]
+                    PackedTail(f("decoder.6.weight"), f("decoder.6.bias"))]
 
         # ---- propagation (feat_prop.py:61-79, :15-33)
         # conv_offset.0 and backbone.0 are linear in their input channels, and a third / a half / two thirds of those do not
@@ -171,9 +169,8 @@ class Engine(BF16Path):
                    PackedConv(f(p + "conv_offset.4.weight"), f(p + "conv_offset.4.bias"), [128], pad=1, **ww),
                    PackedConv(f(p + "conv_offset.6.weight"), f(p + "conv_offset.6.bias"), [128], pad=1,
                               algo=ww["algo"])]
-            # (split-operand MFMA with the other x3 kernels: ops.X3_ENABLED, E2FGVI_DCN_X3=0 keeps the fp32 MFMA)
-            dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1,
-                            mfma="x3" if (precision == "fp32" and ops.X3_ENABLED and os.environ.get("E2FGVI_DCN_X3", "1") != "0") else "fp32")
+            # (split-operand MFMA with the other x3 kernels: ops.X3_ENABLED)
+            dcn = PackedDcn(f(p + "weight"), f(p + "bias"), 16, pad=1, mfma="x3" if (precision == "fp32" and ops.X3_ENABLED) else "fp32")
             b = "feat_prop_module.backbone.%s." % d
             bb = [PackedConv(f(b + "0.weight"), f(b + "0.bias"), [128] * nparts, pad=1, **ww),
                   PackedConv(f(b + "2.weight"), f(b + "2.bias"), [128], pad=1, **ww)]
@@ -525,11 +522,7 @@ class Engine(BF16Path):
             # written by the qkv GEMM's epilogue when the split-operand GEMM runs it (round 5: no separate pass over the rows, and
             # the fp32 K / V columns are never stored), by e2fgvi_split3_kv otherwise (ops.PackedConv.__call__, kv_planes)
             planes = torch.empty((3, rows + prow, 1024), dtype=torch.bfloat16, device=x.device)
-            if ops.KV_EPILOGUE:
-                both = blk["qkv"](nbuf, kv_planes=planes)
-            else:
-                both = blk["qkv"](nbuf)
-                ops.split3_kv(both, out=planes)
+            both = blk["qkv"](nbuf, kv_planes=planes)
             att = ops.focal_attention_x3(both[:rows], planes, tab, nk, b, t, fh, fw)
         else:
             both = blk["qkv"](nbuf)

@@ -12,19 +12,16 @@ bytes live and which pipe multiplies them:
   * LayerNorm, window pooling, fold / unfold + GELU, SoftComp fold and the x2 upsamples read / write bf16 and compute
     in fp32 (typed variants of the fp32 kernels, csrc/misc.hip).
 """
-import os
-
 import torch
 
 from . import ops
 from .ops import ACT_DCNPOST, ACT_LRELU, ACT_NONE, ACT_TANH, PackedConvX, PackedLinearX
 
 BF16 = torch.bfloat16
-TAIL_KERNEL = os.environ.get("E2FGVI_TAIL", "1") != "0"        # decoder.6 on csrc/conv_tail.hip
-DCN_PLANAR = os.environ.get("E2FGVI_DCN_PLANAR", "1") != "0"    # deformable conv gathers from [group][pixel][16] copies
-# flow-warp sources of the conv_offset condition: the bf16 copies of the propagated features (1) or fp32 ones written beside (0)
-PROP_BF16SRC = os.environ.get("E2FGVI_PROP_BF16SRC", "1") != "0"
-FC2_CONV = os.environ.get("E2FGVI_FC2_CONV", "1") != "0"     # FFN second Linear as a conv of the folded tensor
+# Settled in rounds 2-5 and no longer switchable (round 6): decoder.6 on csrc/conv_tail.hip; the deformable conv gathers from
+# [group][pixel][16] copies of the propagated features; the recurrent propagation state and the flow-warp sources are the bf16
+# copies (an fp32 state changes the end-to-end error by < 1 % of itself: tools/bf16_error_growth.py); the FFN's second Linear is
+# the 7x7 / stride-3 conv of the folded tensor; SoftComp (HQ) runs in gather form.
 
 
 class BF16Path:
@@ -45,8 +42,7 @@ class BF16Path:
         self.xdec = [PackedConvX(f("decoder.0.conv.weight"), f("decoder.0.conv.bias"), [128], pad=1),
                      PackedConvX(f("decoder.2.weight"), f("decoder.2.bias"), [128], pad=1),
                      PackedConvX(f("decoder.4.conv.weight"), f("decoder.4.conv.bias"), [64], pad=1),
-                     (ops.PackedTailConv(f("decoder.6.weight"), f("decoder.6.bias"), dtype=BF16) if TAIL_KERNEL else
-                      PackedConvX(f("decoder.6.weight"), f("decoder.6.bias"), [64], pad=1))]
+                     ops.PackedTailConv(f("decoder.6.weight"), f("decoder.6.bias"), dtype=BF16)]
         for k, n in enumerate(("decoder.0.conv", "decoder.2", "decoder.4.conv", "decoder.6")):
             self.xdec[k].name = n
         self.xprop = {}
@@ -77,9 +73,8 @@ class BF16Path:
             self.xsc_bias_conv = PackedConvX(f("sc.bias_conv.weight"), f("sc.bias_conv.bias"), [128], pad=1)
             self.xsc_bias_conv.name = "sc.bias_conv"
             # SoftComp in gather form (nine phase convolutions writing the folded image directly: no [tokens, 6272] tensor,
-            # 813 MB at 720p T=10, and no fold kernel); E2FGVI_SC_GATHER=0: the Linear + fold kernel pair (A/B measurements)
-            self.xsc_gather = (ops.SoftCompGather(f("sc.embedding.weight"), f("sc.embedding.bias"), 128)
-                               if os.environ.get("E2FGVI_SC_GATHER", "1") != "0" else None)
+            # 813 MB at 720p T=10, and no fold kernel); other token grids than 3 x the feature size take the Linear + fold pair
+            self.xsc_gather = ops.SoftCompGather(f("sc.embedding.weight"), f("sc.embedding.bias"), 128)
         # SPyNet: the conv stacks of the six pyramid levels on bf16 MFMA (they are 15 % of the 720p forward in fp32); the
         # geometry stays fp32 -- pyramid images, warps, the flow itself and the residual sum flow = up(flow) + net(...)
         # (the last conv of a level adds the fp32 upsampled flow and stores fp32).
@@ -99,12 +94,11 @@ class BF16Path:
             w2 = f(p + "mlp.conv2.1.weight").view(512, 40, 49).permute(0, 2, 1).reshape(512, 1960).contiguous()
             blk = dict(qkv=PackedLinearX(f(p + "attn.qkv.weight"), f(p + "attn.qkv.bias")),
                        proj=PackedLinearX(f(p + "attn.proj.weight"), f(p + "attn.proj.bias")),
-                       fc1=PackedLinearX(w1, b1), fc2=PackedLinearX(w2, f(p + "mlp.conv2.1.bias")))
-            if FC2_CONV:
-                # Linear(1960 -> 512) of the unfolded 7x7 patches == the 7x7 / stride 3 / pad 3 convolution of the folded
-                # [F, H, W, 40] tensor (tfocal_transformer.py:81,95-97): no unfold kernel, no [rows, 1960] tensor
-                blk["fc2"] = PackedConvX(f(p + "mlp.conv2.1.weight").view(512, 40, 7, 7), f(p + "mlp.conv2.1.bias"), [40],
-                                         stride=3, pad=3)
+                       fc1=PackedLinearX(w1, b1),
+                       # Linear(1960 -> 512) of the unfolded 7x7 patches == the 7x7 / stride 3 / pad 3 convolution of the folded
+                       # [F, H, W, 40] tensor (tfocal_transformer.py:81,95-97): no unfold kernel, no [rows, 1960] tensor
+                       fc2=PackedConvX(f(p + "mlp.conv2.1.weight").view(512, 40, 7, 7), f(p + "mlp.conv2.1.bias"), [40],
+                                       stride=3, pad=3))
             for k in ("qkv", "proj", "fc1", "fc2"):
                 blk[k].name = "transformer.%d.%s" % (i, k)
             self.xblocks.append(blk)
@@ -169,37 +163,29 @@ class BF16Path:
             if name == "backward_":
                 order = order[::-1]
             img_stride = (l_t - 1) * h * w * 2
-            hist = []                       # fp32 propagated features in processing order (flow-warp sources)
-            hist16 = []                     # their bf16 copies (the DCN gathers these: 8 channels per 16-byte corner fetch)
+            hist16 = []                     # bf16 propagated features in processing order: conv, flow-warp and DCN sources
             # ... re-laid out [group][pixel][16]: the 32-byte runs a deform group's samples fetch are then adjacent for
             # neighbouring pixels and share cache lines (NHWC: one run per 256-byte pixel) -- tools/dcn_bench_x.py
             planar16 = []
-            zero16p = self._zero16((ch // 16, b, h, w, 16)) if DCN_PLANAR else None
+            zero16p = self._zero16((ch // 16, b, h, w, 16))
             aligned = zero16
             for i, idx in enumerate(order):
                 cur = loc[idx]
                 if i > 0:
                     flow_a = flows[0, i - 1]
                     flow_b = flows[0, i - 2] if i > 1 else None
-                    warp = hist16 if PROP_BF16SRC else hist
-                    feat_n2 = warp[-2] if i > 1 else None
-                    cond, fl, fl8 = ops.prop_cond(warp[-1], feat_n2, flow_a, flow_b, img_stride, cond_dtype=BF16, flows8=True)
+                    feat_n2 = hist16[-2] if i > 1 else None
+                    cond, fl, fl8 = ops.prop_cond(hist16[-1], feat_n2, flow_a, flow_b, img_stride, cond_dtype=BF16, flows8=True)
                     x = off[0]([(cond, 0), cur, (cond, ch), fl8], **lk)
                     x = off[1]([x], **lk)
                     x = off[2]([x], **lk)
                     offs = off[3]([x], out_dtype=torch.float32, residual=fl, act=ACT_DCNPOST, slope=10.0)
-                    if DCN_PLANAR:
-                        aligned = dcn([planar16[-1], planar16[-2] if i > 1 else zero16p], offs, out_dtype=BF16, planar=True)
-                    else:
-                        aligned = dcn([hist16[-1], hist16[-2] if i > 1 else zero16], offs, out_dtype=BF16)
+                    aligned = dcn([planar16[-1], planar16[-2] if i > 1 else zero16p], offs, out_dtype=BF16, planar=True)
                 srcs = [cur, stores["backward_"][idx], aligned] if name == "forward_" else [cur, aligned]
                 y = bb[0](srcs, **lk)
-                if PROP_BF16SRC:           # one bf16 result: conv source, warp source and (re-laid out) DCN source of later steps
-                    bb[1]([y], out=store16[idx], residual=aligned)
-                else:
-                    hist.append(bb[1]([y], out_dtype=torch.float32, residual=aligned, out2=store16[idx]))
+                bb[1]([y], out=store16[idx], residual=aligned)     # one bf16 result: conv, warp and (re-laid out) DCN source of later steps
                 hist16.append(store16[idx])
-                if DCN_PLANAR and i + 1 < l_t:
+                if i + 1 < l_t:
                     planar16.append(ops.to_planar16(store16[idx]))
             stores[name] = store16
         out = self.xfusion([stores["backward_"].view(l_t * b, h, w, ch), stores["forward_"].view(l_t * b, h, w, ch)],
@@ -225,13 +211,10 @@ class BF16Path:
         # GELU in front of the unfold (a gather with zero padding: GELU commutes with it, 5.4x fewer erf evaluations)
         folded = ops.ffn_fold_gelu(hid, b * t, fh, fw, H, W, 40)
         copy = torch.empty((rows, 512), dtype=BF16, device=x.device) if want_bf16_copy else None
-        if FC2_CONV:
-            y = torch.empty((rows, 512), dtype=torch.float32, device=x.device)
-            xb["fc2"]([folded], out=y.view(b * t, fh, fw, 512), residual=x1.view(b * t, fh, fw, 512),
-                      out2=None if copy is None else copy.view(b * t, fh, fw, 512))
-            return y, x1, copy
-        unf = ops.ffn_unfold(folded, fh, fw, out=hid)
-        return xb["fc2"](unf, out_dtype=torch.float32, residual=x1, out2=copy), x1, copy
+        y = torch.empty((rows, 512), dtype=torch.float32, device=x.device)
+        xb["fc2"]([folded], out=y.view(b * t, fh, fw, 512), residual=x1.view(b * t, fh, fw, 512),
+                  out2=None if copy is None else copy.view(b * t, fh, fw, 512))
+        return y, x1, copy
 
     def compose_x(self, tok16, enc, b, t, fh, fw):
         """SoftComp + residual with the encoder features (tfocal_transformer.py:65-72, e2fgvi.py:258), bf16."""

@@ -44,13 +44,11 @@ def empty_nhwc(n, h, w, c, device):
 TUNE_CANDIDATES = (0, 213, 223, 211, 219, 216)
 # Winograd block shapes: 16x16-pixel blocks x 64 / 32 couts, 8x16-pixel blocks x 32 / 64 couts
 WINO_CANDIDATES = (64, 132, 164, 32)
-# wide-tile Winograd variants (csrc/conv_wino4.hip): tile code -> (fy, couts per workgroup); F(2x4,3x3) issues 3 and
-# F(4x4,3x3) 2.25 multiplies per output and input channel (F(2x2,3x3): 4)
-W4_CODES = {2464: (2, 64), 2432: (2, 32), 4432: (4, 32)}
-# E2FGVI_WINO4=<code>: force that variant on every qualifying Winograd call with >= E2FGVI_WINO4_MINPIX output pixels
-# (A/B measurements); unset: the static per-size rule of PackedConv._wino4_rule
-_W4_FORCE = int(os.environ.get("E2FGVI_WINO4", "0") or 0)
-_W4_MINPIX = int(os.environ.get("E2FGVI_WINO4_MINPIX", "20000") or 0)
+# wide-tile Winograd variant (csrc/conv_wino4.hip): tile code -> (fy, couts per workgroup); F(2x4,3x3) issues 3 multiplies per
+# output and input channel (F(2x2,3x3): 4).  Round 6 pruned the shapes that never won a layer (F(2x4) x 32 couts, F(4x4) x 32:
+# profiles/r02_wino4_bench.txt) together with their instantiations and the E2FGVI_WINO4* switches that forced them.
+W4_CODES = {2464: (2, 64)}
+_W4_MINPIX = 20000          # output pixels from which PackedConv._wino4_rule hands a qualifying layer to F(2x4)
 # bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles; tile codes +10
 # are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
 XTUNE_CANDIDATES = (1, 4, 6, 7, 8, 2, 5, 3)
@@ -58,7 +56,7 @@ XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
 # fp32 layers on the bf16 matrix pipe by exact operand splitting (conv_bf16x.hip MODE 2, PackedConvX(x3=True)): a tuning
 # alternative of every fp32 layer that asks for it (PackedConv.try_x3 / PackedConvX.try_x3); taken when its best tile beats
 # the fp32 kernel of the call by more than X3_MARGIN.  Tile codes X3_BASE + tile in the decision table (clear of the Winograd
-# codes 2432 / 2464 / 4432 and of the 2000 + tile codes of the LDS-DMA fp32 kernel).  E2FGVI_X3=0: never.
+# code 2464 and of the 2000 + tile codes of the LDS-DMA fp32 kernel).  E2FGVI_X3=0: never.
 X3_ENABLED = os.environ.get("E2FGVI_X3", "1") != "0"
 X3_MARGIN = 0.97
 X3_BASE = 30000
@@ -67,18 +65,14 @@ W3_BASE = 40000
 # (+ 1000: LDS-DMA patch staging with two stages of lookahead -- measured slower everywhere; 5132: four positions per wave in
 #  four-wave workgroups, two per CU: 5-20 % ahead of 132 on the batched layers, level with 164 where 64 couts per workgroup fit;
 #  6064 (round 4): 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place, patch by LDS-DMA)
-W3_CANDIDATES = tuple(c for c in (132, 164, 32, 5132, 6064) if str(c) not in os.environ.get("E2FGVI_W3_SKIP", "").split(","))     # E2FGVI_W3_SKIP=6064: A/B runs
+W3_CANDIDATES = (132, 164, 32, 5132, 6064)
 # The wide-tile split-operand Winograd kernel (6064) is a candidate of every 3x3 layer, whatever runs beside it (round 5).  Round 4
 # restricted it to layers with the chip to themselves (a per-layer flag): beside the SPyNet stream it returned wrong 16x16-pixel
 # blocks.  Root cause: the weight loads for the stage past the end were in flight while the compiler had reused their
 # registers for the epilogue's addresses; fixed in conv_wino.hip for every Winograd kernel, guarded by build.verify_exit_reuse() and
 # by tests/test_gpu_hazards.py (every selectable kernel beside device copies, bit-equal to the unaccompanied launch).
-# E2FGVI_W3_WIDE=0 switches the kernel off (A/B runs).
-WIDE_X3_OK = os.environ.get("E2FGVI_W3_WIDE", "1") != "0"
-# A/B switches (measurements): E2FGVI_KV_EPILOGUE=0 -- the attention's K / V planes by a separate e2fgvi_split3_kv pass instead of
-# the qkv GEMM's epilogue; E2FGVI_DCN_TILE=<code> -- the deformable conv's tile (0 = the library's rule)
-KV_EPILOGUE = os.environ.get("E2FGVI_KV_EPILOGUE", "1") != "0"
-DCN_TILE = int(os.environ.get("E2FGVI_DCN_TILE", "0") or 0)
+# (The A/B switches of rounds 3-5 whose verdict is in: E2FGVI_W3_WIDE, _W3_SKIP, _KV_EPILOGUE, _DCN_TILE, _TAPS, _SCG_TILE, _ATT_X3
+#  are gone since round 6; what remains selectable from the environment is listed once)
 W3_WIDE = 6064
 W3_WIDE_FALLBACK = 164
 _TUNED = {}      # (layer geometry, input size class) -> tile code; shared by all layers of the same geometry (the 8 blocks)
@@ -316,15 +310,11 @@ class PackedConv:
         """tile code of the wide-tile Winograd variant for this call, or 0 for the F(2x2,3x3) kernel"""
         if W % 4 or self._w_oihw is None:
             return 0
-        if _W4_FORCE:
-            fy = W4_CODES[_W4_FORCE][0]
-            return _W4_FORCE if (N * H * W >= _W4_MINPIX and H % fy == 0) else 0
         # Measured on MI355X (tools/wino_bench.py, profiles/r02_wino4_bench.txt): F(2x4) x 64 couts beats the F(2x2) kernel
         # by 6-8 % on the batched layers with >= 256 output channels per group (encoder.layers.8 / .10) and loses
         # everywhere else (one workgroup per CU: the 16x16-pixel x 32-cout F(2x2) shape runs two); F(4x4) ties at best.
         # (... and >= 256 input channels per group: on encoder.layers.6, 128 -> 256, the 8x16x32 F(2x2) shape is 6-10 % faster)
-        if (self.Cout // self.groups >= 256 and sum(self.cpg) >= 256 and N * H * W >= _W4_MINPIX
-                and os.environ.get("E2FGVI_WINO4_AUTO", "1") != "0"):
+        if self.Cout // self.groups >= 256 and sum(self.cpg) >= 256 and N * H * W >= _W4_MINPIX:
             return 2464
         return 0
 
@@ -582,8 +572,6 @@ class PackedConv:
                     # ... and the Winograd kernel with split operands: codes W3_BASE + its block shape
                     w3 = {}
                     for shape in W3_CANDIDATES:
-                        if shape == W3_WIDE and not WIDE_X3_OK:
-                            continue
                         if launch_w3(shape)[0] != 0:
                             continue
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -602,8 +590,6 @@ class PackedConv:
             try:
                 if best and best >= W3_BASE and self._wino_x3() is not None:
                     w3_tile = best - W3_BASE
-                    if w3_tile == W3_WIDE and not WIDE_X3_OK:
-                        w3_tile = W3_WIDE_FALLBACK
                 elif best and X3_BASE <= best < W3_BASE and self._alt3() is not None:
                     return self.alt3(srcs, out=out, out_coff=out_coff, residual=residual, res_coff=res_coff, act=act, slope=slope,
                                      tile=best - X3_BASE, out_nchw=out_nchw, planes=kv_planes,
@@ -692,7 +678,7 @@ class PackedConvX:
         # narrow single-source layers (SPyNet's 7x7 stacks, the encoder's first layer): K-steps that carry several taps
         # (fp32 operands: only on request -- the one fp32 user is the FFN's second Linear as a conv, engine.py)
         self.taps = (len(self.cpg) == 1 and groups == 1 and self.cpg[0] <= 56 and self.KW > 1
-                     and (taps is True if self.f32 else taps is not False) and os.environ.get("E2FGVI_TAPS", "1") != "0")
+                     and (taps is True if self.f32 else taps is not False))
         self._wdtype = wdtype
         self._wp = None
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
@@ -933,7 +919,7 @@ class SoftCompGather:
                 self.phases.append((py, px, 1 if py == 0 else 0, 1 if px == 0 else 0, layer))
         self.bias = None if bias is None else _chk(bias.detach().float().contiguous(), "bias")
         self._bias_img = {}
-        self.tile = int(os.environ.get("E2FGVI_SCG_TILE", "0") or 0)
+        self.tile = 0
 
     def bias_image(self, fh, fw):
         """fold of the Linear's bias: [3 fh, 3 fw, C] fp32 (computed once per token grid with the fold kernel)"""
@@ -1147,7 +1133,7 @@ class PackedDcn:
         if out is None:
             out = torch.empty((N, Ho, Wo, self.Cout), dtype=out_dtype, device=sources[0].device)
         _chk_any(out, "out")
-        d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile or DCN_TILE, _dt(out)
+        d.dst, d.dst_ld, d.dst_coff, d.tile, d.dst_dtype = out.data_ptr(), out.shape[3], 0, tile, _dt(out)
         d.mfma_dtype = 2 if self.mfma_x3 else (_L.DT_BF16 if self.mfma_bf16 else _L.DT_F32)
         if _L.TRACE is not None:
             m = N * Ho * Wo * self.Cout * self.C * K
@@ -1246,7 +1232,7 @@ def attention_x3_applies(B, T, fh, fw):
     """the split-operand attention takes the call: enabled, the three planes inside one 4 GiB buffer resource, and the
     window's key table + two 48 KB stages inside the LDS"""
     rows = B * T * (fh * fw + (fh // 5) * (fw // 9))
-    return (X3_ENABLED and os.environ.get("E2FGVI_ATT_X3", "1") != "0" and 3 * rows * 2048 < 0xFFFFF000
+    return (X3_ENABLED and 3 * rows * 2048 < 0xFFFFF000
             and -(-(T * 210) // 32) * 128 + 2 * 49152 + 1280 <= 160 * 1024)
 
 

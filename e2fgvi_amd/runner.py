@@ -117,13 +117,17 @@ class ShardedStep:
         if self._pipes is None:
             keep = (self.graph, self.out)
             pipes = []
-            for _ in range(self.in_flight):
+            # the K replay streams first, back to back: torch hands out its pool's streams in creation order and HIP spreads
+            # consecutive streams over its hardware queues -- K streams taken in a row sit on K different queues (taken one by one
+            # between the captures, every other one shared a queue with an earlier one and those two pipelines ran in turn)
+            streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
+            for k in range(self.in_flight):
                 self.graph = None
                 self._capture()
                 if self.graph is None:                 # capture unsupported: sequential eager steps
                     self.in_flight, self.graph, self.out = 1, None, keep[1]
                     return self.run()
-                pipes.append([self.graph, self.out, torch.cuda.Stream(), torch.cuda.Event(), False])
+                pipes.append([self.graph, self.out, streams[k], torch.cuda.Event(), False])
             self._pipes, self._issued = pipes, 0
         K, n = self.in_flight, self._issued
         cur = torch.cuda.current_stream()

@@ -17,7 +17,7 @@ PER_ROUND = 8
 def _codes():
     from e2fgvi_amd import ops
     w3 = [ops.W3_BASE + c for c in (6064, 5132, 164, 132, 32)]         # split-operand: wide tile, four positions per wave, 8-wave shapes
-    return w3 + [2464, 2432, 4432] + [64, 32, 164, 132]               # fp32 F(2x4) / F(4x4) and the fp32 F(2x2) block shapes
+    return w3 + [2464] + [64, 32, 164, 132]                           # fp32 F(2x4) and the fp32 F(2x2) block shapes
 
 
 # (name, Cout, cpg, groups, N): the two encoder shapes the fault was found on (one source; two sources in two groups) and the

@@ -1,4 +1,4 @@
-"""Wide-tile Winograd kernels F(2x4,3x3) / F(4x4,3x3) (csrc/conv_wino4.hip) against torch fp32 conv2d -- the operator the
+"""Wide-tile Winograd kernel F(2x4,3x3) x 64 couts (csrc/conv_wino4.hip; the F(4x4) and 32-cout shapes were pruned in round 6) against torch fp32 conv2d -- the operator the
 reference runs at model/e2fgvi.py:77-93,112-150 and model/modules/feat_prop.py:20-28,73-79 -- through the C ABI
 (e2fgvi_conv3x3_winograd4).  Same contract as the F(2x2,3x3) tests of test_gpu_ops.py: virtual concat, groups, bias,
 activation, residual, strided destination, the DCN offset post-processing.  Tolerances: F(2x4) 2e-5 x rms (as F(2x2)),
@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 # floors; above them the bound grows with sqrt(input channels): the transforms' own fp32 roundings are amplified by the
 # transform coefficients (F(2x4): up to 4, F(4x4): up to 8) before the channel sum.  Measured over 4 data sets
 # (tools/gpu_suite_soak.sh): F(2x4) 1.1e-6 x sqrt(cin), F(4x4) 4.9e-6 x sqrt(cin) (x rms of the output); allowed: twice that.
-TOL = {2464: 3e-5, 2432: 3e-5, 4432: 1e-4}
-SLOPE = {2464: 2.4e-6, 2432: 2.4e-6, 4432: 1e-5}
+TOL = {2464: 3e-5}
+SLOPE = {2464: 2.4e-6}
 
 
 def wtol(code, cin, floor_scale=1.0):
@@ -42,7 +42,7 @@ W4_CASES = [
 ]
 
 
-@pytest.mark.parametrize("code", [2464, 2432, 4432])
+@pytest.mark.parametrize("code", [2464])
 @pytest.mark.parametrize("case", W4_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
 def test_conv3x3_winograd4(dev, case, code):
     from e2fgvi_amd import ops
@@ -66,7 +66,7 @@ def test_conv3x3_winograd4(dev, case, code):
     assert_close(nchw(out.cpu()), ref, wtol(code, cin_g), "winograd4 conv %d %s" % (code, case))
 
 
-@pytest.mark.parametrize("code", [2464, 2432, 4432])
+@pytest.mark.parametrize("code", [2464])
 def test_conv3x3_winograd4_residual(dev, code):
     """residual add in the epilogue (backbone.2 of the propagation: feat_prop + conv(...)), aligned and not"""
     from e2fgvi_amd import ops
@@ -83,7 +83,7 @@ def test_conv3x3_winograd4_residual(dev, code):
         assert_close(nchw(out.cpu()), ref, wtol(code, 128), "winograd4 %d conv + residual (ld %d coff %d)" % (code, res_ld, res_coff))
 
 
-@pytest.mark.parametrize("code", [2464, 2432, 4432])
+@pytest.mark.parametrize("code", [2464])
 def test_conv3x3_winograd4_dcnpost(dev, code):
     """ACT_DCNPOST epilogue (10*tanh + flow.flip on the offsets, sigmoid on the masks; feat_prop.py:38-53) == the torch
     formula (the epilogue uses hardware exp2 / rcp: absolute error ~2e-6 on offsets of magnitude ~10)"""
@@ -113,7 +113,11 @@ def test_conv3x3_winograd4_argument_errors(dev):
     layer = ops.PackedConv(w, None, [16], pad=1, algo="winograd")
     with pytest.raises(HipError):
         layer([torch.randn(1, 16, 18, 16, device=dev)], tile=2464)       # W % 4
-    with pytest.raises(HipError):
-        layer([torch.randn(1, 18, 16, 16, device=dev)], tile=4432)       # H % 4
-    out = layer([torch.randn(1, 18, 16, 16, device=dev)], tile=2432)     # H % 2 is enough for F(2x4)
+    out = layer([torch.randn(1, 18, 16, 16, device=dev)], tile=2464)     # H % 2 is enough for F(2x4)
     assert out.shape == (1, 18, 16, 32)
+    # the shapes pruned in round 6 are refused by the library, not silently replaced
+    from e2fgvi_amd import lib
+    import ctypes as C
+    d = lib.ConvDesc()
+    d.tile = 32
+    assert lib.load().e2fgvi_conv3x3_winograd4(C.byref(d), 4, None) != 0

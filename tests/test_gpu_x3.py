@@ -235,7 +235,7 @@ def test_conv3x3_winograd_x3(dev, case):
     tol = fp32_tol(cin_g * 9, floor=3e-5)
     src_d = [nhwc(s_).to(dev) for s_ in srcs]
     fp32 = layer(src_d, act=act, slope=0.2, tile=132)
-    for shape in (132, 164, 32, 1132, 1032, 5132, 6064):
+    for shape in (132, 164, 32, 5132, 6064):
         if dst_ld is None:
             out = layer(src_d, act=act, slope=0.2, tile=ops.W3_BASE + shape)
         else:
@@ -249,7 +249,7 @@ def test_conv3x3_winograd_x3(dev, case):
         assert_close(out.cpu(), fp32.cpu(), 1.5 * tol, "winograd x3 vs fp32 winograd, shape %d %s" % (shape, case))
 
 
-@pytest.mark.parametrize("shape", [132, 164, 32, 1132, 1032, 5132, 6064])
+@pytest.mark.parametrize("shape", [132, 164, 32, 5132, 6064])
 def test_conv3x3_winograd_x3_epilogues(dev, shape):
     """residual (aligned and not) and ACT_DCNPOST on the split-bf16 Winograd kernel; reruns bit-identical"""
     from e2fgvi_amd import ops
