@@ -465,7 +465,7 @@ class PackedConv:
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.groups, d.Cout, d.bk = self.groups, self.Cout, self.bk
         use_wino = self.algo == "winograd" or (self.algo == "auto" and H % 2 == 0 and W % 2 == 0 and not out_nchw
-                                               and (tile in (0, 32, 64, 132, 164) or tile in W4_CODES or 1000 < tile < 2000
+                                               and (tile in (0, 32, 64, 132, 164) or tile in W4_CODES
                                                     or tile >= W3_BASE))
         w3_tile = None                         # block shape of the split-bf16 Winograd kernel, when that is what runs
         if use_wino and tile >= W3_BASE:

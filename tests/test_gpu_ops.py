@@ -580,13 +580,10 @@ def test_conv3x3_winograd(dev, case):
     direct = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, stride=1, pad=1)([nhwc(s).to(dev) for s in srcs],
                                                                                        act=act, slope=0.2)
     assert_close(out.cpu(), direct.cpu(), 1.5 * tol, "winograd vs implicit GEMM %s" % (case,))
-    # the same block shapes with the raw patch staged by LDS-DMA (tile codes + 1000, round 3): same arithmetic in the same
-    # order -> the same bits as the register-staged kernel of that shape
+    # every block shape of the fp32 kernel agrees with the tile the case names (round 6 removed the LDS-DMA staged copies, + 1000)
     for base in (32, 64, 132, 164):
-        ref_t = layer([nhwc(s).to(dev) for s in srcs], act=act, slope=0.2, tile=base)
-        dma_t = layer([nhwc(s).to(dev) for s in srcs], act=act, slope=0.2, tile=1000 + base)
-        assert_close(nchw(dma_t.cpu()), ref, tol, "winograd conv, LDS-DMA staging, tile %d %s" % (1000 + base, case))
-        assert torch.equal(dma_t, ref_t), "LDS-DMA staged Winograd (tile %d) differs from the register-staged kernel" % (1000 + base)
+        other = layer([nhwc(s).to(dev) for s in srcs], act=act, slope=0.2, tile=base)
+        assert_close(nchw(other.cpu()), ref, tol, "winograd conv, block shape %d %s" % (base, case))
 
 
 @pytest.mark.parametrize("tile", [0, 64, 132])
