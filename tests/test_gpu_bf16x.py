@@ -319,7 +319,8 @@ def test_bf16_path_against_reference_golden(dev, fixture):
     assert_bound(d, 6e-2 if peaked else 1e-2, "bf16 golden %s max abs" % fixture)
     assert_bound(np.sqrt((diff.astype(np.float64) ** 2).mean()) / rms, 8e-2 if peaked else 2e-2, "bf16 golden %s rms of difference / rms" % fixture)
     fmax = max(1.0, float(z["flow_fwd_stats"][3]))
-    fb_bound = 0.3 if peaked else 5e-2 * max(1.0, fmax / 4)      # px; peaked: flows up to 10 px, measured 0.10 px
+    # px; peaked: flows up to 10 px at 432x240 (measured 0.10 px) and up to 26 px at 720x1296 (measured 0.44 px): 3 % of the largest
+    fb_bound = max(0.3, 3e-2 * fmax) if peaked else 5e-2 * max(1.0, fmax / 4)
     if kind == "default":
         # SPyNet at its kaiming init on unsmoothed noise (bench.py's clip): flows of up to 120 px that mean nothing; the bf16 conv
         # stacks move them by up to 4 px (3.3 % of the largest) -- and the frames still agree to 0.83 % rms
