@@ -247,7 +247,24 @@ def _successors(ins, at):
             if tgt is None:
                 raise RuntimeError("branch at 0x%x leaves the kernel" % a)
             succ.append((tgt,) if m == "s_branch" else (tgt, i + 1))
-        elif m.startswith("s_setpc") or m.startswith("s_swappc"):
+        elif m.startswith("s_setpc"):
+            # the compiler's LONG branch (a kernel of more than 128 KB: the persistent wide-tile kernel): s_getpc_b64 s[x:y] /
+            # s_add_u32 sx, sx, imm / s_addc_u32 sy, sy, hi / s_setpc_b64 s[x:y] -- target = address of the s_add + the 64-bit immediate
+            tgt = None
+            if i >= 3 and ins[i - 3][1] == "s_getpc_b64" and ins[i - 2][1] == "s_add_u32" and ins[i - 1][1] == "s_addc_u32" \
+                    and ins[i - 3][2].strip() == o.strip():
+                try:
+                    lo = int(ins[i - 2][2].split(",")[-1].strip(), 0)
+                    hi = int(ins[i - 1][2].split(",")[-1].strip(), 0)
+                    off = (hi << 32) | (lo & 0xFFFFFFFF)
+                    off -= (1 << 64) if off >= (1 << 63) else 0
+                    tgt = at.get(ins[i - 2][0] + off)
+                except ValueError:
+                    tgt = None
+            if tgt is None:
+                raise RuntimeError("indirect jump at 0x%x: control flow cannot be followed" % a)
+            succ.append((tgt,))
+        elif m.startswith("s_swappc"):
             raise RuntimeError("indirect jump at 0x%x: control flow cannot be followed" % a)
         else:
             succ.append((i + 1,) if i + 1 < len(ins) else ())
@@ -404,16 +421,18 @@ def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
                     nxt = nxt[1:]
                 todo.extend((t, dead) for t in nxt)
     if persistent:
-        # PERSISTENT kernel: weight planes are also loaded OUTSIDE the K loops -- the first tile's prologue and, under every
-        # epilogue, the next tile's first stage ("+v": into the registers the K loop reads).  From each such load to the first wait
-        # that contains vmcnt(0) on every path nothing but further plane loads may name a weight register: a compiler-made copy
-        # or spill in between would read the register before the data has landed.
-        outside = [k for k, (_, m, o) in enumerate(ins) if not inside[k] and re.match(r"buffer_load_dword", m)
-                   and not o.rstrip().endswith(" lds") and _vregs(o.split(",")[0]) & wregs]
-        if not outside:
-            raise RuntimeError("%s: %s: persistent kernel without weight loads outside its K loops (the prefetch is gone?)" % (obj, name[:60]))
-        for st in outside:
+        # PERSISTENT kernel: under every epilogue the next tile's first weight planes are loaded ("+v": into the registers the K
+        # loop reads), between the markers `s_nop 11` and `s_nop 12` of the source.  From the opening marker to the first wait that
+        # contains vmcnt(0) on every path nothing but those plane loads may name a weight register: a compiler-made copy or spill
+        # in between would read the register before the data has landed.  (The K loop's own reloads -- also the copy of its first
+        # stage that the compiler peels off for the zero accumulators -- follow the group-wait discipline that
+        # check_kernel_waits() verifies; they are not inside the markers.)
+        opens = [k for k, (_, m, o) in enumerate(ins) if m == "s_nop" and o.strip() == "11"]
+        if not opens:
+            raise RuntimeError("%s: %s: persistent kernel without the prefetch markers (s_nop 11 / 12)" % (obj, name[:60]))
+        for st in opens:
             edges += 1
+            loads = 0
             seen, todo = set(), [(t, False) for t in succ[st]]
             while todo:
                 k, dead = todo.pop()
@@ -424,11 +443,12 @@ def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
                 if m == "s_waitcnt" and "vmcnt(0)" in o:
                     continue
                 if m.startswith("s_endpgm") or (inside[k] and not dead):
-                    raise RuntimeError("%s: %s: the weight load at 0x%x reaches 0x%x (%s) without an s_waitcnt vmcnt(0)"
+                    raise RuntimeError("%s: %s: the prefetch at 0x%x reaches 0x%x (%s) without an s_waitcnt vmcnt(0)"
                                        % (obj, name[:60], ins[st][0], a, "a K loop" if inside[k] else m))
                 plane_load = re.match(r"buffer_load_dword", m) and not o.rstrip().endswith(" lds") and _vregs(o.split(",")[0]) & wregs
+                loads += 1 if plane_load else 0
                 if not dead and not m.startswith("s_") and not plane_load and _vregs(o) & wregs:
-                    raise RuntimeError("%s: %s: 0x%x %s %s touches a weight register between the load at 0x%x and its vmcnt(0)"
+                    raise RuntimeError("%s: %s: 0x%x %s %s touches a weight register between the prefetch at 0x%x and its vmcnt(0)"
                                        % (obj, name[:60], a, m, o, ins[st][0]))
                 if plane_load and not dead and _vregs(",".join(o.split(",")[1:])) & wregs:
                     raise RuntimeError("%s: %s: 0x%x %s %s reads a weight register as an address" % (obj, name[:60], a, m, o))
@@ -443,6 +463,8 @@ def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
                 elif dead and m == "s_cbranch_execnz":
                     nxt = nxt[1:]
                 todo.extend((t, dead) for t in nxt)
+            if not loads:
+                raise RuntimeError("%s: %s: no weight load behind the prefetch marker at 0x%x" % (obj, name[:60], ins[st][0]))
     return edges
 
 

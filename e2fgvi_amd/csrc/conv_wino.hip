@@ -1119,6 +1119,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        // the tile's first stage was prefetched under the previous epilogue.  (An int the compiler cannot see through: with a bool it
+        // peeled the first stage out of the K loop -- a second copy of the stage's code, outside the loop the build checks walk)
+        int held = (PS && !first) ? 1 : 0;
 
         // fragments of one row-tile: positions a = 0, 1 x planes hi, mid, lo; built one channel quad at a time
         auto prep = [&](const unsigned char* rm, bf16x8 (&A)[6]) __attribute__((always_inline)) {
@@ -1159,7 +1162,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 if constexpr (!LAST) {
                     // this position's 3 TN plane loads were issued a stage ago, and after them the other position's (a = 0: 3 TN)
                     // (issued twice: the mark build.verify_wino_waits() looks for)
-                    if (a == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(3 * TN) : "memory");
+                    // PS, first stage of a prefetched tile (`held`): the planes were waited for and claimed under the previous
+                    // epilogue; what is in flight is that epilogue's STORES and the second patch stage -- waiting here would put the
+                    // stores' acknowledge latency in front of the tile's first MFMA (measured: it cancels the whole gain)
+                    if (PS && held) {
+                    } else if (a == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(3 * TN) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
@@ -1232,6 +1239,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             mma(IC<1>{}, IC<1>{}, A1);
             u_lane += u_step;
             slot = slot == 2 ? 0 : slot + 1;
+            if (PS && held) {
+                // ... the second patch stage (issued behind the previous epilogue's E reads, in front of its stores) must have landed
+                // before this stage's barrier publishes it: everything older than this stage's own 2 NPW pieces + 6 TN plane loads.
+                // Loads return in order, so the count cannot be reached while an older load is outstanding; a store that is still
+                // unacknowledged only makes the wait pass early, and nothing here depends on the stores.
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SC * NPW + 6 * TN) : "memory");
+                held = 0;
+            }
         };
         auto stage_barrier = [&]() __attribute__((always_inline)) {
             __syncthreads();
@@ -1249,6 +1264,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             }
         } else {
             for (int st = 0; st < nstages; ++st) {
+                if constexpr (PS) asm volatile("" : "+s"(held));
                 bf16x8 A1[6];
                 first_half(A1);
                 second_half(A1);
@@ -1365,8 +1381,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 }
         constexpr bool last = nh == TN - 1;
         if (PS && last && has_next) {
-            // the accumulators are parked: their registers are free for the next tile's first weight planes (a whole pass to land)
+            // the accumulators are parked: their registers are free for the next tile's first weight planes (a whole pass to land).
+            // s_nop 11 / 12: the markers between which build.check_exit_reuse() expects these loads and from which it walks to the
+            // vmcnt(0) below, refusing any other instruction that names a weight register on the way
+            asm volatile("s_nop 11" ::: "memory");
             prefetch_all(2);
+            asm volatile("s_nop 12" ::: "memory");
             u_lane += u_step;
         }
         __syncthreads();

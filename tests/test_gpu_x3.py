@@ -439,7 +439,7 @@ def test_persistent_wide_tile_kernel_returns_the_bits_of_the_one_tile_form(dev, 
     sequence per tile -> torch.equal with the one-tile-per-workgroup form (48064) and fp32-level against fp64; 30 reruns bit-equal."""
     from e2fgvi_amd import ops
     name, N, H, W, cpg, groups, Cout, kind = case
-    g = gen(name_seed(name))
+    g = _gen(name_seed(name))
     cin_g = sum(cpg)
     w = torch.randn(Cout, cin_g, 3, 3, generator=g) / (3 * cin_g ** 0.5)
     b = torch.randn(Cout, generator=g) * 0.1
