@@ -247,31 +247,14 @@ def _successors(ins, at):
             if tgt is None:
                 raise RuntimeError("branch at 0x%x leaves the kernel" % a)
             succ.append((tgt,) if m == "s_branch" else (tgt, i + 1))
-        elif m.startswith("s_setpc"):
-            # the compiler's LONG branch (a kernel of more than 128 KB: the persistent wide-tile kernel): s_getpc_b64 s[x:y] /
-            # s_add_u32 sx, sx, imm / s_addc_u32 sy, sy, hi / s_setpc_b64 s[x:y] -- target = address of the s_add + the 64-bit immediate
-            tgt = None
-            if i >= 3 and ins[i - 3][1] == "s_getpc_b64" and ins[i - 2][1] == "s_add_u32" and ins[i - 1][1] == "s_addc_u32" \
-                    and ins[i - 3][2].strip() == o.strip():
-                try:
-                    lo = int(ins[i - 2][2].split(",")[-1].strip(), 0)
-                    hi = int(ins[i - 1][2].split(",")[-1].strip(), 0)
-                    off = (hi << 32) | (lo & 0xFFFFFFFF)
-                    off -= (1 << 64) if off >= (1 << 63) else 0
-                    tgt = at.get(ins[i - 2][0] + off)
-                except ValueError:
-                    tgt = None
-            if tgt is None:
-                raise RuntimeError("indirect jump at 0x%x: control flow cannot be followed" % a)
-            succ.append((tgt,))
-        elif m.startswith("s_swappc"):
+        elif m.startswith("s_setpc") or m.startswith("s_swappc"):
             raise RuntimeError("indirect jump at 0x%x: control flow cannot be followed" % a)
         else:
             succ.append((i + 1,) if i + 1 < len(ins) else ())
     return succ
 
 
-def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
+def check_exit_reuse(obj, name, ins, min_mfma=8):
     """For hipcc the destination of an inline-asm load is written when the statement ends.  The weight loads a K loop issues for
     the stage PAST the end are still in flight when the loop exits; if the compiler reuses their registers (it did: for the
     epilogue's address arithmetic, hoisted above the kernel's own `s_waitcnt vmcnt(0)`) the late data lands on top of the new values
@@ -293,8 +276,6 @@ def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
 
     Returns the number of exit edges walked; raises RuntimeError on a violation."""
     import re
-    if persistent is None:
-        persistent = re.search(r"conv_wino_x3w_kernelILi\d+ELb1E", name) is not None       # <BN, PS = true>
     at = {a: i for i, (a, _, _) in enumerate(ins)}
     succ = _successors(ins, at)
     is_mfma = [("mfma" in m) for _, m, _ in ins]
@@ -313,72 +294,46 @@ def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
     # K loops: the strongly connected components of the control-flow graph that hold >= min_mfma MFMAs (Tarjan, iterative).  Address
     # ranges of backward branches would not do: block placement puts parts of the epilogue in front of the loops.
     n = len(ins)
-
-    def components(nodes, edges):
-        """strongly connected components (lists of instruction indices) of the sub-graph on `nodes` with successor lists `edges`"""
-        index, low, comp = {}, {}, {}
-        stack, onstack, out = [], set(), []
-        counter = 0
-        for root in nodes:
-            if root in index:
+    index, low, comp = [-1] * n, [0] * n, [-1] * n
+    stack, onstack, counter, ncomp = [], [False] * n, 0, 0
+    for root in range(n):
+        if index[root] >= 0:
+            continue
+        work = [(root, 0)]
+        while work:
+            v, pi = work.pop()
+            if pi == 0:
+                index[v] = low[v] = counter
+                counter += 1
+                stack.append(v)
+                onstack[v] = True
+            recurse = False
+            for j in range(pi, len(succ[v])):
+                w = succ[v][j]
+                if index[w] < 0:
+                    work.append((v, j + 1))
+                    work.append((w, 0))
+                    recurse = True
+                    break
+                if onstack[w]:
+                    low[v] = min(low[v], index[w])
+            if recurse:
                 continue
-            work = [(root, 0)]
-            while work:
-                v, pi = work.pop()
-                if pi == 0:
-                    index[v] = low[v] = counter
-                    counter += 1
-                    stack.append(v)
-                    onstack.add(v)
-                recurse = False
-                ev = edges[v]
-                for j in range(pi, len(ev)):
-                    w = ev[j]
-                    if w not in index:
-                        work.append((v, j + 1))
-                        work.append((w, 0))
-                        recurse = True
+            if low[v] == index[v]:
+                while True:
+                    w = stack.pop()
+                    onstack[w] = False
+                    comp[w] = ncomp
+                    if w == v:
                         break
-                    if w in onstack:
-                        low[v] = min(low[v], index[w])
-                if recurse:
-                    continue
-                if low[v] == index[v]:
-                    c = []
-                    while True:
-                        w = stack.pop()
-                        onstack.discard(w)
-                        c.append(w)
-                        if w == v:
-                            break
-                    out.append(c)
-                if work:
-                    u = work[-1][0]
-                    low[u] = min(low[u], low[v])
-        return out
-
-    def k_loops(nodes, edges, depth=0):
-        found = []
-        for c in components(nodes, edges):
-            if len(c) < 2 or sum(1 for k in c if is_mfma[k]) < min_mfma:
-                continue
-            # A PERSISTENT kernel (round 6: conv_wino_x3w_kernel<.., PS = true>) wraps the wave roles' K loops, the post-loop wait and
-            # the epilogue in a tile loop: one component.  Cut the edges from inside the component into its header(s) -- the nodes a
-            # predecessor outside the component reaches: the tile loop is entered from the kernel's preamble -- and the K loops are
-            # the components of what is left; a plain K loop has no MFMA-holding cycle left once its own back edge is cut.
-            cs = set(c)
-            preds_out = set()
-            for u in range(n):
-                if u not in cs:
-                    for w in succ[u]:
-                        if w in cs:
-                            preds_out.add(w)
-            cut = {v: [w for w in edges[v] if w in cs and w not in preds_out] for v in c}
-            inner = k_loops(sorted(c), cut, depth + 1) if depth < 2 and preds_out else []
-            found += inner if inner else [c]
-        return found
-
-    loops = k_loops(list(range(n)), {k: list(succ[k]) for k in range(n)})
+                ncomp += 1
+            if work:
+                u = work[-1][0]
+                low[u] = min(low[u], low[v])
+    members = {}
+    for k in range(n):
+        members.setdefault(comp[k], []).append(k)
+    loops = [m for m in members.values() if len(m) > 1 and sum(1 for k in m if is_mfma[k]) >= min_mfma]
     inside = [False] * n
     for m in loops:
         for k in m:
@@ -420,51 +375,6 @@ def check_exit_reuse(obj, name, ins, min_mfma=8, persistent=None):
                 elif dead and m == "s_cbranch_execnz":
                     nxt = nxt[1:]
                 todo.extend((t, dead) for t in nxt)
-    if persistent:
-        # PERSISTENT kernel: under every epilogue the next tile's first weight planes are loaded ("+v": into the registers the K
-        # loop reads), between the markers `s_nop 11` and `s_nop 12` of the source.  From the opening marker to the first wait that
-        # contains vmcnt(0) on every path nothing but those plane loads may name a weight register: a compiler-made copy or spill
-        # in between would read the register before the data has landed.  (The K loop's own reloads -- also the copy of its first
-        # stage that the compiler peels off for the zero accumulators -- follow the group-wait discipline that
-        # check_kernel_waits() verifies; they are not inside the markers.)
-        opens = [k for k, (_, m, o) in enumerate(ins) if m == "s_nop" and o.strip() == "11"]
-        if not opens:
-            raise RuntimeError("%s: %s: persistent kernel without the prefetch markers (s_nop 11 / 12)" % (obj, name[:60]))
-        for st in opens:
-            edges += 1
-            loads = 0
-            seen, todo = set(), [(t, False) for t in succ[st]]
-            while todo:
-                k, dead = todo.pop()
-                if (k, dead) in seen:
-                    continue
-                seen.add((k, dead))
-                a, m, o = ins[k]
-                if m == "s_waitcnt" and "vmcnt(0)" in o:
-                    continue
-                if m.startswith("s_endpgm") or (inside[k] and not dead):
-                    raise RuntimeError("%s: %s: the prefetch at 0x%x reaches 0x%x (%s) without an s_waitcnt vmcnt(0)"
-                                       % (obj, name[:60], ins[st][0], a, "a K loop" if inside[k] else m))
-                plane_load = re.match(r"buffer_load_dword", m) and not o.rstrip().endswith(" lds") and _vregs(o.split(",")[0]) & wregs
-                loads += 1 if plane_load else 0
-                if not dead and not m.startswith("s_") and not plane_load and _vregs(o) & wregs:
-                    raise RuntimeError("%s: %s: 0x%x %s %s touches a weight register between the prefetch at 0x%x and its vmcnt(0)"
-                                       % (obj, name[:60], a, m, o, ins[st][0]))
-                if plane_load and not dead and _vregs(",".join(o.split(",")[1:])) & wregs:
-                    raise RuntimeError("%s: %s: 0x%x %s %s reads a weight register as an address" % (obj, name[:60], a, m, o))
-                flip = m == "s_andn2_saveexec_b64" or (m == "s_xor_b64" and o.startswith("exec"))
-                if flip and not dead:
-                    dead = True
-                elif m in ("s_or_b64", "s_mov_b64") and o.startswith("exec"):
-                    dead = False
-                nxt = succ[k]
-                if dead and m == "s_cbranch_execz":
-                    nxt = nxt[:1]
-                elif dead and m == "s_cbranch_execnz":
-                    nxt = nxt[1:]
-                todo.extend((t, dead) for t in nxt)
-            if not loads:
-                raise RuntimeError("%s: %s: no weight load behind the prefetch marker at 0x%x" % (obj, name[:60], ins[st][0]))
     return edges
 
 

@@ -926,14 +926,7 @@ __device__ __forceinline__ void wino_split4(const f32x4& v, unsigned (&H)[2], un
 // barrier and the next stage's first fragment phase to land.  Wave w owns the transform positions 2w, 2w + 1 as in the
 // eight-wave kernel; fragments are built one row-tile at a time, one channel quad at a time (12 fragment registers per
 // position), the patch of stage st + 1 is parked between the two row-tiles' MFMA blocks.
-// PS (round 6): PERSISTENT form.  One workgroup per CU walks the tiles of its XCD's range (gridDim.x workgroups per group
-// instead of one per tile), and the next tile's prologue -- source-pixel indices, the LDS-DMA of its first patch stage, its first
-// weight planes -- is issued UNDER the current tile's epilogue instead of behind a workgroup launch: the epilogue's position
-// buffer E moves up by one stage (LDS: stage slot 0 | E over slots 1, 2 and beyond: 28 + 128 = 156 KB), so slot 0 can be filled
-// while E is in use; the second stage goes into slot 1 as soon as the last pass has read E.  Per tile the kernel's K-independent
-// cost (profiles/r05_x3w_fixed_cost.txt: 9.3 - 10.6 us = launch + prologue latency + epilogue) loses the launch and the
-// prologue's memory latency.  Same MFMA sequence per tile: the results are bit-identical to the one-tile-per-workgroup form.
-template <int BN, bool PS>
+template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams p) {
     constexpr int MT = 2, SC = 2;
     constexpr int TN = BN / 32;
@@ -946,9 +939,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
     constexpr int NSTAGE = 3;
     constexpr int TILES = 32 * MT;
     constexpr int EPI_BYTES = 16 * TILES * 32 * 4;
-    constexpr int E_OFF = PS ? STAGE_BYTES : 0;                            // PS: the position buffer leaves stage slot 0 free
-    constexpr int SMEM = PS ? E_OFF + EPI_BYTES : ((NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES);
-    static_assert(SMEM <= 160 * 1024 && E_OFF + EPI_BYTES >= NSTAGE * STAGE_BYTES, "LDS");
+    constexpr int SMEM = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
     constexpr int PIECES = CHUNK_BYTES / 1024;                            // wave w issues the pieces w, w + 8 of a chunk
     constexpr int NPMAX = (PIECES + 7) / 8;
 
@@ -957,42 +948,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.y;
+    const int logical = xcd_remap(blockIdx.x, p.nblk);
     const int mblocks = p.N * p.blocksY * p.blocksX;
-    // the tiles of this workgroup: one (PS = false), or every (gridDim.x / 8)-th tile of its XCD's contiguous range of the
-    // xcd_remap order (PS; gridDim.x is a multiple of 8) -- a workgroup stays inside one cout tile's weight slab as long as the range does
-    int logical, t_end = 0, t_step = 0;
-    if constexpr (PS) {
-        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        t_end = lo + q + (xcd < r ? 1 : 0);
-        t_step = gridDim.x >> 3;
-        logical = lo + idx;
-        if (logical >= t_end) return;
-    } else {
-        logical = xcd_remap(blockIdx.x, p.nblk);
-    }
-    int tile_n, img, by, bx, n0, y0, x0;
-    auto decode = [&](int lg) __attribute__((always_inline)) {
-        tile_n = lg / mblocks;
-        int rem = lg - tile_n * mblocks;
-        img = rem / (p.blocksY * p.blocksX);
-        rem -= img * (p.blocksY * p.blocksX);
-        by = rem / p.blocksX;
-        bx = rem - by * p.blocksX;
-        n0 = tile_n * BN;
-        y0 = by * (8 * MT) - 1;
-        x0 = bx * 16 - 1;
-    };
-    decode(logical);
+    const int tile_n = logical / mblocks;
+    int rem = logical - tile_n * mblocks;
+    const int img = rem / (p.blocksY * p.blocksX);
+    rem -= img * (p.blocksY * p.blocksX);
+    const int by = rem / p.blocksX, bx = rem - by * p.blocksX;
+    const int n0 = tile_n * BN;
+    const int y0 = by * (8 * MT) - 1, x0 = bx * 16 - 1;
 
     // The raw patch goes global -> LDS by LDS-DMA (no staging registers: the 128 accumulator + 48 weight registers leave no room
     // for them): each lane fetches the 16-byte unit that belongs at its LDS position of piece j of its wave (unit U of the chunk
     // area = plane [kq][column parity], patch row, column pair; padding units and pixels outside the image fetch out of range =
     // zeros).  dma_pix: the source pixel, bit 31 set = nothing to fetch; bit 30 = the channel quad kq of the unit's plane.
     unsigned dma_pix[NPMAX];
-    // (a function of the tile: PS recomputes it per tile -- a dozen integer instructions with compile-time divisors -- rather than
-    //  carrying the unit's patch coordinates through the K loop, whose register budget is full)
-    auto set_pix = [&]() __attribute__((always_inline)) {
+    {
         constexpr int UP = PLANE_BYTES / 16;
 #pragma unroll
         for (int j = 0; j < NPMAX; ++j) {
@@ -1004,23 +975,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             const bool in = plane < 4 && py < RAW_H && c < RAW_W / 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             dma_pix[j] = in ? ((unsigned)((img * p.H + gy) * p.W + gx) | ((unsigned)(plane >> 1) << 30)) : OOB;
         }
-    };
-    set_pix();
+    }
     const unsigned smem_lds = (unsigned)(unsigned long long)(wino_lds_void*)smem;
     // The source walk of the pieces (chunks are fetched strictly in order: 0, 1, 2, ...): the parameters of the source being
     // walked live in scalar registers and are re-read from the kernel arguments only when the walk crosses into the next source
     // (past the last chunk the pieces fetch out of range, and so do those stages' weights: zeros).
-    int w_s, w_c0, w_cpg, w_left;   // w_left: chunks of the walk still inside the layer: the pieces of the two stages past the end fetch out of range
-    const float* w_src;
-    unsigned w_bytes, w_ld4, w_chan;
-    auto reset_walk = [&]() __attribute__((always_inline)) {
-        w_s = 0; w_c0 = 0;
-        w_src = p.src[0];
-        w_bytes = p.src_bytes[0]; w_ld4 = (unsigned)p.ld[0] * 4u; w_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
-        w_cpg = p.cpg[0];
-        w_left = p.nchunks;
-    };
-    reset_walk();
+    int w_s = 0, w_c0 = 0;
+    const float* w_src = p.src[0];
+    unsigned w_bytes = p.src_bytes[0], w_ld4 = (unsigned)p.ld[0] * 4u, w_chan = (unsigned)(p.coff[0] + g * p.cpg[0]) * 4u;
+    int w_cpg = p.cpg[0];
+    int w_left = p.nchunks;         // chunks of the walk still inside the layer: the pieces of the two stages past the end fetch out of range
     // the pieces of wave WV of the NEXT chunk of the walk -> LDS chunk area lds_chunk; exactly NPW vector-memory instructions
     auto dma_chunk = [&](auto W_, auto NPW_, unsigned lds_chunk) __attribute__((always_inline)) {
         constexpr int WV = decltype(W_)::value, NPW = decltype(NPW_)::value;
@@ -1065,16 +1029,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
     const unsigned u_step = 96u * (unsigned)p.Npad * 16u;
     const unsigned u_plane = 2u * (unsigned)p.Npad * 16u;
     unsigned u_lane = (unsigned)((h * p.Npad + n0 + i) * 16);
-    bool first = true;                      // PS: the first tile of this workgroup (its prologue runs inside k_loop, like PS = false)
     auto load_plane = [&](f32x4& v, unsigned soff) __attribute__((always_inline)) {
         // s_nop 4: the scalar offset may be a spilled SGPR that the compiler has just restored with v_readlane (a VALU write of an
         // SGPR needs 5 wait states before a vector-memory instruction reads it, and the hazard recognizer does not look inside an
         // asm statement: without the nops, single plane loads used a stale offset in a few workgroups per launch)
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(u_lane), "s"(wrsrc), "s"(soff) : "memory");
-    };
-    // (PS: the next tile's first planes, loaded under the epilogue INTO the registers the K loop reads -- the operand is tied, "+v")
-    auto load_plane_tied = [&](f32x4& v, unsigned soff) __attribute__((always_inline)) {
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(v) : "v"(u_lane), "s"(wrsrc), "s"(soff) : "memory");
     };
     f32x4 bw[2][TN][3];
     f32x16 acc[2][MT][TN];
@@ -1103,25 +1062,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
 #pragma unroll
         for (int n = 0; n < TN; ++n) u_n[n] = (n0 + n * 32 < p.Npad) ? (unsigned)(n * 32 * 16) : 0u;
         // prologue: stages 0 and 1 of the patch, stage 0's planes; everything waited for
-        // (PS, every tile but the workgroup's first: issued under the previous tile's epilogue, see `prefetch` below)
-        if (!PS || first) {
 #pragma unroll
-            for (int c4 = 0; c4 < 2 * SC; ++c4)
-                dma_chunk(IC<WV>{}, IC<NPW>{}, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
+        for (int c4 = 0; c4 < 2 * SC; ++c4)
+            dma_chunk(IC<WV>{}, IC<NPW>{}, smem_lds + (unsigned)((c4 / SC) * STAGE_BYTES + (c4 % SC) * CHUNK_BYTES));
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int n = 0; n < TN; ++n)
+            for (int n = 0; n < TN; ++n)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        load_plane(bw[a][n][pl], u_pos + (unsigned)(a * 3 + pl) * u_plane + u_n[n]);
-            u_lane += u_step;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        // the tile's first stage was prefetched under the previous epilogue.  (An int the compiler cannot see through: with a bool it
-        // peeled the first stage out of the K loop -- a second copy of the stage's code, outside the loop the build checks walk)
-        int held = (PS && !first) ? 1 : 0;
+                for (int pl = 0; pl < 3; ++pl)
+                    load_plane(bw[a][n][pl], u_pos + (unsigned)(a * 3 + pl) * u_plane + u_n[n]);
+        u_lane += u_step;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 
         // fragments of one row-tile: positions a = 0, 1 x planes hi, mid, lo; built one channel quad at a time
         auto prep = [&](const unsigned char* rm, bf16x8 (&A)[6]) __attribute__((always_inline)) {
@@ -1162,11 +1115,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 if constexpr (!LAST) {
                     // this position's 3 TN plane loads were issued a stage ago, and after them the other position's (a = 0: 3 TN)
                     // (issued twice: the mark build.verify_wino_waits() looks for)
-                    // PS, first stage of a prefetched tile (`held`): the planes were waited for and claimed under the previous
-                    // epilogue; what is in flight is that epilogue's STORES and the second patch stage -- waiting here would put the
-                    // stores' acknowledge latency in front of the tile's first MFMA (measured: it cancels the whole gain)
-                    if (PS && held) {
-                    } else if (a == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(3 * TN) : "memory");
+                    if (a == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt vmcnt(%0)" ::"n"(3 * TN) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
@@ -1239,14 +1188,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             mma(IC<1>{}, IC<1>{}, A1);
             u_lane += u_step;
             slot = slot == 2 ? 0 : slot + 1;
-            if (PS && held) {
-                // ... the second patch stage (issued behind the previous epilogue's E reads, in front of its stores) must have landed
-                // before this stage's barrier publishes it: everything older than this stage's own 2 NPW pieces + 6 TN plane loads.
-                // Loads return in order, so the count cannot be reached while an older load is outstanding; a store that is still
-                // unacknowledged only makes the wait pass early, and nothing here depends on the stores.
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SC * NPW + 6 * TN) : "memory");
-                held = 0;
-            }
         };
         auto stage_barrier = [&]() __attribute__((always_inline)) {
             __syncthreads();
@@ -1264,7 +1205,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             }
         } else {
             for (int st = 0; st < nstages; ++st) {
-                if constexpr (PS) asm volatile("" : "+s"(held));
                 bf16x8 A1[6];
                 first_half(A1);
                 second_half(A1);
@@ -1272,47 +1212,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             }
         }
     };
-    // PS: the next tile's prologue pieces, issued from inside the epilogue of the current one.  `pre_patch(s)`: this wave's LDS-DMA
-    // pieces of the next two chunks of the (freshly reset) source walk into stage slot s; `pre_planes`: the first stage's weight
-    // planes into the registers the K loop reads them from ("+v": the very registers -- the loop's own reloads are tied the same
-    // way through `bw`), at the lane offset of the NEXT tile's columns.  Both in the wave's own role constants, like the K loop.
-    auto prefetch = [&](auto W_, int what) __attribute__((always_inline)) {
-        constexpr int WV = decltype(W_)::value;
-        constexpr int NPW = (PIECES - WV + 7) / 8;
-        if (what < 2) {
-#pragma unroll
-            for (int q = 0; q < SC; ++q) dma_chunk(IC<WV>{}, IC<NPW>{}, smem_lds + (unsigned)(what * STAGE_BYTES + q * CHUNK_BYTES));
-        } else {
-            const unsigned u_pos = (unsigned)(WV * 2 * 6) * (unsigned)p.Npad * 16u;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    const unsigned u_nn = (n0 + n * 32 < p.Npad) ? (unsigned)(n * 32 * 16) : 0u;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned soff = u_pos + (unsigned)(a * 3 + pl) * u_plane + u_nn;
-                        load_plane_tied(bw[a][n][pl], soff);
-                    }
-                }
-        }
-    };
-    auto prefetch_all = [&](int what) __attribute__((always_inline)) {
-        switch (wave) {
-            case 0: prefetch(IC<0>{}, what); break;
-            case 1: prefetch(IC<1>{}, what); break;
-            case 2: prefetch(IC<2>{}, what); break;
-            case 3: prefetch(IC<3>{}, what); break;
-            case 4: prefetch(IC<4>{}, what); break;
-            case 5: prefetch(IC<5>{}, what); break;
-            case 6: prefetch(IC<6>{}, what); break;
-            default: prefetch(IC<7>{}, what); break;
-        }
-    };
-
-    float* E = reinterpret_cast<float*>(smem + E_OFF);
-    const int HW = p.H * p.W;
-    for (;;) {
     switch (wave) {          // wave-uniform
         case 0: k_loop(IC<0>{}, IC<0>{}); break;
         case 1: k_loop(IC<0>{}, IC<1>{}); break;
@@ -1338,37 +1237,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             for (int pl = 0; pl < 3; ++pl) E2_CLAIM_AFTER_LOOP(bw[a][n][pl]);
     __syncthreads();
 
-    // the tile whose results are in the accumulators (the epilogue below), and -- PS -- the next one (the prefetch)
-    const int e_n0 = n0, e_img = img, e_by = by, e_bx = bx;
-    // PS: the epilogue's lane-derived indices are formed HERE, per tile, from an opaque copy of the thread index: as invariants of
-    // the tile loop the compiler computed them once in front of the K loop, whose register budget is full, and spilled them
-    int tid_e = tid;
-    if constexpr (PS) asm volatile("" : "+v"(tid_e));
-    const int i_e = tid_e & 31, h_e = (tid_e >> 5) & 1;
-    bool has_next = false;
-    if constexpr (PS) {
-        logical += t_step;
-        has_next = logical < t_end;
-        if (has_next) {
-            decode(logical);
-            set_pix();
-            reset_walk();
-            u_lane = (unsigned)((h_e * p.Npad + n0 + i_e) * 16);
-            prefetch_all(0);                   // patch stage 0 -> slot 0 (outside E)
-        }
-    }
-
     // ---- epilogue: gather the 16 positions in LDS, inverse transform, bias, residual, activation, store
-    auto claim_planes = [&]() __attribute__((always_inline)) {
+    float* E = reinterpret_cast<float*>(smem);
+    const int HW = p.H * p.W;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int n2 = 0; n2 < TN; ++n2)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) E2_CLAIM_AFTER_LOOP(bw[a][n2][pl]);
-    };
-    auto epi_pass = [&](auto NH_) __attribute__((always_inline)) {
-        constexpr int nh = decltype(NH_)::value;
+    for (int nh = 0; nh < TN; ++nh) {
         if (nh) __syncthreads();
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1376,40 +1249,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h_e;
-                    E[((2 * wave + a) * TILES + tile) * 32 + i_e] = acc[a][m][nh][r];
+                    const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    E[((2 * wave + a) * TILES + tile) * 32 + i] = acc[a][m][nh][r];
                 }
-        constexpr bool last = nh == TN - 1;
-        if (PS && last && has_next) {
-            // the accumulators are parked: their registers are free for the next tile's first weight planes (a whole pass to land).
-            // s_nop 11 / 12: the markers between which build.check_exit_reuse() expects these loads and from which it walks to the
-            // vmcnt(0) below, refusing any other instruction that names a weight register on the way
-            asm volatile("s_nop 11" ::: "memory");
-            prefetch_all(2);
-            asm volatile("s_nop 12" ::: "memory");
-            u_lane += u_step;
-        }
         __syncthreads();
-        const int cq = tid_e & 7, tile = tid_e >> 3;
-        const int n = e_n0 + nh * 32 + cq * 4;
-        const int oy = e_by * (8 * MT) + 2 * (tile >> 3), ox = e_bx * 16 + 2 * (tile & 7);
-        const bool act_t = tile < TILES && n < p.Cout_g && oy < p.H && ox < p.W;
-        f32x4 mm[16];
-        if (act_t) {
+        const int cq = tid & 7, tile = tid >> 3;
+        const int n = n0 + nh * 32 + cq * 4;
+        const int oy = by * (8 * MT) + 2 * (tile >> 3), ox = bx * 16 + 2 * (tile & 7);
+        if (tile < TILES && n < p.Cout_g && oy < p.H && ox < p.W) {
+            f32x4 mm[16];
 #pragma unroll
             for (int a = 0; a < 16; ++a) mm[a] = *reinterpret_cast<const f32x4*>(E + (a * TILES + tile) * 32 + cq * 4);
-        }
-        if (PS && last) {
-            // E has been read (this wave: the lgkmcnt wait; all waves: the barrier), stage 0 and the planes have landed (vmcnt: in
-            // front of this pass's stores, so that the wait does not include them): slot 1 -- inside E -- takes the second stage.
-            // (Unconditional, also behind the workgroup's last tile: every path from the plane loads above leads through this wait,
-            //  which is what build.check_exit_reuse() verifies in the generated code.)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            claim_planes();
-            __syncthreads();
-            if (has_next) prefetch_all(1);
-        }
-        if (act_t) {
             f32x4 t0[4], t1[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
@@ -1422,7 +1272,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
             y[2] = t1[0] + t1[1] + t1[2];
             y[3] = t1[1] - t1[2] - t1[3];
             const int co = g * p.Cout_g + n;
-            const long long pix0 = (long long)e_img * HW + (long long)oy * p.W + ox;
+            const long long pix0 = (long long)img * HW + (long long)oy * p.W + ox;
             const int pstep[4] = {0, 1, p.W, p.W + 1};
             const bool full = n + 3 < p.Cout_g;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -1459,20 +1309,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_x3w_kernel(const WinoParams 
                 }
             }
         }
-    };
-    epi_pass(IC<0>{});
-    if constexpr (TN > 1) epi_pass(IC<1>{});
-    static_assert(TN <= 2, "epilogue passes");
-    if (!PS || !has_next) break;
-    first = false;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
     }
 }
 #endif
@@ -1660,20 +1496,14 @@ static int launch_wino_p4(WinoParams& p, int groups, hipStream_t st) {
 
 #if E2_WINO_X3
 template <int BN>
-static int launch_wino_w(WinoParams& p, int groups, hipStream_t st, int persist) {
+static int launch_wino_w(WinoParams& p, int groups, hipStream_t st) {
     p.blocksY = cdiv(p.H, 16);
     p.blocksX = cdiv(p.W, 16);
     p.tilesN = cdiv(p.Cout_g, BN);
     const long long nblk = (long long)p.N * p.blocksY * p.blocksX * p.tilesN;
     E2_REQUIRE(nblk < 2147483647LL, E2FGVI_EUNSUP, "conv3x3_winograd_x3: grid too large");
     p.nblk = (int)nblk;
-    // persist: 0 = one workgroup per tile, 1 = persistent workgroups (256 / groups per group, a multiple of 8) walking the tiles,
-    // -1 = persistent when a group's tiles number at least twice its workgroups (every workgroup then overlaps a prologue with an
-    // epilogue at least once; with fewer tiles the one-tile form has no launch to hide)
-    const int wgs = (256 / groups) & ~7;
-    const bool ps = wgs >= 8 && p.nblk > wgs && (persist == 1 || (persist < 0 && p.nblk >= 2 * wgs));
-    if (ps) hipLaunchKernelGGL((conv_wino_x3w_kernel<BN, true>), dim3(wgs, groups, 1), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv_wino_x3w_kernel<BN, false>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_wino_x3w_kernel<BN>), dim3(p.nblk, groups, 1), dim3(512), 0, st, p);
     E2_LAUNCH_CHECK("conv3x3_winograd_x3 (wide tile)");
     return 0;
 }
@@ -1745,11 +1575,7 @@ static int wino_run(const e2fgvi_conv_desc* d, void* stream, bool x3) {
         // + 5000: four positions per wave, four-wave workgroups (two per CU)
         case 5132: return launch_wino_p4<32>(p, d->groups, st);
         // + 6000: 16x16-pixel blocks x 64 couts, single-buffered weights reloaded in place (round 4)
-        //         6064: persistent workgroups when the layer has the tiles for it (round 6), 7064: always, 8064: never -- the three
-        //         run the same MFMA sequence per tile and return the same bits
-        case 6064: return launch_wino_w<64>(p, d->groups, st, -1);
-        case 7064: return launch_wino_w<64>(p, d->groups, st, 1);
-        case 8064: return launch_wino_w<64>(p, d->groups, st, 0);
+        case 6064: return launch_wino_w<64>(p, d->groups, st);
         default: break;
     }
     e2fgvi_set_error("conv3x3_winograd_x3: tile must be 0 (auto), 32 (16x16-pixel blocks) or 132, 164 (8x16-pixel blocks)");

@@ -16,7 +16,7 @@ PER_ROUND = 8
 
 def _codes():
     from e2fgvi_amd import ops
-    w3 = [ops.W3_BASE + c for c in (6064, 7064, 8064, 5132, 164, 132, 32)]         # split-operand: wide tile, four positions per wave, 8-wave shapes
+    w3 = [ops.W3_BASE + c for c in (6064, 5132, 164, 132, 32)]         # split-operand: wide tile, four positions per wave, 8-wave shapes
     return w3 + [2464] + [64, 32, 164, 132]                           # fp32 F(2x4) and the fp32 F(2x2) block shapes
 
 

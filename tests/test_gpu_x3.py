@@ -418,47 +418,3 @@ def test_qkv_epilogue_writes_the_attention_planes(dev, rows):
     assert torch.equal(y[:, :512], ref[:, :512]) and torch.equal(planes, ops.split3_kv(ref))
     with pytest.raises(Exception):
         layer([x4], out=out, planes=planes[:, :, :1000].contiguous(), split_from=512)
-
-
-PS_CASES = [
-    # name, N, H, W, cpg, groups, Cout, kind of epilogue
-    ("encoder.10", 10, 60, 108, [128, 192], 2, 512, "lrelu"),          # two sources in two groups, 8.75 tiles per CU
-    ("decoder.4", 4, 240, 432, [64], 1, 64, "lrelu"),                  # 4 stages, 6.3 tiles per CU
-    ("decoder.0 + residual", 10, 120, 216, [128], 1, 128, "res"),
-    ("odd couts, partial blocks", 12, 52, 100, [40, 24], 1, 200, "lrelu"),    # Cout_g not a multiple of 64, 4-channel chunk tails
-    ("conv_offset.6 batched", 6, 60, 108, [128], 1, 432, "dcnpost"),
-    ("four groups", 8, 60, 108, [64, 128], 4, 384, "lrelu"),           # 64 workgroups per group
-    ("few tiles", 1, 60, 108, [128], 1, 128, "lrelu"),                 # fewer tiles than workgroups: the one-tile form runs
-]
-
-
-@pytest.mark.parametrize("case", PS_CASES, ids=[c[0] for c in PS_CASES])
-def test_persistent_wide_tile_kernel_returns_the_bits_of_the_one_tile_form(dev, case):
-    """conv_wino_x3w_kernel<64, PS = true> (round 6, tile code 47064; 46064 picks it when a group has >= 2 tiles per workgroup): a
-    workgroup walks its tiles and issues the next tile's first patch stage and weight planes under the current epilogue.  Same MFMA
-    sequence per tile -> torch.equal with the one-tile-per-workgroup form (48064) and fp32-level against fp64; 30 reruns bit-equal."""
-    from e2fgvi_amd import ops
-    name, N, H, W, cpg, groups, Cout, kind = case
-    g = _gen(name_seed(name))
-    cin_g = sum(cpg)
-    w = torch.randn(Cout, cin_g, 3, 3, generator=g) / (3 * cin_g ** 0.5)
-    b = torch.randn(Cout, generator=g) * 0.1
-    srcs = [torch.randn(N, H, W, c * groups, generator=g).to(dev) for c in cpg]
-    layer = ops.PackedConv(w.to(dev), b.to(dev), cpg, groups=groups, pad=1, algo="winograd")
-    kw = dict(act=ops.ACT_LRELU, slope=0.2)
-    if kind == "res":
-        kw["residual"] = torch.randn(N, H, W, Cout, generator=g).to(dev)
-    if kind == "dcnpost":
-        kw = dict(residual=(3 * torch.randn(N, H, W, 4, generator=g)).to(dev), act=ops.ACT_DCNPOST, slope=10.0)
-    one = layer(srcs, tile=ops.W3_BASE + 8064, **kw)
-    ps = layer(srcs, tile=ops.W3_BASE + 7064, **kw)
-    auto = layer(srcs, tile=ops.W3_BASE + 6064, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal(ps, one), "persistent form differs: max %.3e" % float((ps - one).abs().max())
-    assert torch.equal(auto, one)
-    bad = sum(int(not torch.equal(layer(srcs, tile=ops.W3_BASE + 7064, **kw), one)) for _ in range(30))
-    assert bad == 0, "%d of 30 reruns of the persistent form differ" % bad
-    if kind == "lrelu":
-        xs = torch.cat([torch.cat([t[..., gi * c:(gi + 1) * c] for t, c in zip(srcs, cpg)], 3) for gi in range(groups)], 3).cpu()
-        ref = F.leaky_relu(F.conv2d(xs.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1, groups=groups), 0.2).permute(0, 2, 3, 1)
-        assert_close(ps.cpu(), ref, 3e-5 * max(1.0, (cin_g / 128) ** 0.5), "persistent wide-tile kernel %s vs fp64" % name)

@@ -23,21 +23,19 @@ def timed(fn, reps=10):
     return best
 
 
-CODES = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8064, 7064]     # 8064: one tile per workgroup, 7064: persistent
-for code in CODES:
-  print("tile code %d" % (ops.W3_BASE + code))
-  for name, N, H, W, Cout in (("decoder.4 shape", 10, 240, 432, 64), ("decoder.0 shape", 10, 120, 216, 128), ("encoder shape", 10, 60, 108, 512),
+CODE = int(sys.argv[1]) if len(sys.argv) > 1 else 6064
+for name, N, H, W, Cout in (("decoder.4 shape", 10, 240, 432, 64), ("decoder.0 shape", 10, 120, 216, 128), ("encoder shape", 10, 60, 108, 512),
                             ("one frame", 1, 60, 108, 448)):
-      wgs = N * ((H + 15) // 16) * ((W + 15) // 16) * ((Cout + 63) // 64)
-      row = []
-      for cin in (16, 32, 64, 128, 256):
-          g = torch.Generator().manual_seed(cin)
-          layer = ops.PackedConv((torch.randn(Cout, cin, 3, 3, generator=g) * 0.05).to(dev), torch.randn(Cout, generator=g).to(dev), [cin], pad=1, algo="winograd")
-          x = torch.randn(N, H, W, cin, generator=g).to(dev)
-          out = torch.empty(N, H, W, Cout, device=dev)
-          us = timed(lambda: layer([x], out=out, act=ops.ACT_LRELU, slope=0.2, tile=ops.W3_BASE + code))
-          row.append((cin // 16, us))
-      (s0, t0), (s1, t1) = row[1], row[-1]
-      slope = (t1 - t0) / (s1 - s0)
-      print("%-16s %5d workgroups (%.1f per CU): " % (name, wgs, wgs / 256.0) + "  ".join("%d stages %.1f us" % r for r in row)
-            + "  | per stage %.1f us, at zero stages %.1f us" % (slope, t0 - slope * s0), flush=True)
+    wgs = N * ((H + 15) // 16) * ((W + 15) // 16) * ((Cout + 63) // 64)
+    row = []
+    for cin in (16, 32, 64, 128, 256):
+        g = torch.Generator().manual_seed(cin)
+        layer = ops.PackedConv((torch.randn(Cout, cin, 3, 3, generator=g) * 0.05).to(dev), torch.randn(Cout, generator=g).to(dev), [cin], pad=1, algo="winograd")
+        x = torch.randn(N, H, W, cin, generator=g).to(dev)
+        out = torch.empty(N, H, W, Cout, device=dev)
+        us = timed(lambda: layer([x], out=out, act=ops.ACT_LRELU, slope=0.2, tile=ops.W3_BASE + CODE))
+        row.append((cin // 16, us))
+    (s0, t0), (s1, t1) = row[1], row[-1]
+    slope = (t1 - t0) / (s1 - s0)
+    print("%-16s %5d workgroups (%.1f per CU): " % (name, wgs, wgs / 256.0) + "  ".join("%d stages %.1f us" % r for r in row)
+          + "  | per stage %.1f us, at zero stages %.1f us" % (slope, t0 - slope * s0), flush=True)
