@@ -113,22 +113,50 @@ class ShardedStep:
         if ops.sync_tile_decisions(self.group) and ops._TUNED != mine:
             self.out = self._forward()
 
+    def _pipeline_setup(self):
+        """K graphs (each with its own static buffers) and K replay streams.  Which hardware queue HIP gives a stream depends on
+        how many streams the process has made before, and two pipelines whose streams (or whose graphs' internal side branches)
+        share a queue run in turn instead of side by side: measured 808 ... 900 frames/s for K = 3 on one box, by creation order
+        alone (profiles/r06_forwards_in_flight.txt).  So the streams are CHOSEN: K graphs are captured once (a graph replays on
+        whatever stream is current), a window of K consecutive streams slides over a dozen candidates, each window replays 2 K
+        steps, the fastest one stays.  The choice moves scheduling only: every window returns the same bits."""
+        import time
+        keep = self.out
+        graphs = []
+        for _ in range(self.in_flight):
+            self.graph = None
+            self._capture()
+            if self.graph is None:                 # capture unsupported: sequential eager steps
+                self.in_flight, self.out = 1, keep
+                return False
+            graphs.append((self.graph, self.out))
+        K = self.in_flight
+        cand = [torch.cuda.Stream() for _ in range(K + 9)]
+        cur = torch.cuda.current_stream()
+        best, best_t = 0, None
+        for off in range(len(cand) - K + 1):
+            sts = cand[off:off + K]
+            ts = []
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for n in range(2 * K):
+                    st = sts[n % K]
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        graphs[n % K][0].replay()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            if best_t is None or min(ts) < best_t:
+                best, best_t = off, min(ts)
+        self.stream_window = (best, round(1e3 * best_t / (2 * K), 3))
+        self._pipes = [[g, o, cand[best + k], torch.cuda.Event(), False] for k, (g, o) in enumerate(graphs)]
+        self._issued = 0
+        return True
+
     def _run_pipelined(self):
-        if self._pipes is None:
-            keep = (self.graph, self.out)
-            pipes = []
-            # the K replay streams first, back to back: torch hands out its pool's streams in creation order and HIP spreads
-            # consecutive streams over its hardware queues -- K streams taken in a row sit on K different queues (taken one by one
-            # between the captures, every other one shared a queue with an earlier one and those two pipelines ran in turn)
-            streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
-            for k in range(self.in_flight):
-                self.graph = None
-                self._capture()
-                if self.graph is None:                 # capture unsupported: sequential eager steps
-                    self.in_flight, self.graph, self.out = 1, None, keep[1]
-                    return self.run()
-                pipes.append([self.graph, self.out, streams[k], torch.cuda.Event(), False])
-            self._pipes, self._issued = pipes, 0
+        if self._pipes is None and not self._pipeline_setup():
+            return self.run()
         K, n = self.in_flight, self._issued
         cur = torch.cuda.current_stream()
         g, out, st, ev, _ = self._pipes[n % K]
