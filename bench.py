@@ -264,8 +264,8 @@ SECONDARY = [   # (label, model, H, W, clips, t, l_t, precision, x3, steps, warm
     ("BASELINE.json configs[1] with E2FGVI_X3=0: every fp32 layer on fp32 MFMA (no split-operand kernels)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", False, 10, 2),
     ("SURVEY.md 8(d) C2 second split: T=10 with 5 local + 5 reference frames (configs/train_e2fgvi.json:9-10)", "e2fgvi", 240, 432, 1, 10, 5, "fp32", True, 10, 2),
     ("BASELINE.json configs[2] per-GPU work on ONE GPU: 8 clips per forward, no collective (the N = 1 point of the 8-GPU job)", "e2fgvi", 240, 432, 8, 10, 10, "fp32", True, 5, 2),
-    ("BASELINE.json configs[1] with THREE forwards in flight (three HIP graphs of the one-clip forward replayed round-robin on three "
-     "streams: runner.ShardedStep(in_flight=3); the headline replays one graph back to back)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", True, 30, 5, 3),
+    ("BASELINE.json configs[1] with THREE forwards in flight (runner.ShardedStep(in_flight=3); the headline keeps two in flight, its "
+     "`sequential` record one)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", True, 30, 6, 3),
     ("BASELINE.json configs[3]", "e2fgvi_hq", 720, 1296, 1, 10, 10, "bf16", True, 20, 3),
     ("BASELINE.json configs[4] (one GPU's clip)", "e2fgvi_hq", 1080, 1944, 1, 20, 20, "bf16", True, 5, 2),
 ]
@@ -344,9 +344,12 @@ def main():
     ap.add_argument("--gather", default="u8", choices=("u8", "f32"), help="dtype of the frames in the all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable HIP-graph replay of the forward")
-    ap.add_argument("--in-flight", type=int, default=1,
-                    help="forwards in flight on one GPU (runner.ShardedStep(in_flight=K): K HIP graphs replayed round-robin on K "
-                         "streams); default 1 = one graph replayed back to back (the headline); ignored with a gather")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="forwards in flight on one GPU (runner.ShardedStep(in_flight=K): K HIP graphs of the same one-clip forward "
+                         "replayed round-robin on K streams -- step n + 1 starts while step n is in its latency-bound propagation "
+                         "chain; every step returns the bits of the sequential forward).  Default: 2 on a single GPU without a "
+                         "gather (the line then also carries `sequential`: one graph replayed back to back, rounds 1-5's headline "
+                         "mode, timed in the same process), 1 with a gather (N > 1 / --force-dist)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (self-test)")
     ap.add_argument("--no-dominant-probe", action="store_true",
                     help="skip the 21 extra launches of encoder.layers.10 behind the timed region (PMC passes count whole processes: "
@@ -428,8 +431,19 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # the forward replays from a HIP graph in every mode; the collective stays outside the graph (runner.ShardedStep)
+    in_flight = 1 if (dist is not None or args.no_graph) else (args.in_flight or 2)
+    sequential = None
+    if in_flight > 1:
+        # rounds 1-5's headline mode on this box, in this process: ONE graph replayed back to back
+        sq_steps = max(5, min(args.steps, 20))
+        el, _, _ = time_local(net, x, lt, sq_steps, 3)
+        LAST_FRAMES[0] = None
+        sequential = {"value": round(b * t * sq_steps / el, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el / sq_steps, 3),
+                      "steps": sq_steps, "forwards_in_flight": 1,
+                      "note": "the same forward, one HIP graph replayed back to back on one stream (the headline mode of rounds 1-5; "
+                              "`ms_per_step` here is also the latency of a forward that has the GPU to itself)"}
     step = runner.ShardedStep(net, x, lt, group_world=world, use_graph=not args.no_graph, force_gather=args.force_dist,
-                              pack_u8=(dist is not None and args.gather == "u8"), in_flight=args.in_flight if dist is None else 1)
+                              pack_u8=(dist is not None and args.gather == "u8"), in_flight=in_flight)
     for _ in range(max(args.warmup, 2 if step.in_flight == 1 else 2 + step.in_flight)):   # the second untimed step captures the HIP graph(s)
         step.run()
     step.finish()
@@ -481,7 +495,9 @@ def main():
                    "kernel_selection": ("timed on this box (E2FGVI_AUTOTUNE=1)" if ops.AUTOTUNE else
                                         "e2fgvi_amd/tile_table.py (checked in, deterministic: ops.py)"),
                    "parallelism": "clip-shard x%d + all-gather of the %s frames" % (world, args.gather) if dist is not None
-                                  else "single GPU, no collective",
+                                  else ("single GPU, no collective" + ("; %d forwards in flight (that many HIP graphs of the one-clip "
+                                        "forward replayed round-robin on as many streams, bit-identical steps; `sequential` = one at a time)"
+                                        % step.in_flight if step.in_flight > 1 else "")),
                    "hip_graph": bool(step.graphed), "forwards_in_flight": step.in_flight},
         "roofline": {"bound": "mfma", "achieved": round(tf_iss, 3), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(tf_iss / peak, 4), "frac_useful": round(gflop_useful / secs / 1e3 / peak, 4),
@@ -584,6 +600,9 @@ def main():
                 out["parity"] = parity
     if same_work is not None:
         out["single_gpu_same_work"] = same_work
+    if sequential is not None:
+        out["sequential"] = sequential
+        out["config"]["stream_window"] = getattr(step, "stream_window", None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
