@@ -260,14 +260,14 @@ ARITHMETIC = {
             "token residual stream and the output frames stay fp32 (DESIGN.md 1b)",
 }
 
-SECONDARY = [   # (label, model, H, W, clips, t, l_t, precision, x3, steps, warmup[, forwards in flight])
-    ("BASELINE.json configs[1] with E2FGVI_X3=0: every fp32 layer on fp32 MFMA (no split-operand kernels)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", False, 10, 2),
-    ("SURVEY.md 8(d) C2 second split: T=10 with 5 local + 5 reference frames (configs/train_e2fgvi.json:9-10)", "e2fgvi", 240, 432, 1, 10, 5, "fp32", True, 10, 2),
-    ("BASELINE.json configs[2] per-GPU work on ONE GPU: 8 clips per forward, no collective (the N = 1 point of the 8-GPU job)", "e2fgvi", 240, 432, 8, 10, 10, "fp32", True, 5, 2),
-    ("BASELINE.json configs[1] with THREE forwards in flight (runner.ShardedStep(in_flight=3); the headline keeps two in flight, its "
-     "`sequential` record one)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", True, 30, 6, 3),
-    ("BASELINE.json configs[3]", "e2fgvi_hq", 720, 1296, 1, 10, 10, "bf16", True, 20, 3),
-    ("BASELINE.json configs[4] (one GPU's clip)", "e2fgvi_hq", 1080, 1944, 1, 20, 20, "bf16", True, 5, 2),
+SECONDARY = [   # (label, model, H, W, clips, t, l_t, precision, x3, steps, warmup, forwards in flight)
+    ("BASELINE.json configs[1] with E2FGVI_X3=0: every fp32 layer on fp32 MFMA (no split-operand kernels)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", False, 10, 4, 2),
+    ("SURVEY.md 8(d) C2 second split: T=10 with 5 local + 5 reference frames (configs/train_e2fgvi.json:9-10)", "e2fgvi", 240, 432, 1, 10, 5, "fp32", True, 10, 4, 2),
+    ("BASELINE.json configs[2] per-GPU work on ONE GPU: 8 clips per forward, no collective (the N = 1 point of the 8-GPU job runs one "
+     "forward at a time: its `sequential`)", "e2fgvi", 240, 432, 8, 10, 10, "fp32", True, 6, 4, 2),
+    ("BASELINE.json configs[1] with THREE forwards in flight (the headline keeps two in flight)", "e2fgvi", 240, 432, 1, 10, 10, "fp32", True, 30, 6, 3),
+    ("BASELINE.json configs[3]", "e2fgvi_hq", 720, 1296, 1, 10, 10, "bf16", True, 20, 4, 2),
+    ("BASELINE.json configs[4] (one GPU's clip)", "e2fgvi_hq", 1080, 1944, 1, 20, 20, "bf16", True, 6, 4, 2),
 ]
 
 
@@ -292,6 +292,12 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
         gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
         gflop_useful = USEFUL_GFLOP
         kernels = dict(KERNELS)
+        sequential = None
+        if in_flight > 1:
+            sq_steps = max(3, min(steps, 10))
+            el, _, _ = time_local(net, x, lt, sq_steps, 2)
+            sequential = {"value": round(b * t * sq_steps / el, 3), "unit": "frames/s", "ms_per_step": round(1e3 * el / sq_steps, 3),
+                          "steps": sq_steps, "forwards_in_flight": 1}
         elapsed, dev_ms, graphed = time_local(net, x, lt, steps, warmup, in_flight=in_flight)
         timed_frames, LAST_FRAMES[0] = LAST_FRAMES[0], None
     finally:
@@ -316,6 +322,8 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
             "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
     if precision == "fp32" and not x3:
         line["config"]["kernels"] = kernels
+    if sequential is not None:
+        line["sequential"] = sequential
     del net, x
     gc.collect()
     torch.cuda.empty_cache()
