@@ -289,7 +289,12 @@ def secondary_line(dev, label, model, H, W, b, t, lt, precision, x3, steps, warm
         torch.cuda.reset_peak_memory_stats(dev)
         net(x, lt)
         torch.cuda.synchronize()
-        gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
+        from e2fgvi_amd import runner
+        if in_flight > 1:
+            with runner.whole_propagation(net):
+                gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
+        else:
+            gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
         gflop_useful = USEFUL_GFLOP
         kernels = dict(KERNELS)
         sequential = None
@@ -410,7 +415,12 @@ def main():
     torch.cuda.reset_peak_memory_stats(dev)
     net(x, lt)
     torch.cuda.synchronize()
-    gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)      # per forward of b clips
+    want_in_flight = 1 if (world > 1 or args.force_dist or args.no_graph) else (args.in_flight or 2)
+    if want_in_flight > 1:
+        with runner.whole_propagation(net):                         # what the pipelines' graphs run (runner.ShardedStep._pipeline_setup)
+            gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)
+    else:
+        gflop_alg, gflop_issued, nlaunch = traced_work(net, x, lt)      # per forward of b clips
     gflop_useful = USEFUL_GFLOP
     kernels = dict(KERNELS)
     same_work = None

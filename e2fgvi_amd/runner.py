@@ -40,6 +40,29 @@ def inpaint_sharded(net, clips, num_local_frames, rank, world, group=None, pack_
     return gather_frames(out, world, group)
 
 
+class whole_propagation:
+    """context: the engine of `net` (if it has one) runs conv_offset.0 / backbone.0 whole, without the side-stream split of the
+    one-clip forward (engine.PROP_SPLIT) -- what ShardedStep's pipelines capture, and what their frames are bit-equal to"""
+
+    def __init__(self, net):
+        eng = getattr(net, "engine", None)
+        try:
+            self.eng = eng() if callable(eng) else None
+        except Exception:
+            self.eng = None
+
+    def __enter__(self):
+        self.keep = getattr(self.eng, "prop_split", None)
+        if self.keep:
+            self.eng.prop_split = {}
+        return self
+
+    def __exit__(self, *a):
+        if self.keep:
+            self.eng.prop_split = self.keep
+        return False
+
+
 class ShardedStep:
     """One benchmark / serving step: forward of this rank's clips (+ optional uint8 packing) + all-gather of the frames.
 
@@ -123,13 +146,18 @@ class ShardedStep:
         import time
         keep = self.out
         graphs = []
-        for _ in range(self.in_flight):
-            self.graph = None
-            self._capture()
-            if self.graph is None:                 # capture unsupported: sequential eager steps
-                self.in_flight, self.out = 1, keep
-                return False
-            graphs.append((self.graph, self.out))
+        # The pipelines run the propagation layers WHOLE: engine.PROP_SPLIT takes the non-recurrent input channels of conv_offset.0 /
+        # backbone.0 out of the one-clip chain into four batched side launches -- +2.3 % for a forward that has the GPU to itself,
+        # -2 ... -4 % once another forward fills the chain's idle CUs and the side launches only compete with it
+        # (tools/inflight_ab.py: 913.7 with the split, 933.6 without, two in flight, same box; sequential: 818.5 / 799.4).
+        with whole_propagation(self.net):
+            for _ in range(self.in_flight):
+                self.graph = None
+                self._capture()
+                if self.graph is None:                 # capture unsupported: sequential eager steps
+                    self.in_flight, self.out = 1, keep
+                    return False
+                graphs.append((self.graph, self.out))
         K = self.in_flight
         cand = [torch.cuda.Stream() for _ in range(K + 9)]
         cur = torch.cuda.current_stream()
