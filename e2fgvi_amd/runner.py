@@ -203,8 +203,13 @@ class ShardedStep:
         return oldest[1]
 
     def run(self):
-        if self.in_flight > 1 and not self.gather and self.use_graph and self._calls >= 1:
-            return self._run_pipelined()
+        if self.in_flight > 1 and not self.gather and self.use_graph:
+            if self._calls >= 1:
+                return self._run_pipelined()
+            with whole_propagation(self.net):          # the first (eager) step returns what the pipelines will return
+                self._calls += 1
+                self.out = self._last = self._forward()
+                return self.out
         if self.use_graph and self.graph is None and self._calls >= 1:
             self._capture()
         self._calls += 1
