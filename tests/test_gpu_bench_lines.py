@@ -81,9 +81,9 @@ def test_default_line_carries_the_hq_configs(dev):
     # (the headline itself keeps two in flight since round 6 and carries the one-at-a-time number of the same process beside it)
     assert fl3["config"]["forwards_in_flight"] == 3 and j["config"]["forwards_in_flight"] == 2
     for s_ in (x30, lt5, c8, hq720, hq1080):          # ... and so do the other lines, each with its one-at-a-time number
-        assert s_["config"]["forwards_in_flight"] == 2 and 0.75 * s_["value"] <= s_["sequential"]["value"] <= 1.05 * s_["value"], s_
+        assert s_["config"]["forwards_in_flight"] == 2 and 0.75 * s_["value"] <= s_["sequential"]["value"] <= 1.08 * s_["value"], s_
     sq = j["sequential"]
-    assert sq["forwards_in_flight"] == 1 and 0.8 * j["value"] <= sq["value"] <= 1.03 * j["value"], (sq, j["value"])
+    assert sq["forwards_in_flight"] == 1 and 0.75 * j["value"] <= sq["value"] <= 1.08 * j["value"], (sq, j["value"])
     assert fl3["value"] > 0.95 * sq["value"] and "in flight" in j["config"]["parallelism"]
     assert "E2FGVI_X3=0" in x30["config"]["workload"] and x30["dtype"] == "f32" and "fp32 MFMA" in x30["config"]["arithmetic"]
     assert not any("x3" in k for k in x30["config"]["kernels"].values()), x30["config"]["kernels"]

@@ -390,3 +390,35 @@ def test_exit_reuse_check_rejects_the_real_kernels_built_without_their_register_
     wide = [n for n in raised if "conv_wino_x3w_kernel" in n]
     assert wide and all(raised[n] for n in wide), raised          # the kernel that failed on the chip in round 4
     assert sum(raised.values()) >= 3, raised
+
+
+def test_sharded_step_without_graphs_ignores_in_flight_and_whole_propagation_restores_the_engine():
+    """runner.ShardedStep(in_flight=K) needs HIP graphs: without them (CPU, use_graph=False) every run() is a plain forward;
+    runner.whole_propagation switches an engine's propagation split off inside the context only, and tolerates nets without an engine"""
+    import torch
+    from e2fgvi_amd import runner
+
+    class Eng:
+        prop_split = {"backward_": 1}
+
+    class Net:
+        def __init__(self):
+            self.eng, self.calls = Eng(), 0
+
+        def engine(self):
+            return self.eng
+
+        def __call__(self, x, lt):
+            self.calls += 1
+            return x.reshape(-1, *x.shape[2:]) * (2.0 if self.eng.prop_split else 3.0), None
+
+    net = Net()
+    x = torch.ones(1, 2, 3, 4, 4)
+    step = runner.ShardedStep(net, x, 2, in_flight=2, use_graph=False)
+    outs = [step.run() for _ in range(3)]
+    assert net.calls == 3 and all(o is not None and float(o.mean()) == 2.0 for o in outs) and float(step.finish().mean()) == 2.0
+    with runner.whole_propagation(net):
+        assert net.eng.prop_split == {} and float(net(x, 2)[0].mean()) == 3.0
+    assert net.eng.prop_split == {"backward_": 1}
+    with runner.whole_propagation(lambda x, lt: (x, None)):          # no engine: nothing to switch
+        pass
