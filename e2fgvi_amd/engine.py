@@ -326,11 +326,20 @@ class Engine(BF16Path):
         return total
 
     def _side_stream(self):
+        """The side stream that belongs to the CURRENT stream: one per main stream a forward has been issued on.  With a single
+        shared side stream, two eager forwards on two main streams (video.inpaint_video(in_flight=2)) raced through the caching
+        allocator: a tensor allocated on the side stream is returned to that stream's pool when its forward ends on the HOST, the
+        other forward's side work takes the block while the first forward's main-stream kernels -- which no wait of the second
+        forward covers -- are still reading it (round 6: different bytes from the one-at-a-time run; graph replay, with its private
+        pools and static buffers, was never exposed)."""
         if self._side is None:
+            self._side = {}
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        if key not in self._side:
             # (default priority on purpose: with a priority on EITHER branch of the captured forward -- this stream or the capture
             #  stream -- the replayed graph takes 21.9 ms instead of 12.0, profiles/r05_tile8_priority_ab.txt)
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+            self._side[key] = torch.cuda.Stream(device=self.device)
+        return self._side[key]
 
     def _zero(self, shape):
         key = tuple(shape)

@@ -67,7 +67,7 @@ def prepare_masks(masks_u8, size_hw, device, dilate=True):
 
 @torch.no_grad()
 def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, num_ref=-1, dilate=True,
-                  device=None, pad=True, batch_windows=1, keep_float=False):
+                  device=None, pad=True, batch_windows=1, keep_float=False, in_flight=1):
     """frames_u8: uint8 [L,H,W,3]; masks_u8: [L,Hm,Wm] (non-zero = hole; resized to the frames with NEAREST like
     read_mask).  Returns uint8 [L,H,W,3] composited frames, computed like test.py:129-179.
     ``model(masked[b,t,3,H',W'], n_local) -> (pred[b*t,3,H',W'], _)`` on the device.
@@ -77,7 +77,11 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
     the reference's window order (the 0.5/0.5 blend is order dependent).
 
     keep_float=True returns the blended frames as the fp32 device tensor [L,H,W,3] they are before the final
-    ``astype(uint8)`` -- what evaluate.py:113-114 feeds to calc_psnr_and_ssim."""
+    ``astype(uint8)`` -- what evaluate.py:113-114 feeds to calc_psnr_and_ssim.
+
+    ``in_flight`` = K > 1 (round 6, with batch_windows = 1): the forwards of K consecutive windows run on K streams -- window
+    i + 1's encoder fills the CUs window i's one-frame propagation chain leaves idle -- while the compositing
+    stays on the caller's stream in the reference's window order: the same kernels on the same data, the same bytes."""
     if device is None:
         device = next(model.parameters()).device if hasattr(model, "parameters") else torch.device("cuda")
     device = torch.device(device)
@@ -111,7 +115,28 @@ def inpaint_video(model, frames_u8, masks_u8, neighbor_stride=5, ref_length=10, 
         n = len(windows[i][0])
         ops.composite(pred.contiguous(), ids_dev[i][:n], first_dev[i], frames_d, masks01, comp)
 
-    if batch_windows <= 1:
+    if batch_windows <= 1 and in_flight > 1:
+        cur = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)]
+        for st in streams:
+            st.wait_stream(cur)                         # the uploads, the mask preparation
+        queue = []                                      # (window, its local predictions, event) in window order
+        for i in range(len(windows)):
+            st = streams[i % in_flight]
+            with torch.cuda.stream(st):
+                p = predict([i])[0]
+                ev = torch.cuda.Event()
+                ev.record(st)
+            p.record_stream(cur)                        # allocated on st, read by the compositing kernel on cur
+            queue.append((i, p, ev))
+            if len(queue) == in_flight:
+                j, pj, evj = queue.pop(0)
+                cur.wait_event(evj)
+                composite(j, pj)
+        for j, pj, evj in queue:
+            cur.wait_event(evj)
+            composite(j, pj)
+    elif batch_windows <= 1:
         # like the reference: every window is composited right after its forward, nothing is kept
         for i in range(len(windows)):
             composite(i, predict([i])[0])

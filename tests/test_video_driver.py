@@ -155,6 +155,26 @@ def test_driver_on_gpu_matches_cpu_oracle(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,hw,L,precision", [("e2fgvi", (240, 432), 36, "fp32"), ("e2fgvi_hq", (120, 200), 23, "bf16")])
+def test_windows_in_flight_return_the_bytes_of_the_sequential_driver(dev, model, hw, L, precision):
+    """video.inpaint_video(in_flight=K), round 6: the forwards of K consecutive windows on K streams (eager launches, the engine's
+    SPyNet / propagation-split side work on a side stream PER main stream), compositing in window order on the caller's stream --
+    the same bytes as one window at a time, five times over.  (With one side stream shared by both main streams the caching allocator
+    handed a flow tensor of window i to window i + 1's side work while window i was still reading it: different bytes.)"""
+    import importlib
+    from e2fgvi_amd.synth import synth_state_dict
+    frames, masks = _toy_video(L, hw[0], hw[1], seed=9)
+    net = importlib.import_module("model." + model).InpaintGenerator()
+    net.load_state_dict(synth_state_dict(model, "stress", 0))
+    net = net.to(dev).eval()
+    net.precision = precision
+    ref = video.inpaint_video(net, np.stack(frames), np.stack(masks), 5, 10, -1)
+    for k in (2, 3, 2, 2, 3):
+        out = video.inpaint_video(net, np.stack(frames), np.stack(masks), 5, 10, -1, in_flight=k)
+        assert np.array_equal(out, ref), "in_flight=%d: %d bytes differ" % (k, int((out != ref).sum()))
+
+
+@pytest.mark.gpu
 def test_sharded_runner_uint8_gather(dev):
     """inpaint_sharded(pack_u8=True): the frames every rank contributes to the gather are the uint8 NHWC form"""
     from e2fgvi_amd.runner import inpaint_sharded

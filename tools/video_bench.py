@@ -1,6 +1,6 @@
 """End-to-end throughput of the sliding-window driver (e2fgvi_amd/video.py) on a synthetic 432x240 video:
 upload of the uint8 frames, all windows (11 local + reference frames each), compositing, download.
-    python tools/video_bench.py [L=100] [batch_windows=1]"""
+    python tools/video_bench.py [L=100] [batch_windows=1] [in_flight=1]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, importlib
@@ -8,6 +8,7 @@ from e2fgvi_amd import video
 from e2fgvi_amd.synth import synth_state_dict
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bw = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+fl = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda:0")
 net = importlib.import_module("model.e2fgvi").InpaintGenerator()
 net.load_state_dict(synth_state_dict("e2fgvi", "default", 0)); net = net.to(dev).eval()
@@ -20,10 +21,12 @@ for tag in ("first_call", "steady"):
     # first_call: includes the one-off tile tuning of every new window shape (GEMM-shaped layers, a few hundred timed
     # launches per size class); steady: the same video again, every decision cached in the process
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = video.inpaint_video(net, frames, masks, batch_windows=bw)
+    out = video.inpaint_video(net, frames, masks, batch_windows=bw, in_flight=fl)
     torch.cuda.synchronize(); res[tag] = time.perf_counter() - t0
 nwin = len(range(0, L, 5))
 dt = res["steady"]
-print(json.dumps({"video_frames": L, "windows": nwin, "batch_windows": bw, "seconds": round(dt, 3),
+ref = video.inpaint_video(net, frames, masks)
+same = bool(np.array_equal(np.asarray(out), np.asarray(ref)))
+print(json.dumps({"video_frames": L, "windows": nwin, "batch_windows": bw, "in_flight": fl, "same_bytes_as_one_at_a_time": same, "seconds": round(dt, 3),
                   "video_frames_per_s": round(L / dt, 1), "ms_per_window": round(1e3 * dt / nwin, 2),
                   "first_call_seconds": round(res["first_call"], 3)}))
