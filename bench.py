@@ -566,7 +566,8 @@ def main():
             out["roofline"]["traffic"] = round(tj["hbm_bytes_per_forward"])
             out["roofline"]["traffic_note"] = ("FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per forward, rocprofv3 --pmc, separate "
                                                "passes (profiles/%s, measured on this library: sha16 %s); fabric-side, includes Infinity-"
-                                               "Cache hits; compulsory minimum (input + weights + output) is %s GB/clip"
+                                               "Cache hits; compulsory minimum (input + weights + output) is %s GB/clip; counted on eager one-at-a-time forwards "
+                                               "(PMC passes serialise the kernels), the same kernels the in-flight graphs replay"
                                                % (os.path.basename(tfile), lib_key, "0.19" if not hq else "0.39"))
             break
         else:
