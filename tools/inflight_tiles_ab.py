@@ -23,7 +23,7 @@ if len(sys.argv) > 1:
 
         def forced(key):
             if (key[-1] == "x3" and key[0] == 128 and key[2] == 3 and key[8] == 50
-                    and (which == "all" or (which == "res") == bool(key[9]))):
+                    and (which == "all" or (which == "co0" and len(key[1]) == 4) or (which in ("res", "nores") and (which == "res") == bool(key[9])))):
                 hits[key] = hits.get(key, 0) + 1
                 return ops.W3_BASE + code
             return plain(key)
@@ -47,5 +47,7 @@ else:
             (4, 6064))
     if os.environ.get("AB_ROWS") == "k3":          # second pass: is K = 3 with 112-workgroup layers ahead of K = 2 / K = 3 as tabled?
         rows = ((2, 0), (3, 0), (3, 164), (2, 0), (3, 0), (3, 164), (3, 164, "nores"), (3, 164, "res"), (4, 164))
+    if os.environ.get("AB_ROWS") == "co0":         # the whole conv_offset.0 (388 -> 128) has no entry at one frame: it takes 164 from two clips
+        rows = ((2, 0), (2, 132, "co0"), (2, 0), (2, 132, "co0"), (2, 0), (2, 132, "co0"), (3, 132, "co0"), (1, 0))
     for row in rows:
         subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(v) for v in row])
