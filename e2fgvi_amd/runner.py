@@ -114,8 +114,14 @@ class ShardedStep:
                 self._forward()                       # warm the allocator on the capture stream
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            # Captured on `s`, the stream the warm-up forward just ran on -- NOT on torch.cuda.graph's process-wide default capture
+            # stream: the engine keeps one side stream per main stream (engine._side_stream), and on torch's stream every new engine
+            # forked a side stream into the capture that had never run anything.  After earlier graphs of the process had been
+            # destroyed, the replay of such a graph died in hip::Graph::UpdateStreams (SIGSEGV under hipGraphLaunch: `python bench.py
+            # --no-cpu-baseline`, first secondary line, 5 of 5 runs).  On `s` both streams of the capture have run the
+            # same forward eagerly one statement earlier.
             # thread_local: RCCL's watchdog thread may query events while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 self.out = self._forward()
             self.graph, self.graphed = g, True
         except Exception as e:                         # capture unsupported -> stay eager, say so
