@@ -167,6 +167,15 @@ class ShardedStep:
         K = self.in_flight
         cand = [torch.cuda.Stream() for _ in range(K + 9)]
         cur = torch.cuda.current_stream()
+        # every candidate runs one eager kernel before a graph is launched on it (no stream meets the graph runtime new;
+        # the one unexplained crash of the calibration happened on a box's first process, in a replay on a never-used stream)
+        tick = torch.zeros(1, device=self.x.device)
+        for c in cand:
+            c.wait_stream(cur)
+            with torch.cuda.stream(c):
+                tick.add_(1.0)
+            cur.wait_stream(c)
+        torch.cuda.synchronize()
         best, best_t = 0, None
         for off in range(len(cand) - K + 1):
             sts = cand[off:off + K]
