@@ -1028,12 +1028,12 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
     hipStream_t st = (hipStream_t)stream;
     int tile = d->tile;
     p.dbg_noload = 0;
-    if (tile == 21 || tile == 26 || tile == 27) { p.dbg_noload = 1; tile -= 20; }        // measurement aids: results are garbage
-    if (tile == 31 || tile == 36) { p.dbg_noload = 2; tile -= 30; }        //   no epilogue
-    if (tile == 41 || tile == 46) { p.dbg_noload = 3; tile -= 40; }        //   neither
+    if (tile == 21 || tile == 24 || tile == 26 || tile == 27) { p.dbg_noload = 1; tile -= 20; }        // measurement aids: results are garbage
+    if (tile == 31 || tile == 34 || tile == 36) { p.dbg_noload = 2; tile -= 30; }        //   no epilogue
+    if (tile == 41 || tile == 44 || tile == 46) { p.dbg_noload = 3; tile -= 40; }        //   neither
     if (tile == 61 || tile == 66) { p.dbg_noload = 8; tile -= 60; }        //   epilogue without its global stores
-    if (tile == 71 || tile == 76 || tile == 77) { p.dbg_noload = 16; tile -= 70; }   //   no A (activation) DMA
-    if (tile == 81 || tile == 86 || tile == 87) { p.dbg_noload = 32; tile -= 80; }   //   no B (weight) DMA
+    if (tile == 71 || tile == 74 || tile == 76 || tile == 77) { p.dbg_noload = 16; tile -= 70; }   //   no A (activation) DMA
+    if (tile == 81 || tile == 84 || tile == 86 || tile == 87) { p.dbg_noload = 32; tile -= 80; }   //   no B (weight) DMA
     if (!tile) {
         if (p.Cout_g <= 32) tile = 3;
         else if (p.Cout_g <= 64) tile = 2;
