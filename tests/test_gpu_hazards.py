@@ -162,3 +162,64 @@ def test_forwards_in_flight_return_the_bits_of_the_serial_forward(dev, model, hw
         got += 1
     assert torch.equal(step.finish(), ref)
     assert step.graphed and step.in_flight == k and none <= k and got >= 60 - k - 1
+
+
+_C8_SCRIPT = r"""
+import importlib, sys, torch
+sys.path.insert(0, %r)
+from e2fgvi_amd import runner
+from e2fgvi_amd.synth import synth_clip, synth_state_dict
+dev = torch.device("cuda:0")
+x = synth_clip(1, 10, 240, 432, seed=0, smooth=False)[0].to(dev)
+
+
+def engine():
+    net = importlib.import_module("model.e2fgvi").InpaintGenerator()
+    net.load_state_dict(synth_state_dict("e2fgvi", "default", 0))
+    net = net.to(dev).eval()
+    net(x, 10)
+    return net
+
+
+def graphed_steps(net, n, **kw):                            # what bench.time_local does: capture, replay, drop the graph(s)
+    step = runner.ShardedStep(net, x, 10, **kw)
+    for _ in range(n):
+        step.run()
+    out = step.finish().clone()
+    torch.cuda.synchronize()
+    assert step.graphed
+    return out
+
+
+net = engine()
+ref = net(x, 10)[0].clone()
+with runner.whole_propagation(net):
+    ref_whole = net(x, 10)[0].clone()
+assert torch.equal(graphed_steps(net, 5), ref)              # bench.py's order: the sequential graph ...
+assert torch.equal(graphed_steps(net, 7, in_flight=2), ref_whole)   # ... two pipelines + the calibration's eleven streams ...
+del net
+torch.cuda.empty_cache()
+from e2fgvi_amd import engine as _engine, ops
+for rep in range(2):                                        # ... then NEW engines (new side streams), one graph each -- the first one
+    ops.X3_ENABLED, _engine.FC2_CONV = rep == 1, rep == 1   # as bench.py's first secondary line builds it (every product an fp32 MFMA)
+    net = engine()
+    ref1 = net(x, 10)[0].clone()
+    assert torch.equal(graphed_steps(net, 4), ref1)
+    del net
+print("__C8_OK__")
+"""
+
+
+def test_graph_of_a_new_engine_replays_after_earlier_graphs_were_destroyed(dev):
+    """with one side stream per main stream, a graph captured on torch.cuda.graph's default capture stream forked a side
+    stream that had never run anything; once earlier graphs of the process had been destroyed its replay died in
+    hip::Graph::UpdateStreams (SIGSEGV -- hence a subprocess).  ShardedStep._capture captures on the stream its warm-up ran on.
+    This walks bench.py's order of captures and destructions in a few seconds; the invocation that crashed 5 of 5 before the fix is
+    tests/test_gpu_bench_lines.py::test_default_line_carries_the_hq_configs (this shorter sequence did not crash with the old capture
+    stream either: it is the smoke test of the rule, that one is the reproducer)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", _C8_SCRIPT % root], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0 and "__C8_OK__" in p.stdout, (p.returncode, p.stderr[-1500:])
