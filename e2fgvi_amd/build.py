@@ -82,6 +82,7 @@ def build(force=False, verbose=False, nopk_all=False, lib=None, tag=None, define
         if not nopk_all:
             verify_wino_waits(objdir)
             verify_exit_reuse(objdir)
+            verify_no_scratch(objdir)
     return out
 
 
@@ -120,6 +121,40 @@ def verify_isa(objdir=None):
         if bad or not isa:
             raise RuntimeError("%s: %s" % (obj, "%d packed-fp32 instructions in a unit that must have none" % len(bad) if isa
                                            else "no gfx950 code object found"))
+
+
+def verify_no_scratch(objdir=None, obj="conv_bf16x.o", marker="ELb0ELi2ELb1EEE"):
+    """The ping-pong instantiations of conv_bf16x_kernel (template tail `false, 2, true`) keep 128 accumulator registers in place
+    across four barriers per K-step; two ways of writing that loop made hipcc spill 414 registers or copy the kernel arguments to
+    scratch without a warning (csrc/conv_bf16x.hip, PP).  Fails the build when one of them has a private segment or a spill."""
+    import re
+    import shutil
+    import tempfile
+    objdir = objdir or os.path.join(CSRC, "build")
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    if not (os.path.exists(OBJDUMP) and os.path.exists(readelf)):
+        return 0
+    d = tempfile.mkdtemp(prefix="e2elf")
+    try:
+        shutil.copy(os.path.join(objdir, obj), os.path.join(d, obj))
+        subprocess.run([OBJDUMP, "--offloading", obj], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dev = [f for f in os.listdir(d) if "gfx950" in f]
+        notes = subprocess.run([readelf, "--notes", os.path.join(d, dev[0])], check=True, capture_output=True, text=True).stdout if dev else ""
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    found = 0
+    for block in notes.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name or marker not in name.group(1):
+            continue
+        found += 1
+        priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1))
+        if priv or spill:
+            raise RuntimeError("%s: %s: private segment %d bytes, %d spilled VGPRs in a ping-pong kernel" % (obj, name.group(1)[:70], priv, spill))
+    if not found:
+        raise RuntimeError("verify_no_scratch: no ping-pong instantiation found in %s (mangled-name marker changed?)" % obj)
+    return found
 
 
 def _kernels(isa):

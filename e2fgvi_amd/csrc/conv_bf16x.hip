@@ -77,6 +77,26 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8&
     e2_split8(v0, v1, hi, mid, lo);
 }
 
+// LDS-DMA piece through inline asm (the PP loop): hipcc neither counts the load nor waits for it -- with the builtin it put an
+// s_waitcnt vmcnt(0) in front of the first ds_read behind every barrier (any LDS read may alias an outstanding LDS-DMA write), which
+// exposes the whole DMA latency in the interval that issued it.  The loop's own vmcnt(0) in front of the barrier behind which the stage
+// is first read is the only wait.  M0 = LDS byte address of the piece (wave-uniform), saved / restored (cdna_hip_programming.md 5.7).
+typedef int pp_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pp_i32x4 pp_rsrc_words(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    pp_i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void pp_dma16(pp_i32x4 rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+
 // Two LDS stages: the DMA of step s+1 flies during the MFMAs of step s and is drained at the barrier that ends step s.
 // (A third stage with counted vmcnt waits was measured slower on every layer -- it costs the second resident workgroup --
 // and was removed, profiles/r02_bf16x_conv_microbench.txt.)
@@ -98,10 +118,18 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8&
 // MODE 1's (fp32 rows, same DMA, same swizzle): a lane reads its 8 consecutive channels as two 16-byte chunks and splits
 // them in registers (44 VALU per fragment, shared by the 6 x TN MFMAs it feeds); the weights are split once, at packing
 // time, into three bf16 planes: a B stage is [3 planes][4 k-octets][BN][8 bf16].
-template <int BM, int BN, int WGM, int WGN, bool S3, int MODE>
+// PP (round 6, MODE 2 only, 8-wave tiles; tile codes 107 / 108): the two waves of a SIMD (w and w + 4) run ONE INTERVAL APART, locked by
+// a barrier per interval (four per K-step): while one half of the workgroup multiplies a 16-channel unit (48 MFMAs + the B-plane reads
+// on the 256x256 tile), the other half reads and splits the A fragments of its next unit (VALU + LDS), then they swap -- the regime
+// MI355X_MICROARCH.md describes under "Two waves per SIMD": a SIMD's matrix pipe and its VALU run side by side only when its two waves
+// are in complementary segments; with one barrier per step both waves split, then both multiply.  Same products in the same order:
+// BIT-IDENTICAL to tiles 7 / 8 (tests/test_gpu_x3.py).  Measured (tools/probe/pp_ab.py, alternating rounds, one process): fc1 94.3 ->
+// 85.0 us, qkv 70.5 -> 66.7, sc 253.0 -> 240.2; the interval timeline: tools/probe/pp_probe.py, profiles/r06_x3_gemm_pingpong.txt.
+template <int BM, int BN, int WGM, int WGN, bool S3, int MODE, bool PP = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin takes an address_space(3) pointer the host pass cannot form
     constexpr bool F32 = MODE == 1, X3 = MODE == 2;
+    static_assert(!PP || (X3 && !S3 && WGM * WGN == 8), "ping-pong halves: split-operand mode, 8 waves, no row-shift stages");
     constexpr int NT = 64 * WGM * WGN;
     constexpr int ESZ = MODE ? 4 : 2;                           // activation element size
     constexpr int CH = 16 / ESZ;                                // channels per 16-byte chunk
@@ -362,6 +390,108 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if constexpr (PP) {
+        // (host: PP tiles reject tap-packed weights)
+        // Unit of the exchange = HALF a K-step (one k-octet pair kk: 16 channels): the fragments of one unit are 3 TM operand
+        // registers-of-4 -- with those of a whole step the 256x256 tile spilled 350 registers.  Per step four intervals, a barrier
+        // behind each:   leading half:  M(kk0)  P(kk1)  M(kk1)  P(kk0 of the next step)
+        //                trailing half: P(kk0)  M(kk0)  P(kk1)  M(kk1)
+        const bool trail = wave >= 4;                              // wave-uniform: waves w and w + 4 share a SIMD
+        bf16x8 fa[TM][3];                                          // the unit's A fragments: [row tile][hi, mid, lo]
+        auto pp_bar = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto prep = [&](const unsigned char* st, const int kk) __attribute__((always_inline)) {
+            const int q = 2 * kk + h;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = a_row[tm];
+                const int rd = row * 128, key = (row >> 1) & 7;
+                split8(*reinterpret_cast<const f32x4*>(st + rd + (((2 * q) ^ key) << 4)),
+                       *reinterpret_cast<const f32x4*>(st + rd + (((2 * q + 1) ^ key) << 4)), fa[tm][0], fa[tm][1], fa[tm][2]);
+            }
+        };
+        // the B planes of column tile tn are read one tile ahead of their six TM MFMAs (two fragment sets; the fences keep hipcc from
+        // hoisting every read of the phase to its top)
+        auto mma = [&](const unsigned char* stb, const int kk) __attribute__((always_inline)) {
+            const int q = 2 * kk + h;
+            bf16x8 bq[2][3];
+            auto rd = [&](int tn, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+                b[0] = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + q * (BN * 16));
+                b[1] = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + (4 + q) * (BN * 16));
+                b[2] = *reinterpret_cast<const bf16x8*>(stb + b_rd[tn] + (8 + q) * (BN * 16));
+            };
+            rd(0, bq[0]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if (tn + 1 < TN) rd(tn + 1, bq[(tn + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);      // the reads stay HERE, twelve MFMAs ahead of their use (hipcc sank them to two MFMAs ahead)
+                const bf16x8 bh = bq[tn & 1][0], bm = bq[tn & 1][1], bl = bq[tn & 1][2];
+                // the order of compute(): smallest terms first, the TM accumulators of a term are independent
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][2], bh, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], bl, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], bm, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][1], bh, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], bm, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm][0], bh, acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // ONE instruction stream for both halves -- P(kk0) | M(kk0) | P(kk1) | M(kk1) per step, a barrier behind each -- and the trailing
+        // half runs it ONE INTERVAL LATER (an extra barrier in front of its loop, one behind the leading half's).  (With the roles
+        // switched by branches around the MFMAs -- `if (lead) mma else prep` -- hipcc no longer kept the 128 accumulator registers in
+        // place across the joins: 414 spilled registers on the 256x256 tile; with advance / retarget / issue wrapped in one more lambda
+        // it copied the kernel arguments to scratch.)  In global intervals t (leading half: P(2s) at t = 4s, trailing half one later):
+        // stage s - 1's last reader is the trailing M(2s - 1) at t = 4s, stage s + 1's first reader the leading P(2s + 2) at t = 4s + 4.
+        // The trailing half issues its share of stage s + 1 at the top of its step (t = 4s + 1, its P(2s) interval), the leading half
+        // in its P(2s + 1) interval (t = 4s + 2) -- never inside a multiply interval, where ten asm pieces cost ~800 cycles -- and both
+        // wait for their pieces in front of the barrier that ends t = 4s + 3 (leading: its fourth of the step, trailing: its third).
+        const unsigned smem_lds = (unsigned)(unsigned long long)(lds_void*)smem;
+        const pp_i32x4 wrsrc_w = pp_rsrc_words(reinterpret_cast<const char*>(p.w) + (long long)g * p.wgroup_bytes, p.wgroup_bytes);
+        auto pp_issue = [&](int stage, int step) __attribute__((always_inline)) {       // issue_a(stage) + issue_b(stage, step), through asm
+            const pp_i32x4 arsrc_w = pp_rsrc_words(cur_src, cur_bytes);
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(c0 * ESZ);
+            const unsigned la = smem_lds + (unsigned)(stage * A_BYTES + wave * 1024);
+            const bool whole = c0 + KC <= cur_cpg;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it)
+                pp_dma16(arsrc_w, (unsigned)__builtin_amdgcn_readfirstlane((int)(la + it * NT * 16)),
+                         (whole || c0 + (int)(a_ch16[it] / ESZ) < cur_cpg) ? a_off[it] : OOB, soff);
+            const unsigned lb = smem_lds + (unsigned)(2 * A_BYTES + stage * B_BYTES + wave * 1024);
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)step * b_step));
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                if (!B_PART || it + 1 < B_IT || tid + it * NT < BN * B_CH)
+                    pp_dma16(wrsrc_w, (unsigned)__builtin_amdgcn_readfirstlane((int)(lb + it * NT * 16)), b_off[it], sb);
+        };
+        if (trail) pp_bar();
+        for (int step = 0; step < p.nsteps; ++step) {
+            const int cur = step & 1;
+            const unsigned char* const sA = smem + cur * A_BYTES;
+            const unsigned char* const sB = smem_b + cur * B_BYTES;
+            if (trail) { if (step + 1 < p.nsteps) { if (advance()) retarget(); pp_issue((step & 1) ^ 1, step + 1); } }
+            prep(sA, 0);
+            pp_bar();
+            mma(sB, 0);
+            pp_bar();
+            prep(sA, 1);
+            if (!trail) { if (step + 1 < p.nsteps) { if (advance()) retarget(); pp_issue((step & 1) ^ 1, step + 1); } }
+            if (trail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pp_bar();
+            mma(sB, 1);
+            if (!trail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pp_bar();
+        }
+        if (!trail) pp_bar();
+    } else
     if constexpr (!S3) {
         if (p.tp_cq) {
             // Tap-packed K-steps: a source of fewer than 64 channels (bf16; fp32: 32 channels per step, 4 per chunk -- the same
@@ -766,10 +896,19 @@ __global__ void pack_conv_weight_x3_kernel(const float* __restrict__ w, unsigned
     o[2 * plane] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool S3>
+template <int BM, int BN, int WGM, int WGN, bool S3, bool PP = false>
 int launch_x(ConvXParams& p, int groups, hipStream_t st, int mode = 0) {
     p.tilesM = cdiv(p.M, BM);
     p.tilesN = cdiv(p.Cout_g, BN);
+    if constexpr (PP) {
+        if (mode != 2 || p.tp_cq) {
+            e2fgvi_set_error("conv2d_x: the ping-pong tiles (107, 108) are for the split-operand mode without tap-packed weights");
+            return E2FGVI_EUNSUP;
+        }
+        hipLaunchKernelGGL((conv_bf16x_kernel<BM, BN, WGM, WGN, false, 2, true>), dim3(p.tilesM * p.tilesN, groups, 1), dim3(64 * WGM * WGN), 0, st, p);
+        E2_LAUNCH_CHECK("conv2d_x");
+        return 0;
+    } else {
     if (S3 && !(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1)) {
         e2fgvi_set_error("conv2d_bf16x: the row-shift tiles (11..17) are for 3x3 stride-1 pad-1 layers");
         return E2FGVI_EINVAL;
@@ -789,6 +928,7 @@ int launch_x(ConvXParams& p, int groups, hipStream_t st, int mode = 0) {
     }
     E2_LAUNCH_CHECK("conv2d_x");
     return 0;
+    }
 }
 
 }  // namespace
@@ -1048,6 +1188,9 @@ static int conv2d_x(const e2fgvi_convx_desc* d, void* stream, int mode) {
         case 6: return launch_x<256, 128, 4, 2, false>(p, d->groups, st, mode);
         case 7: return launch_x<256, 256, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 128): half the DMA per FLOP of tile 1
         case 8: return launch_x<256, 192, 4, 2, false>(p, d->groups, st, mode);     // 8 waves x (64 x 96): N = 1536 in 8 column tiles (qkv: 232 instead of 174 workgroups)
+        // split-operand mode with the two halves of the workgroup half a step apart (kernel comment, PP)
+        case 107: return launch_x<256, 256, 4, 2, false, true>(p, d->groups, st, mode);
+        case 108: return launch_x<256, 192, 4, 2, false, true>(p, d->groups, st, mode);
         // 3x3 stride-1 pad-1 layers: the three horizontal taps share one A stage (row-shifted reads)
         case 11: return launch_x<128, 128, 2, 2, true>(p, d->groups, st, mode);
         case 12: return launch_x<128, 64, 2, 2, true>(p, d->groups, st, mode);

@@ -51,7 +51,7 @@ W4_CODES = {2464: (2, 64)}
 _W4_MINPIX = 20000          # output pixels from which PackedConv._wino4_rule hands a qualifying layer to F(2x4)
 # bf16 data path (conv_bf16x): 128x128, 64x128, 256x128 and 256x256 (8 waves), 128x64, 64x64, 128x32 tiles; tile codes +10
 # are the row-shift variants for 3x3 stride-1 pad-1 layers (the three horizontal taps share one A stage).
-XTUNE_CANDIDATES = (1, 4, 6, 7, 8, 2, 5, 3)
+XTUNE_CANDIDATES = (1, 4, 6, 7, 8, 2, 5, 3, 107, 108)     # 107 / 108: the ping-pong forms of 7 / 8, split-operand layers only (others: EUNSUP, skipped)
 XTUNE_ROWSHIFT = (11, 16, 17, 12, 13, 18)
 # fp32 layers on the bf16 matrix pipe by exact operand splitting (conv_bf16x.hip MODE 2, PackedConvX(x3=True)): a tuning
 # alternative of every fp32 layer that asks for it (PackedConv.try_x3 / PackedConvX.try_x3); taken when its best tile beats

@@ -387,7 +387,8 @@ int e2fgvi_pack_conv_weight_f32x(const float* w, float* wpacked, int32_t Cout, i
  * e2fgvi_conv2d_f32x; every weight is stored as three bf16 numbers whose sum is the fp32 weight bit for bit (hi / mid / lo,
  * 8 significand bits each), every activation is split the same way in registers, and of the nine bf16 products of a*b the six
  * largest are accumulated by v_mfma_f32_32x32x16_bf16 in fp32 (the three dropped ones are < 2^-22 |a*b| together): fp32-level
- * rounding at 2.7x the fp32 MFMA rate.  Same descriptor, tile codes 1..7; wpacked holds 3 x the fp32 element count, in bf16
+ * rounding at 2.7x the fp32 MFMA rate.  Same descriptor, tile codes 1..8 and 107 / 108 (the 256x256 / 256x192 tiles with the two
+ * halves of the workgroup one K-half-step apart: same bits as 7 / 8, not for tap-packed weights); wpacked holds 3 x the fp32 element count, in bf16
  * ([group][K-step][plane][4 k-octets][Npad][8]).  Replaces the same reference calls as e2fgvi_conv2d_nhwc (nn.Conv2d /
  * nn.Linear of model/e2fgvi_hq.py, model/modules/tfocal_transformer_hq.py). */
 int e2fgvi_conv2d_f32x3(const e2fgvi_convx_desc* d, void* stream);

@@ -164,6 +164,42 @@ def test_forwards_in_flight_return_the_bits_of_the_serial_forward(dev, model, hw
     assert step.graphed and step.in_flight == k and none <= k and got >= 60 - k - 1
 
 
+@pytest.mark.parametrize("tile,ref_tile", [(107, 7), (108, 8)])
+def test_ping_pong_gemm_beside_device_copies_returns_the_bits_of_the_one_barrier_tile(dev, tile, ref_tile):
+    """conv_bf16x.hip PP (round 6): LDS-DMA through inline asm, raw s_barrier, the kernel's own vmcnt waits -- the discipline the wide-tile
+    Winograd kernel needed C4's guards for.  With 256 MB device copies on a second stream (slow, late operand traffic) every launch
+    must return the bits of the one-barrier tile's launch alone: a stage read before its pieces have landed, or overwritten while
+    its trailing readers are still on it, shows up here.  Shapes: fc1 (K = 512: 16 steps), the SoftSplit convolution (7x7 stride 3,
+    retargets per tap: 196 steps) and a two-source 1x1 layer (the source walk)."""
+    from e2fgvi_amd import ops
+    g = gen(4100 + tile)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    cases = [("fc1", [rnd(7200, 1, 1, 512)], ops.PackedConvX(rnd(1960, 512, 1, 1) * 0.05, rnd(1960), [512], dtype=torch.float32, x3=True)),
+             ("ss", [rnd(10, 60, 108, 128)], ops.PackedConvX(rnd(512, 128, 7, 7) * 0.02, rnd(512), [128], stride=3, pad=3, dtype=torch.float32, x3=True)),
+             ("fusion", [rnd(10, 60, 108, 128), rnd(10, 60, 108, 128)], ops.PackedConvX(rnd(256, 256, 1, 1) * 0.06, rnd(256), [128, 128], dtype=torch.float32, x3=True))]
+    big_a, big_b = torch.empty(64 << 20, device=dev), torch.empty(64 << 20, device=dev)
+    big_a.normal_()
+    side, main = torch.cuda.Stream(device=dev), torch.cuda.current_stream()
+    for name, srcs, layer in cases:
+        ref = layer(srcs, tile=ref_tile).clone()
+        torch.cuda.synchronize()
+        outs = [torch.empty_like(ref) for _ in range(PER_ROUND)]
+        bad = 0
+        for _ in range(LAUNCHES // PER_ROUND):
+            for o in outs:
+                o.fill_(float("nan"))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(3 * PER_ROUND):
+                    big_b.copy_(big_a, non_blocking=True)
+            for o in outs:
+                layer(srcs, out=o, tile=tile)
+            main.wait_stream(side)
+            torch.cuda.synchronize()
+            bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+        assert bad == 0, "%s, tile %d: %d of %d launches beside device copies differ from tile %d alone" % (name, tile, bad, LAUNCHES, ref_tile)
+
+
 _C8_SCRIPT = r"""
 import importlib, sys, torch
 sys.path.insert(0, %r)

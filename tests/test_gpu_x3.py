@@ -35,10 +35,14 @@ def test_conv_x3(dev, case):
     src_d = [(s.to(dev), 4) for s in srcs]
     res = torch.randn(N, ref0.shape[2], ref0.shape[3], Cout, generator=g)
     ref = F.leaky_relu(ref0 + nchw(res), 0.1)
-    for tile in sorted(set(t for t in tiles if t < 10) | {1, 5, 7, 8}):
+    outs = {}
+    for tile in sorted(set(t for t in tiles if t < 10) | {1, 5, 7, 8, 107, 108}):
         out = layer(src_d, residual=res.to(dev), act=ops.ACT_LRELU, slope=0.1, tile=tile)
         assert out.dtype == torch.float32
         assert_close(nchw(out.cpu()), ref, fp32_tol(sum(cpg) * k * k), "%s x3 tile %d" % (name, tile))
+        outs[tile] = out.clone()
+    # the ping-pong forms (round 6: the two waves of a SIMD one interval apart) issue the products of tiles 7 / 8 in the same order
+    assert torch.equal(outs[107], outs[7]) and torch.equal(outs[108], outs[8]), "%s: tiles 107 / 108 are not bit-identical to 7 / 8" % name
     with pytest.raises(Exception):
         layer(src_d, tile=11)               # the row-shift tiles are bf16-only
 
@@ -154,6 +158,11 @@ def test_x3_reruns_are_bit_identical(dev):
     for _ in range(100):
         bad += int(not torch.equal(l3([x], tile=7), first))
     assert bad == 0, "%d of 100 launches differ" % bad
+    # the ping-pong forms (asm LDS-DMA, raw barriers, their own waits): 200 launches each, the bits of tile 7 / tile 8's first launch
+    first8 = l3([x], tile=8).clone()
+    for tile, want in ((107, first), (108, first8)):
+        bad = sum(int(not torch.equal(l3([x], tile=tile), want)) for _ in range(200))
+        assert bad == 0, "tile %d: %d of 200 launches differ from the one-barrier tile" % (tile, bad)
 
 
 def test_fp32_layers_may_pick_the_split_kernel(dev):
@@ -393,7 +402,7 @@ def test_qkv_epilogue_writes_the_attention_planes(dev, rows):
     layer = ops.PackedConvX(w, b, [512], dtype=torch.float32, x3=True)
     x4 = x.view(rows, 1, 1, 512)
     ran = 0
-    for tile in (1, 2, 4, 5, 6, 7, 8):
+    for tile in (1, 2, 4, 5, 6, 7, 8, 107, 108):
         full = torch.empty(rows, 1, 1, 1536, device=dev)
         try:
             layer([x4], out=full, tile=tile)

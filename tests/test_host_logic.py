@@ -276,7 +276,10 @@ def test_kernel_table_invariants_and_nearest_size_class_lookup(monkeypatch):
         elif 2000 <= v < 2100:
             assert v - 2000 in ops.XTUNE_CANDIDATES, (k, v)
     # round 5: the qkv Linear on the 256x192 tile, SPyNet layers and the propagation split's layers among the decisions
-    assert any(v == ops.X3_BASE + 8 for v in tile_table.TILES.values())
+    # round 6: ... on the ping-pong form of that tile; no split-operand entry still names the one-barrier tiles 7 / 8 except the
+    # tap-packed FFN convolution (the ping-pong loop does not take tap-packed weights)
+    assert any(v == ops.X3_BASE + 108 for v in tile_table.TILES.values()) and any(v == ops.X3_BASE + 107 for v in tile_table.TILES.values())
+    assert all(v not in (ops.X3_BASE + 7, ops.X3_BASE + 8) or (isinstance(k[0], str) and k[0].startswith("x32+")) for k, v in tile_table.TILES.items())
     assert any(k[0] != "x" and k[2] == 7 and v >= ops.X3_BASE for k, v in tile_table.TILES.items()), "no SPyNet layer on the split-operand GEMM"
     assert any(k[0] != "x" and k[1] == (128, 128, 4) for k in tile_table.TILES), "the recurrent part of conv_offset.0 is not tabled"
     if ops.AUTOTUNE:
@@ -365,6 +368,11 @@ def test_registers_of_loads_in_flight_behind_the_k_loop_are_not_reused():
         # every Winograd kernel of the three objects, 8 (or 4) wave roles each: 4 fp32 F(2x2) shapes, 3 + 1 + 1 split-operand kernels,
         # F(2x4) x 64 (round 6 pruned 5 instantiations: 76 exits, before 116)
         assert build.verify_exit_reuse() >= 76
+    if os.path.exists(build.OBJDUMP) and os.path.exists(os.path.join(build.CSRC, "build", "conv_bf16x.o")):
+        # round 6: the two ping-pong instantiations of the split-operand GEMM hold their accumulators in place: no private segment, no spills
+        assert build.verify_no_scratch() == 2
+        with pytest.raises(RuntimeError, match="no ping-pong instantiation"):
+            build.verify_no_scratch(marker="ELb0ELi9ELb1EEE")
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")

@@ -1,5 +1,6 @@
-"""Interval timeline of the ping-pong split-operand GEMM (tools/probe/conv_bf16x_pingpong.patch built with -DE2_PP_PROBE=1 into
-csrc/libe2fgvi_hip_pp.so):   E2FGVI_LIB=e2fgvi_amd/csrc/libe2fgvi_hip_pp.so python tools/probe/pp_probe.py [tile]
+"""Interval timeline of the ping-pong split-operand GEMM (csrc/conv_bf16x.hip, PP).  Build the stamps in:
+    patch -p0 < tools/probe/conv_bf16x_pingpong_probe.patch && python -c "from e2fgvi_amd import build; build.build_variant('pp', '-DE2_PP_PROBE=1')" && git checkout e2fgvi_amd/csrc/conv_bf16x.hip
+    E2FGVI_LIB=e2fgvi_amd/csrc/libe2fgvi_hip_pp.so python tools/probe/pp_probe.py [tile]
 Workgroup 0's waves 0 (leading half) and 4 (trailing half, same SIMD) stamp s_memtime around every phase of the K loop into the
 layer's bias buffer (the output of that launch is garbage).  Prints, per K-step, the cycles of P0 | bar | M0 | bar | P1 | bar | M1 | bar."""
 import os, sys
