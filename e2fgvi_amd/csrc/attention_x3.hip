@@ -321,6 +321,12 @@ __global__ __launch_bounds__(64 * NW * KS, 1) void focal_attn_x3_kernel(const fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int cur = 0;
+        // round 6: the two key groups (waves w and w + NW share a SIMD) ONE PHASE APART: while group 0 is in its S phase (QK^T MFMAs, then the
+        // softmax's VALU) group 1 is in its PV phase (the split's VALU, then the PV MFMAs) and vice versa -- complementary halves per SIMD
+        // (conv_bf16x.hip PP, MI355X_MICROARCH.md "Two waves per SIMD").  The rings are per group, the barriers per workgroup: group 1
+        // passes one extra barrier in front of its loop, group 0 one behind its loop; nothing else moves.  Same bits; 165.8 -> 159.4 us
+        // per block at the headline shape (tools/probe/att_ab.py).
+        if (kg == 1) __syncthreads();
         for (int itr = 0; itr < nIter; ++itr) {
             const int kt = kg + itr * KS;                             // may be == ntiles for the last group: an all-masked tile
             const bool more = itr + 1 < nIter;
@@ -336,6 +342,7 @@ __global__ __launch_bounds__(64 * NW * KS, 1) void focal_attn_x3_kernel(const fl
             if (more) issue_half(kt + KS, 6u * X_KB, true);           // V of the next tile: lands under its S products and softmax
             cur ^= 1;
         }
+        if (kg == 0) __syncthreads();
         // merge the key groups: O = sum_g 2^(m_g - m) O_g, l likewise (attention.hip); group 1 parks its state in its own ring
         float* scr = reinterpret_cast<float*>(smem + RING);
         if (kg > 0) {
