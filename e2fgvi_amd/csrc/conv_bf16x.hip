@@ -393,9 +393,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_bf16x_kernel(const ConvXP
     if constexpr (PP) {
         // (host: PP tiles reject tap-packed weights)
         // Unit of the exchange = HALF a K-step (one k-octet pair kk: 16 channels): the fragments of one unit are 3 TM operand
-        // registers-of-4 -- with those of a whole step the 256x256 tile spilled 350 registers.  Per step four intervals, a barrier
-        // behind each:   leading half:  M(kk0)  P(kk1)  M(kk1)  P(kk0 of the next step)
-        //                trailing half: P(kk0)  M(kk0)  P(kk1)  M(kk1)
+        // registers-of-4 -- with those of a whole step the 256x256 tile spilled 350 registers.  Four intervals per step, a barrier
+        // behind each; side by side in time:   leading half:  P(kk0)       M(kk0)  P(kk1)  M(kk1)
+        //                                     trailing half: M(kk1, s-1)  P(kk0)  M(kk0)  P(kk1)
         const bool trail = wave >= 4;                              // wave-uniform: waves w and w + 4 share a SIMD
         bf16x8 fa[TM][3];                                          // the unit's A fragments: [row tile][hi, mid, lo]
         auto pp_bar = [&]() __attribute__((always_inline)) {
